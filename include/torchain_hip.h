@@ -1,0 +1,145 @@
+/*
+ * torchain_hip.h -- C ABI of the MI355X-native LF-MMI chain loss (libtorchain_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of nttcslab-sp/torchain: the chain objective and its
+ * derivative.  Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository).  Plain pointers and sizes only: no torch / TH types, no C++ exceptions
+ * across the boundary; all functions that can fail return 0 (TC_OK) or a negative TC_ERR_* code.
+ *
+ * Conventions (same as the reference, torchain/functions.py:27-30, src/my_lib_chain.cpp:104-136):
+ *   nnet_output is a (num_sequences*frames_per_sequence) x num_pdfs fp32 matrix in DEVICE memory,
+ *   row = frame * num_sequences + sequence ("all sequences for frame 0; all for frame 1; ..."),
+ *   unit column stride, row stride >= num_pdfs (in elements).  All tensors are borrowed for the
+ *   duration of the call and never retained.  Work is enqueued on `stream` (a hipStream_t passed as
+ *   void*) of `device`; no entry point synchronises the host.
+ */
+#ifndef TORCHAIN_HIP_H_
+#define TORCHAIN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TC_OK 0
+#define TC_ERR_INVALID_ARGUMENT (-1)  /* null pointer, bad dims/stride, leaky not in (0,1)        */
+#define TC_ERR_BAD_FST (-2)           /* state/label out of range, arcs not state-major, ...      */
+#define TC_ERR_UNSUPPORTED (-3)       /* graph or supervision too large for the on-chip layout    */
+#define TC_ERR_WORKSPACE (-4)         /* workspace missing or smaller than tc_*_workspace_bytes   */
+#define TC_ERR_HIP (-5)               /* a HIP runtime call failed (see tc_last_hip_error)        */
+#define TC_ERR_IO (-6)                /* file could not be read / is not an OpenFst vector FST    */
+#define TC_ERR_NOT_SEPARABLE (-7)     /* merged supervision FST does not factor per sequence      */
+
+typedef struct tc_den_graph tc_den_graph;     /* replaces the void* to kaldi::chain::DenominatorGraph */
+typedef struct tc_supervision tc_supervision; /* replaces the void* to kaldi::chain::Supervision      */
+
+const char *tc_strerror(int code);
+int tc_version(void);
+int tc_last_hip_error(void);
+
+/* ---- denominator graph ------------------------------------------------------------------- */
+
+/* Replaces my_lib_denominator_graph_new (src/my_lib.h:29, src/my_lib_example.cpp:129-134) for an FST
+ * already in memory.  Arcs are listed state-major in the order an OpenFst ArcIterator yields them;
+ * ilabel = pdf_id + 1; weights are tropical (-log prob); final_weight[s] = +inf for a non-final
+ * state.  Builds the transition tables, the 100-iteration initial-probability estimate and the
+ * wavefront schedules used by the kernels.  Host only; touches no GPU. */
+int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs, const int32_t *arc_src,
+                        const int32_t *arc_dst, const int32_t *arc_ilabel, const float *arc_weight,
+                        const float *final_weight, int32_t start_state, int32_t num_pdfs);
+
+/* Replaces my_lib_denominator_graph_new(rxfilename, num_pdf) (src/my_lib.h:29) for a den.fst on disk:
+ * reads an OpenFst binary VectorFst<StdArc> file (what fst::ReadFstKaldi accepts for a plain
+ * filename) and calls tc_den_graph_create. */
+int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pdfs);
+
+/* Replaces my_lib_denominator_graph_free (src/my_lib.h:30). */
+void tc_den_graph_free(tc_den_graph *graph);
+
+int32_t tc_den_graph_num_states(const tc_den_graph *graph);
+int64_t tc_den_graph_num_arcs(const tc_den_graph *graph);
+int32_t tc_den_graph_num_pdfs(const tc_den_graph *graph);
+/* Copies the num_states initial probabilities ([K] DenominatorGraph::InitialProbs) to host memory. */
+int tc_den_graph_initial_probs(const tc_den_graph *graph, float *out_host);
+
+/* Uploads the graph's immutable tables to `device` (idempotent, thread-safe).  The hot calls do this
+ * on first use; call it at init to keep allocation out of the first step.  One copy per device:
+ * this is what makes a single graph handle usable from every rank/GPU (the reference cannot:
+ * example/chime5/parallel_train.py:27-31,47). */
+int tc_den_graph_prepare(tc_den_graph *graph, int device);
+
+/* ---- supervision -------------------------------------------------------------------------- */
+
+/* Replaces my_lib_supervision_new (src/my_lib.h:21, src/my_lib_example.cpp:71-76): builds the handle
+ * from the five fields of [K] chain::Supervision the path uses (weight, num_sequences,
+ * frames_per_sequence, label_dim, fst).  The FST is the merged, epsilon-free, time-sorted acceptor
+ * in CSR form: state i owns arcs [arc_begin[i], arc_begin[i+1]); start state 0; ilabel = pdf_id + 1;
+ * final_weight[i] = +inf when state i is not final.  The handle splits the FST into its
+ * num_sequences independent per-sequence acceptors (TC_ERR_NOT_SEPARABLE if it does not factor). */
+int tc_supervision_create(tc_supervision **out, float weight, int32_t num_sequences,
+                          int32_t frames_per_sequence, int32_t label_dim, int32_t num_states,
+                          const int32_t *arc_begin, const int32_t *arc_ilabel, const float *arc_weight,
+                          const int32_t *arc_nextstate, const float *final_weight);
+
+/* Replaces my_lib_supervision_free (src/my_lib.h:22). */
+void tc_supervision_free(tc_supervision *supervision);
+/* Replace my_lib_supervision_num_pdf / _num_sequence / _num_frame (src/my_lib.h:23-25). */
+int32_t tc_supervision_num_pdf(const tc_supervision *supervision);
+int32_t tc_supervision_num_sequence(const tc_supervision *supervision);
+int32_t tc_supervision_num_frame(const tc_supervision *supervision);
+float tc_supervision_weight(const tc_supervision *supervision);
+
+/* Copies the supervision's arc tables to `device` on `stream` (asynchronously, idempotent). */
+int tc_supervision_prepare(tc_supervision *supervision, int device, void *stream);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+
+/* Bytes of device scratch the calls below need for this problem size (alpha history etc.). */
+int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);
+
+/* Replaces my_lib_ComputeChainObjfAndDeriv (src/my_lib.h:33-42, src/my_lib_chain.cpp:104-136), i.e.
+ * [K] chain::ComputeChainObjfAndDeriv:
+ *   objf = w*num - w*den;  weight = w*S*T;  l2_term = -0.5*w*l2*sum(y^2)
+ *   deriv = w*gamma_num - w*gamma_den - w*l2*y      (written, not accumulated; may be NULL)
+ *   xent_deriv = w*gamma_num                        (written when non-NULL)
+ * and on NaN/inf or a failed alpha.beta check: deriv = xent_deriv = 0, objf = -10*weight.
+ * results_dev3 is DEVICE memory for {objf, l2_term, weight} (the reference writes a CPU
+ * THFloatTensor, src/my_lib_chain.cpp:126,130; the host wrapper copies the 12 bytes). */
+int tc_chain_objf_and_deriv(tc_den_graph *graph, tc_supervision *supervision, const float *nnet_output,
+                            int64_t num_rows, int32_t num_cols, int64_t row_stride, float *results_dev3,
+                            float *nnet_output_deriv, int64_t deriv_stride, float *xent_output_deriv,
+                            int64_t xent_stride, float l2_regularize, float leaky_hmm_coefficient,
+                            float xent_regularize, void *workspace, int64_t workspace_bytes, int device,
+                            void *stream);
+
+/* The benchmarked unit: [K] DenominatorComputation::Forward() + Backward(deriv_weight, deriv)
+ * (direct use in the reference: src/chain-supervision-test.hpp:403-414).
+ *   logprob_dev   : device double[1], sum over sequences of the denominator log-prob
+ *   deriv         : nullable; accumulate != 0 -> deriv += deriv_weight*gamma (Kaldi's semantics),
+ *                   accumulate == 0 -> deriv  = deriv_weight*gamma - l2_scale*y (one store per element)
+ *   status_dev    : nullable device int32[1], set to 0 when the t=0 checks pass, else nonzero
+ */
+int tc_den_forward_backward(tc_den_graph *graph, int32_t num_sequences, const float *nnet_output,
+                            int64_t num_rows, int32_t num_cols, int64_t row_stride,
+                            float leaky_hmm_coefficient, float deriv_weight, float l2_scale, int accumulate,
+                            float *deriv, int64_t deriv_stride, double *logprob_dev, int32_t *status_dev,
+                            void *workspace, int64_t workspace_bytes, int device, void *stream);
+
+/* [K] NumeratorComputation::Forward() + Backward() (src/chain-supervision-test.hpp:99-107):
+ *   logprob_dev : device double[1] = weight * log Z_num
+ *   deriv       : nullable; deriv[row, pdf] += weight * occupation at the supervision's (row, pdf)s */
+int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_output, int64_t num_rows,
+                            int32_t num_cols, int64_t row_stride, float *deriv, int64_t deriv_stride,
+                            double *logprob_dev, void *workspace, int64_t workspace_bytes, int device,
+                            void *stream);
+
+/* Diagnostics for bench.py / DESIGN.md: copies a few schedule statistics of the graph
+ * (out[0]=padded forward arc slots, out[1]=padded backward arc slots, out[2]=LDS bytes of the fused
+ * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows). */
+int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCHAIN_HIP_H_ */

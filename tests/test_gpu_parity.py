@@ -1,0 +1,176 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Tolerance: BASELINE.json's north_star asks for objf / l2_term / d objf/d nnet_output "within 1e-4
+relative" of the Kaldi CPU arithmetic; every comparison below uses REL = 1e-4 (scalars: relative to
+the oracle's value; matrices: max abs difference relative to the oracle's max abs entry).
+"""
+import numpy as np
+import pytest
+import torch
+
+from torchain_amd import synth
+
+from helpers import hip_chain, hip_den, rel_err
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _check_full(oracle, fst, S, T, l2, leaky, weight=1.0, seed=5, zero=False, row_pad=0, paths=3):
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, paths, seed=seed + 2, weight=weight, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=seed, zero=zero)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, l2, leaky, want_xent=True)
+    out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True, row_pad=row_pad)
+    res = out["results"]
+    assert abs(res[0] - ref["objf"]) <= REL * abs(ref["objf"]), (res, ref["results"])
+    assert abs(res[1] - ref["l2_term"]) <= REL * max(abs(ref["l2_term"]), 1e-30), (res, ref["results"])
+    assert res[2] == ref["weight"] == weight * S * T  # README.md:12-32 pins weight = w*S*T
+    assert rel_err(out["deriv"], ref["deriv"]) <= REL
+    assert rel_err(out["xent_deriv"], ref["xent_deriv"]) <= REL
+    return out, ref
+
+
+def test_config1_full_objective(oracle):
+    """BASELINE.json configs[0]: batch 16, 50 frames, 200 pdf-ids, random 3-state left-to-right den.fst."""
+    c = synth.CONFIGS["C1"]
+    fst = synth.config_den_fst("C1")
+    for leaky in (1e-5, 0.2):  # the two values the reference's test draws (chain-supervision-test.hpp:253-255)
+        _check_full(oracle, fst, c["S"], c["T"], l2=5e-5, leaky=leaky)
+
+
+def test_supervision_weight_half(oracle):
+    """supervision.weight = 0.5 as in my_lib_chain.cpp:198-199."""
+    _check_full(oracle, synth.config_den_fst("C1"), 5, 17, l2=1e-3, leaky=0.1, weight=0.5)
+
+
+def test_zero_nnet_output(oracle):
+    """The all-zero nnet output the reference tests with p = 1/4 (chain-supervision-test.hpp:397-399)."""
+    _check_full(oracle, synth.random_den_fst(96, 5, 40, seed=9), 4, 23, l2=0.0, leaky=1e-5, zero=True)
+
+
+@pytest.mark.parametrize("H,deg,P,S,T", [(1, 1, 1, 1, 2), (7, 3, 5, 1, 1), (130, 4, 77, 3, 9), (1000, 6, 300, 5, 31)])
+def test_ragged_small_shapes(oracle, H, deg, P, S, T):
+    """Odd sizes: P and H not multiples of 4 (scalar row path), one state, one frame, one sequence."""
+    _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
+
+
+def test_unaligned_row_stride(oracle):
+    """Row stride > num_pdfs and not a multiple of 4: the C ABI takes (rows, cols, row_stride)
+    like common::make_matrix (src/common.hpp:109-117)."""
+    _check_full(oracle, synth.random_den_fst(64, 4, 32, seed=3), 3, 8, l2=1e-4, leaky=0.1, row_pad=3)
+
+
+def test_skewed_graph_row_splitting(oracle):
+    """Hub states with hundreds of in/out arcs, arbitrary arc->pdf labels, non-final states:
+    exercises virtual-row splitting in the schedule."""
+    fst = synth.skewed_den_fst(300, 6000, 120, seed=4)
+    _check_full(oracle, fst, 4, 15, l2=0.0, leaky=0.1)
+
+
+def test_denominator_alone_and_accumulate(oracle):
+    """[K] DenominatorComputation used directly (chain-supervision-test.hpp:403-423): log-prob,
+    Backward(1.0, &deriv) semantics (adds into deriv), sum(deriv) = S*T."""
+    fst = synth.random_den_fst(200, 6, 90, seed=11)
+    S, T = 5, 19
+    g = oracle.DenGraph(fst)
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=2)
+    ref = oracle.den_forward_backward(g, y, S, leaky=1e-5, deriv_weight=1.0)
+    out = hip_den(fst, y, S, leaky=1e-5, deriv_weight=1.0, accumulate=True, init=0.25)
+    assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+    assert out["status"] == 0 and ref["ok"]
+    assert rel_err(out["deriv"] - 0.25, ref["deriv"]) <= REL
+    assert abs(out["deriv"].sum() - 0.25 * y.size - S * T) < 10.0 * 1e-2
+    # overwrite form with the fused l2 term
+    out2 = hip_den(fst, y, S, leaky=1e-5, deriv_weight=-0.5, l2_scale=1e-3, accumulate=False)
+    assert rel_err(out2["deriv"], -0.5 * ref["deriv"] - 1e-3 * y) <= REL
+    # forward only
+    out3 = hip_den(fst, y, S, leaky=1e-5, want_deriv=False)
+    assert abs(out3["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+
+
+def test_numerical_failure_is_soft(oracle):
+    """[K] NaN/inf objf -> derivs zeroed (then the l2 derivative is added), objf = -10*weight."""
+    fst = synth.random_den_fst(40, 4, 20, seed=6)
+    S, T = 2, 6
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 2, seed=1, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=1)
+    y[3, 5] = np.nan
+    out = hip_chain(fst, sup, y, l2=0.0, leaky=1e-5, xent=True)
+    assert out["results"][0] == -10.0 * S * T
+    assert out["results"][2] == S * T
+    assert np.all(out["deriv"][np.isfinite(y)] == 0) and np.all(out["xent_deriv"] == 0)
+
+
+def test_medium_config2_shape_subset(oracle):
+    """CHiME5-like graph of config 2/3 (H=8192, A=65536, P=4096) at a batch the oracle finishes in
+    seconds; full objective."""
+    c = synth.CONFIGS["C2"]
+    fst = synth.config_den_fst("C2")
+    _check_full(oracle, fst, 6, 40, l2=c["l2"], leaky=c["leaky"])
+
+
+def test_config5_large_vocab_subset(oracle):
+    """Config 5 graph (P=10240, H=8192, A=61440): alpha' does not fit LDS next to gamma -> the
+    kernel variant that reads alpha' from the history."""
+    c = synth.CONFIGS["C5"]
+    fst = synth.config_den_fst("C5")
+    assert len(fst.src) == 61440
+    _check_full(oracle, fst, 3, 20, l2=c["l2"], leaky=c["leaky"])
+
+
+def test_full_size_properties_config3():
+    """BASELINE.json configs[2] at full size (S=256, T=150, P=4096): size-independent properties
+    the reference's own test asserts (chain-supervision-test.hpp:417-423,267-283): gamma sums to
+    one per (frame, sequence); row sums of the full derivative vanish; objf <= 0."""
+    c = synth.CONFIGS["C3"]
+    fst = synth.config_den_fst("C3")
+    S, T, P = c["S"], c["T"], c["P"]
+    y = synth.random_nnet_output(S, T, P, seed=1237)
+    out = hip_den(fst, y, S, leaky=c["leaky"], deriv_weight=1.0, accumulate=False)
+    assert out["status"] == 0
+    rows = out["deriv"].sum(axis=1, dtype=np.float64)
+    assert np.abs(rows - 1.0).max() < 1e-3
+    assert abs(out["deriv"].sum(dtype=np.float64) - S * T) < 10.0
+    assert out["deriv"].min() >= 0.0
+    # shift property of the denominator: adding r[row] to every pdf of a row adds sum(r) to the log-prob
+    r = np.random.default_rng(0).standard_normal(S * T).astype(np.float32)
+    out_s = hip_den(fst, y + r[:, None], S, leaky=c["leaky"], want_deriv=False, graph=out["graph"])
+    assert abs((out_s["logprob"] - out["logprob"]) - float(r.sum(dtype=np.float64))) < 1e-4 * abs(out["logprob"])
+    # full objective with a numerator that is a weighted subset of denominator paths
+    sup = synth.random_supervision(fst, S, T, 3, seed=7, initial_probs=out["graph"].initial_probs())
+    full = hip_chain(fst, sup, y, l2=0.0, leaky=c["leaky"], graph=out["graph"])
+    assert full["results"][0] <= 0.0
+    assert full["results"][2] == S * T
+    rs = full["deriv"].sum(axis=1, dtype=np.float64)
+    assert np.linalg.norm(rs) < 0.1 and abs(full["deriv"].sum(dtype=np.float64)) < 0.2
+
+
+def test_autograd_wrapper_matches_reference_semantics(oracle):
+    """chain_loss(): (B, C, T) input, loss = -objf/weight, backward = -(deriv) ignoring grad_output,
+    xent grad scaled by xent_regularize (torchain/functions.py:62-138)."""
+    from torchain_amd import io
+    from torchain_amd.functions import chain_loss
+
+    fst = synth.random_den_fst(120, 5, 64, seed=21)
+    B, T, P = 4, 12, 64
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, B, T, 3, seed=3, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(B, T, P, seed=8)  # rows t*B + b
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 5e-5, 0.1, want_xent=True)
+
+    den = io.DenominatorGraph(fst, P)
+    hsup = io.Supervision.from_synth(sup)
+    x = torch.from_numpy(y.reshape(T, B, P).transpose(1, 2, 0).copy()).cuda().requires_grad_(True)  # (B, C, T)
+    xe = torch.randn(B, P, T, device="cuda", requires_grad=True)
+    loss, results = chain_loss(x, den, hsup, l2_regularize=5e-5, leaky_hmm_coefficient=0.1, xent_regularize=0.1,
+                               xent_input=xe, kaldi_way=True)
+    assert loss.is_cuda and loss.shape == (1,)
+    assert abs(float(loss) - (-ref["objf"] / ref["weight"])) <= REL * abs(ref["objf"] / ref["weight"])
+    (loss * 123.0).backward()  # grad_output must be ignored
+    gx = x.grad.permute(2, 0, 1).reshape(T * B, P).cpu().numpy()
+    assert rel_err(gx, -ref["deriv"]) <= REL
+    gxe = xe.grad.permute(2, 0, 1).reshape(T * B, P).cpu().numpy()
+    assert rel_err(gxe, -0.1 * ref["xent_deriv"]) <= REL
+    assert "ChainResults(loss=" in repr(results)

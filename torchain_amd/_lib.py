@@ -1,0 +1,91 @@
+"""ctypes binding of libtorchain_hip.so, the C-ABI drop-in boundary (include/torchain_hip.h).
+
+The reference binds its C functions through cffi (``torchain/functions.py:5-6``,
+``build.py:19-31``); here the same role is played by ctypes on a hipcc-built shared library that
+takes raw device pointers.  There is no CPU fallback: if the library is missing the import of this
+module raises, and every hot call requires CUDA/ROCm tensors.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtorchain_hip.so")
+
+TC_OK = 0
+ERRORS = {
+    -1: "TC_ERR_INVALID_ARGUMENT", -2: "TC_ERR_BAD_FST", -3: "TC_ERR_UNSUPPORTED", -4: "TC_ERR_WORKSPACE",
+    -5: "TC_ERR_HIP", -6: "TC_ERR_IO", -7: "TC_ERR_NOT_SEPARABLE",
+}
+
+
+class TorchainHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.tc_strerror(code).decode() if _lib is not None else "?"
+        extra = " (hipError %d)" % lib.tc_last_hip_error() if code == -5 else ""
+        super().__init__("%s failed: %s [%s]%s" % (where, msg, ERRORS.get(code, code), extra))
+
+
+_lib = None
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "torchain_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C torchain_amd/csrc`; there is no CPU fallback for the chain loss." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.tc_strerror.restype = C.c_char_p
+    L.tc_strerror.argtypes = [C.c_int]
+    L.tc_version.restype = C.c_int
+    L.tc_last_hip_error.restype = C.c_int
+    L.tc_den_graph_create.restype = C.c_int
+    L.tc_den_graph_create.argtypes = [C.POINTER(vp), i32, i64, vp, vp, vp, vp, vp, i32, i32]
+    L.tc_den_graph_read.restype = C.c_int
+    L.tc_den_graph_read.argtypes = [C.POINTER(vp), C.c_char_p, i32]
+    L.tc_den_graph_free.restype = None
+    L.tc_den_graph_free.argtypes = [vp]
+    L.tc_den_graph_num_states.restype = i32
+    L.tc_den_graph_num_states.argtypes = [vp]
+    L.tc_den_graph_num_arcs.restype = i64
+    L.tc_den_graph_num_arcs.argtypes = [vp]
+    L.tc_den_graph_num_pdfs.restype = i32
+    L.tc_den_graph_num_pdfs.argtypes = [vp]
+    L.tc_den_graph_initial_probs.restype = C.c_int
+    L.tc_den_graph_initial_probs.argtypes = [vp, vp]
+    L.tc_den_graph_prepare.restype = C.c_int
+    L.tc_den_graph_prepare.argtypes = [vp, C.c_int]
+    L.tc_den_graph_stats.restype = C.c_int
+    L.tc_den_graph_stats.argtypes = [vp, vp]
+    L.tc_supervision_create.restype = C.c_int
+    L.tc_supervision_create.argtypes = [C.POINTER(vp), f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.tc_supervision_free.restype = None
+    L.tc_supervision_free.argtypes = [vp]
+    for name in ("tc_supervision_num_pdf", "tc_supervision_num_sequence", "tc_supervision_num_frame"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp]
+    L.tc_supervision_weight.restype = f32
+    L.tc_supervision_weight.argtypes = [vp]
+    L.tc_supervision_prepare.restype = C.c_int
+    L.tc_supervision_prepare.argtypes = [vp, C.c_int, vp]
+    L.tc_chain_workspace_bytes.restype = i64
+    L.tc_chain_workspace_bytes.argtypes = [vp, i32, i32]
+    L.tc_chain_objf_and_deriv.restype = C.c_int
+    L.tc_chain_objf_and_deriv.argtypes = [vp, vp, vp, i64, i32, i64, vp, vp, i64, vp, i64, f32, f32, f32, vp, i64,
+                                          C.c_int, vp]
+    L.tc_den_forward_backward.restype = C.c_int
+    L.tc_den_forward_backward.argtypes = [vp, i32, vp, i64, i32, i64, f32, f32, f32, C.c_int, vp, i64, vp, vp, vp,
+                                          i64, C.c_int, vp]
+    L.tc_num_forward_backward.restype = C.c_int
+    L.tc_num_forward_backward.argtypes = [vp, vp, i64, i32, i64, vp, i64, vp, vp, i64, C.c_int, vp]
+    return L
+
+
+lib = _load()
+_lib = lib
+
+
+def check(code, where):
+    if code != TC_OK:
+        raise TorchainHipError(code, where)

@@ -1,0 +1,226 @@
+// C ABI entry points of the hot path (include/torchain_hip.h).  Replaces the reference's Kaldi
+// bridge src/my_lib_chain.cpp:104-136: validates the borrowed tensors the way common::make_matrix
+// does (2-D, unit column stride, src/common.hpp:109-117), carves the caller's workspace, and enqueues
+// the kernels on the caller's stream.  No allocation, no host synchronisation, no globals.
+#include <cstring>
+
+#include "chain_internal.h"
+
+using namespace tc;
+
+namespace tc {
+int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream);
+}
+
+namespace {
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+  float *alpha_hist;
+  double *den_lp, *num_lp, *y2;
+  float *ab, *gs;
+  int32_t *fail;
+  double *scalar;
+  size_t total;
+};
+
+Workspace carve(char *base, int H, int S, int T) {
+  const int Hs = (H + 3) & ~3;
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char *p = base ? base + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  w.alpha_hist = (float *)take((size_t)(T + 1) * S * Hs * sizeof(float));
+  w.den_lp = (double *)take((size_t)S * 8);
+  w.num_lp = (double *)take((size_t)S * 8);
+  w.y2 = (double *)take((size_t)S * 8);
+  w.ab = (float *)take((size_t)S * 4);
+  w.gs = (float *)take((size_t)S * 4);
+  w.fail = (int32_t *)take(256);
+  w.scalar = (double *)take(256);
+  w.total = off;
+  return w;
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) ok = false;
+    if (ok && prev != device && hipSetDevice(device) != hipSuccess) ok = false;
+    if (prev == device) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int64_t rows, int32_t cols,
+                    int64_t y_stride, float leaky, float deriv_weight, float l2_scale, float *deriv,
+                    int64_t deriv_stride, const Workspace &w, DenParams *p) {
+  if (!g || !y || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
+  if (cols != g->P || y_stride < cols) return TC_ERR_INVALID_ARGUMENT;
+  if (deriv && deriv_stride < cols) return TC_ERR_INVALID_ARGUMENT;
+  if (!(leaky > 0.0f && leaky < 1.0f)) return TC_ERR_INVALID_ARGUMENT;  // [K] KALDI_ASSERT in the ctor
+  const int T = (int)(rows / S);
+  int rc = tc_den_graph_prepare(g, device);
+  if (rc != TC_OK) return rc;
+  DenGraphDev d;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    d = g->dev[device];
+  }
+  if (!compute_layout(g->H, g->P, T, &p->L)) return TC_ERR_UNSUPPORTED;
+  p->fwd = d.fwd;
+  p->bwd = d.bwd;
+  p->pi = d.pi;
+  p->y = y;
+  p->y_stride = y_stride;
+  p->deriv = deriv;
+  p->deriv_stride = deriv_stride;
+  p->alpha_hist = w.alpha_hist;
+  p->seq_logprob = w.den_lp;
+  p->seq_y2 = w.y2;
+  p->seq_ab = w.ab;
+  p->seq_gsum = w.gs;
+  p->S = S;
+  p->T = T;
+  p->H = g->H;
+  p->P = g->P;
+  p->leaky = leaky;
+  p->deriv_weight = deriv_weight;
+  p->l2_scale = l2_scale;
+  p->y_vec = (cols % 4 == 0 && y_stride % 4 == 0 && aligned16(y)) ? 1 : 0;
+  p->d_vec = (deriv && cols % 4 == 0 && deriv_stride % 4 == 0 && aligned16(deriv)) ? 1 : 0;
+  return TC_OK;
+}
+
+int fill_num_params(tc_supervision *sup, int device, hipStream_t stream, const float *y, int64_t rows, int32_t cols,
+                    int64_t y_stride, float *deriv, int64_t deriv_stride, float *xent, int64_t xent_stride,
+                    double *seq_lp, NumParams *p) {
+  if (!sup || !y) return TC_ERR_INVALID_ARGUMENT;
+  if ((int64_t)sup->S * sup->T != rows || sup->P != cols || y_stride < cols) return TC_ERR_INVALID_ARGUMENT;
+  if ((deriv && deriv_stride < cols) || (xent && xent_stride < cols)) return TC_ERR_INVALID_ARGUMENT;
+  int rc = tc_supervision_prepare(sup, device, stream);
+  if (rc != TC_OK) return rc;
+  {
+    std::lock_guard<std::mutex> lock(sup->mu);
+    p->t = sup->dev[device];
+  }
+  p->y = y;
+  p->y_stride = y_stride;
+  p->deriv = deriv;
+  p->deriv_stride = deriv_stride;
+  p->xent = xent;
+  p->xent_stride = xent_stride;
+  p->seq_logprob = seq_lp;
+  p->S = sup->S;
+  p->T = sup->T;
+  p->P = sup->P;
+  p->weight = sup->weight;
+  p->lds_states = (sup->tab.max_states + 1) & ~1;
+  p->lds_arcs = (sup->tab.max_arcs + 3) & ~3;
+  p->lds_uniq = (sup->tab.max_uniq + 3) & ~3;
+  return TC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
+  if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
+  return (int64_t)carve(nullptr, g->H, S, T).total;
+}
+
+int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
+                            int64_t y_stride, float leaky, float deriv_weight, float l2_scale, int accumulate,
+                            float *deriv, int64_t deriv_stride, double *logprob_dev, int32_t *status_dev,
+                            void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
+  if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
+  const int T = (int)(rows / S);
+  Workspace w = carve((char *)workspace, g->H, S, T);
+  if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
+  DeviceGuard guard(device);
+  if (!guard.ok) return TC_ERR_HIP;
+  hipStream_t stream = (hipStream_t)stream_v;
+  DenParams p;
+  int rc = fill_den_params(g, device, S, y, rows, cols, y_stride, leaky, deriv_weight, l2_scale, deriv, deriv_stride, w,
+                           &p);
+  if (rc != TC_OK) return rc;
+  rc = launch_den_mode(p, accumulate, stream);
+  if (rc != TC_OK) return rc;
+  if (logprob_dev || status_dev)
+    rc = launch_den_reduce(w.den_lp, deriv ? w.ab : nullptr, w.gs, S, logprob_dev, status_dev, stream);
+  return rc;
+}
+
+int tc_num_forward_backward(tc_supervision *sup, const float *y, int64_t rows, int32_t cols, int64_t y_stride,
+                            float *deriv, int64_t deriv_stride, double *logprob_dev, void *workspace,
+                            int64_t workspace_bytes, int device, void *stream_v) {
+  if (!sup) return TC_ERR_INVALID_ARGUMENT;
+  const size_t need = align256((size_t)sup->S * 8);
+  if (!workspace || (int64_t)need > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
+  DeviceGuard guard(device);
+  if (!guard.ok) return TC_ERR_HIP;
+  hipStream_t stream = (hipStream_t)stream_v;
+  NumParams p;
+  int rc = fill_num_params(sup, device, stream, y, rows, cols, y_stride, deriv, deriv_stride, nullptr, 0,
+                           (double *)workspace, &p);
+  if (rc != TC_OK) return rc;
+  rc = launch_num(p, stream);
+  if (rc != TC_OK) return rc;
+  if (logprob_dev) rc = launch_sum_double((const double *)workspace, sup->S, (double)sup->weight, logprob_dev, stream);
+  return rc;
+}
+
+int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
+                            int64_t y_stride, float *results_dev3, float *deriv, int64_t deriv_stride, float *xent,
+                            int64_t xent_stride, float l2_regularize, float leaky, float xent_regularize,
+                            void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
+  (void)xent_regularize;  // as in the reference it only decides whether the caller passes xent (my_lib_chain.cpp:127)
+  if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
+  if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
+  if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
+  Workspace w = carve((char *)workspace, g->H, sup->S, sup->T);
+  if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
+  DeviceGuard guard(device);
+  if (!guard.ok) return TC_ERR_HIP;
+  hipStream_t stream = (hipStream_t)stream_v;
+
+  const float wgt = sup->weight;
+  DenParams dp;
+  int rc = fill_den_params(g, device, sup->S, y, rows, cols, y_stride, leaky, -wgt, wgt * l2_regularize, deriv,
+                           deriv_stride, w, &dp);
+  if (rc != TC_OK) return rc;
+  NumParams np;
+  rc = fill_num_params(sup, device, stream, y, rows, cols, y_stride, deriv, deriv_stride, xent, xent_stride, w.num_lp,
+                       &np);
+  if (rc != TC_OK) return rc;
+
+  if (xent) {
+    if (xent_stride == cols)
+      TC_HIP_CHECK(hipMemsetAsync(xent, 0, (size_t)rows * cols * sizeof(float), stream));
+    else
+      TC_HIP_CHECK(hipMemset2DAsync(xent, (size_t)xent_stride * 4, 0, (size_t)cols * 4, (size_t)rows, stream));
+  }
+  // denominator first: it writes every element of deriv (-w*gamma_den - w*l2*y); the numerator then
+  // adds its sparse posteriors.  [K] runs the numerator first; the sum is the same.
+  rc = launch_den(dp, stream);
+  if (rc != TC_OK) return rc;
+  rc = launch_num(np, stream);
+  if (rc != TC_OK) return rc;
+  rc = launch_finalize(w.den_lp, w.num_lp, w.y2, w.ab, w.gs, sup->S, sup->T, wgt, l2_regularize, deriv != nullptr,
+                       results_dev3, w.fail, stream);
+  if (rc != TC_OK) return rc;
+  return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_stride, y, y_stride, wgt * l2_regularize, rows,
+                             cols, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+// Internal declarations shared by the host code and the HIP kernels of libtorchain_hip.so.
+// Public C ABI: include/torchain_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "torchain_hip.h"
+
+namespace tc {
+
+// ---- fused denominator kernel geometry ---------------------------------------------------------
+// One workgroup per sequence, 16 wavefronts of 64 lanes (the CU's maximum), one workgroup per CU:
+// the frame recursion is serial, so everything a sequence needs per frame lives in that CU's LDS.
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxRowLen = 32;             // longer in/out-arc lists are split into virtual rows
+constexpr int kLdsLimitBytes = 160 * 1024; // gfx950 LDS per CU / per workgroup
+
+// One transition as the kernels stream it: probability + two 16-bit dword indices (the state to
+// gather alpha'/beta from and the pdf), 8 bytes.  [K] DenominatorGraphTransition is 12 bytes.
+struct ArcRec {
+  float w;
+  uint32_t idx;  // state | (pdf << 16)
+};
+
+// A "row" is the in-arc list (forward) or out-arc list (backward) of one state, at most kMaxRowLen
+// long.  Rows are sorted by length and dealt 64 at a time into "slots"; lane l of a slot walks row l,
+// so one wave instruction loads 64 consecutive ArcRec (512 B, coalesced).  Slots are balanced over the
+// 16 waves.  Padding records have w = 0 and index 0.
+struct ScheduleHost {
+  std::vector<ArcRec> recs;        // [slot][step][lane]
+  std::vector<uint32_t> rowid;     // [slot][lane]: state the row accumulates into (Hs = dummy)
+  std::vector<int2> slots;         // per slot {record offset, steps}; each wave's slots contiguous
+  std::vector<int32_t> wave_begin; // kWaves + 1
+  int64_t real_arcs = 0, padded_arcs = 0;
+  int32_t rows = 0;
+};
+
+struct ScheduleDev {
+  const ArcRec *recs;
+  const uint32_t *rowid;
+  const int2 *slots;
+  const int32_t *wave_begin;
+};
+
+struct DenGraphDev {
+  ScheduleDev fwd, bwd;
+  const float *pi;  // initial probs padded to Hs
+  void *blob = nullptr;
+};
+
+// LDS layout of the fused kernel, in floats.  Forward uses [A | ACC | P]; backward reuses the same
+// space as [B | BACC | P | GAMMA | ALPHA?].
+struct DenLayout {
+  int Hs, Ps;           // H, P rounded up to a multiple of 4
+  int off_acc, off_p, off_g, off_al, off_red, off_asum, total_floats;
+  bool alpha_in_lds;
+  int JV, PV;           // float4s of states / pdfs owned per thread
+};
+
+struct DenParams {
+  ScheduleDev fwd, bwd;
+  const float *pi;
+  const float *y;
+  int64_t y_stride;
+  float *deriv;
+  int64_t deriv_stride;
+  float *alpha_hist;    // [(T+1)][S][Hs]
+  double *seq_logprob;  // [S]
+  double *seq_y2;       // [S] sum of y^2 (for the l2 term)
+  float *seq_ab;        // [S] sum_h alpha'_0 beta'_0
+  float *seq_gsum;      // [S] sum_pdf gamma_0
+  int S, T, H, P;
+  float leaky, deriv_weight, l2_scale;
+  int y_vec, d_vec;     // rows 16-byte aligned -> float4 path
+  DenLayout L;
+};
+
+}  // namespace tc
+
+struct tc_den_graph {
+  int32_t H = 0, P = 0;
+  int64_t A = 0;
+  std::vector<int32_t> arc_src, arc_dst, arc_pdf;
+  std::vector<float> arc_prob;
+  std::vector<float> initial_probs;
+  tc::ScheduleHost fwd, bwd;
+  tc::DenLayout layout;
+  bool layout_ok = false;
+  std::mutex mu;
+  std::map<int, tc::DenGraphDev> dev;
+};
+
+// ---- numerator -----------------------------------------------------------------------------------
+namespace tc {
+
+// Per-sequence acceptors flattened into arrays.  Local state 0 of a sequence is its (possibly
+// virtual) start state; states are in time order; arcs are sorted by source state.
+struct NumTables {
+  std::vector<int32_t> seq_state_off, seq_arc_off, seq_uniq_off;  // S + 1 each
+  std::vector<int32_t> level_begin;   // [S][T + 2] local state index where each time level begins
+  std::vector<int32_t> out_begin;     // per state (+1 per sequence): arc range, local arc ids
+  std::vector<int32_t> in_begin;      // per state (+1 per sequence): range into in_arc
+  std::vector<int32_t> in_arc;        // per arc: local arc id, grouped by destination state
+  std::vector<int32_t> arc_src, arc_dst, arc_uniq;  // local ids
+  std::vector<float> arc_logw;        // -arc.weight
+  std::vector<float> final_logw;      // per state: -final weight, -inf when not final
+  std::vector<int32_t> uniq_t, uniq_pdf;  // per unique (frame, pdf) of a sequence
+  std::vector<int32_t> uniq_begin;    // per uniq (+1 per sequence): range into uniq_arc
+  std::vector<int32_t> uniq_arc;      // local arc ids in increasing order
+  int32_t max_states = 0, max_arcs = 0, max_uniq = 0;
+};
+
+struct NumDev {
+  const int32_t *seq_state_off, *seq_arc_off, *seq_uniq_off, *level_begin, *out_begin, *in_begin, *in_arc,
+      *arc_src, *arc_dst, *arc_uniq, *uniq_t, *uniq_pdf, *uniq_begin, *uniq_arc;
+  const float *arc_logw, *final_logw;
+  void *blob = nullptr;
+  hipEvent_t ready = nullptr;
+};
+
+struct NumParams {
+  NumDev t;
+  const float *y;
+  int64_t y_stride;
+  float *deriv;
+  int64_t deriv_stride;
+  float *xent;
+  int64_t xent_stride;
+  double *seq_logprob;  // [S]
+  int S, T, P;
+  float weight;
+  int lds_states, lds_arcs, lds_uniq;
+};
+
+}  // namespace tc
+
+struct tc_supervision {
+  float weight = 1.f;
+  int32_t S = 0, T = 0, P = 0;
+  tc::NumTables tab;
+  std::vector<char> pinned_image;  // host image of the device blob
+  std::vector<size_t> blob_off;
+  std::mutex mu;
+  std::map<int, tc::NumDev> dev;
+};
+
+namespace tc {
+
+int build_schedules(tc_den_graph *g);
+bool compute_layout(int H, int P, int T_hint, DenLayout *L);
+int64_t layout_lds_bytes(const DenLayout &L, int T);
+
+int launch_den(const DenParams &p, hipStream_t stream);
+int launch_num(const NumParams &p, hipStream_t stream);
+int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
+                    int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,
+                    hipStream_t stream);
+int launch_zero_on_fail(const int32_t *fail_flag, float *a, int64_t a_stride, float *b, int64_t b_stride,
+                        const float *y, int64_t y_stride, float l2_scale, int64_t rows, int cols, hipStream_t stream);
+int launch_den_reduce(const double *den_lp, const float *ab, const float *gs, int S, double *logprob_out,
+                      int32_t *status_out, hipStream_t stream);
+int launch_sum_double(const double *in, int n, double scale, double *out, hipStream_t stream);
+
+extern thread_local int g_last_hip_error;
+#define TC_HIP_CHECK(expr)                        \
+  do {                                            \
+    hipError_t e__ = (expr);                      \
+    if (e__ != hipSuccess) {                      \
+      tc::g_last_hip_error = (int)e__;            \
+      return TC_ERR_HIP;                          \
+    }                                             \
+  } while (0)
+
+}  // namespace tc

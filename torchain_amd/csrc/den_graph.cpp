@@ -1,0 +1,394 @@
+// Host side of the denominator graph: construction from an FST (what the reference does by calling
+// kaldi::chain::DenominatorGraph at src/my_lib_example.cpp:129-134), the wavefront schedules the HIP
+// kernels stream, the OpenFst binary reader, and the per-device immutable copies.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+
+#include "chain_internal.h"
+
+namespace tc {
+
+thread_local int g_last_hip_error = 0;
+
+static int round4(int x) { return (x + 3) & ~3; }
+
+// Lays the per-frame working set of one sequence out in LDS.  Returns false if it cannot fit.
+bool compute_layout(int H, int P, int T_hint, DenLayout *L) {
+  L->Hs = round4(H);
+  L->Ps = round4(P);
+  L->JV = (L->Hs / 4 + kThreads - 1) / kThreads;
+  L->PV = (L->Ps / 4 + kThreads - 1) / kThreads;
+  if (H > 65535 || P > 65535) return false;  // 16-bit indices in ArcRec
+  for (int with_alpha = 1; with_alpha >= 0; --with_alpha) {
+    int off = 0;
+    off += L->Hs;  // A / B
+    L->off_acc = off;
+    off += L->Hs + 4;  // ACC / BACC (+ dummy row)
+    L->off_p = off;
+    off += L->Ps;
+    L->off_g = off;
+    off += L->Ps;
+    L->off_al = off;
+    if (with_alpha) off += L->Hs + 4;
+    L->off_red = off;
+    off += 4 * kWaves;
+    L->off_asum = off;
+    off += round4(T_hint + 1);
+    L->total_floats = off;
+    L->alpha_in_lds = with_alpha != 0;
+    if ((int64_t)off * 4 <= kLdsLimitBytes) return true;
+  }
+  return false;
+}
+
+int64_t layout_lds_bytes(const DenLayout &L, int T) {
+  return 4 * (int64_t)(L.off_asum + round4(T + 1));
+}
+
+// Builds the row/slot schedule for one direction.  key[a] is the state whose sum arc a belongs to
+// (destination for the forward pass, source for the backward pass), other[a] the state it gathers.
+static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_t *other, const int32_t *pdf,
+                      const float *prob, ScheduleHost *out) {
+  struct Row {
+    int32_t state, len;
+    int64_t begin;
+  };
+  // stable counting sort of arcs by key keeps the FST's arc order inside a row
+  std::vector<int64_t> first(H + 1, 0);
+  for (int64_t a = 0; a < A; ++a) first[key[a] + 1]++;
+  for (int h = 0; h < H; ++h) first[h + 1] += first[h];
+  std::vector<int64_t> order(A), fill(first.begin(), first.end() - 1);
+  for (int64_t a = 0; a < A; ++a) order[fill[key[a]]++] = a;
+
+  std::vector<Row> rows;
+  for (int h = 0; h < H; ++h) {
+    int64_t b = first[h], e = first[h + 1];
+    while (b < e) {
+      int len = (int)std::min<int64_t>(kMaxRowLen, e - b);
+      rows.push_back({h, len, b});
+      b += len;
+    }
+  }
+  std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.len > y.len; });
+  const int nrows = (int)rows.size();
+  const int nslots = (nrows + 63) / 64;
+
+  // longest-processing-time assignment of slots to waves
+  std::vector<std::vector<int>> per_wave(kWaves);
+  std::vector<int64_t> load(kWaves, 0);
+  for (int sidx = 0; sidx < nslots; ++sidx) {
+    int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    per_wave[w].push_back(sidx);
+    load[w] += rows[(size_t)sidx * 64].len;
+  }
+  out->recs.clear();
+  out->rowid.clear();
+  out->slots.clear();
+  out->wave_begin.assign(kWaves + 1, 0);
+  for (int w = 0; w < kWaves; ++w) {
+    out->wave_begin[w] = (int)out->slots.size();
+    for (int sidx : per_wave[w]) {
+      const int steps = rows[(size_t)sidx * 64].len;
+      const int off = (int)out->recs.size();
+      out->slots.push_back(make_int2(off, steps));
+      out->recs.resize(out->recs.size() + (size_t)steps * 64, ArcRec{0.f, 0u});
+      for (int l = 0; l < 64; ++l) {
+        int r = sidx * 64 + l;
+        if (r >= nrows) {
+          out->rowid.push_back((uint32_t)Hs);
+          continue;
+        }
+        out->rowid.push_back((uint32_t)rows[r].state);
+        for (int k = 0; k < rows[r].len; ++k) {
+          int64_t a = order[rows[r].begin + k];
+          out->recs[(size_t)off + (size_t)k * 64 + l] =
+              ArcRec{prob[a], (uint32_t)other[a] | ((uint32_t)pdf[a] << 16)};
+        }
+      }
+    }
+  }
+  out->wave_begin[kWaves] = (int)out->slots.size();
+  out->real_arcs = A;
+  out->padded_arcs = (int64_t)out->recs.size();
+  out->rows = nrows;
+  if (out->recs.empty()) out->recs.push_back(ArcRec{0.f, 0u});
+  if (out->rowid.empty()) out->rowid.push_back((uint32_t)Hs);
+  if (out->slots.empty()) out->slots.push_back(make_int2(0, 0));
+}
+
+int build_schedules(tc_den_graph *g) {
+  g->layout_ok = compute_layout(g->H, g->P, 256, &g->layout);
+  const int Hs = round4(g->H);
+  // forward: alpha_{t+1}(dst) sums over in-arcs, gathers alpha'_t(src)
+  build_one(g->H, Hs, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->fwd);
+  // backward: beta'_t(src) sums over out-arcs, gathers beta_{t+1}(dst)
+  build_one(g->H, Hs, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->bwd);
+  return TC_OK;
+}
+
+}  // namespace tc
+
+using namespace tc;
+
+extern "C" {
+
+int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs, const int32_t *arc_src,
+                        const int32_t *arc_dst, const int32_t *arc_ilabel, const float *arc_weight,
+                        const float *final_weight, int32_t start_state, int32_t num_pdfs) {
+  if (!out) return TC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (num_states <= 0 || num_arcs < 0 || num_pdfs <= 0 || !final_weight) return TC_ERR_INVALID_ARGUMENT;
+  if (num_arcs > 0 && (!arc_src || !arc_dst || !arc_ilabel || !arc_weight)) return TC_ERR_INVALID_ARGUMENT;
+  if (start_state < 0 || start_state >= num_states) return TC_ERR_BAD_FST;
+  if (num_arcs >= (int64_t)1 << 30) return TC_ERR_UNSUPPORTED;
+  for (int64_t a = 0; a < num_arcs; ++a) {
+    if (arc_src[a] < 0 || arc_src[a] >= num_states || arc_dst[a] < 0 || arc_dst[a] >= num_states)
+      return TC_ERR_BAD_FST;
+    if (arc_ilabel[a] < 1 || arc_ilabel[a] > num_pdfs) return TC_ERR_BAD_FST;  // [K] KALDI_ASSERT on pdf_id
+    if (a > 0 && arc_src[a] < arc_src[a - 1]) return TC_ERR_BAD_FST;           // must be state-major
+    if (!(arc_weight[a] == arc_weight[a])) return TC_ERR_BAD_FST;
+  }
+  tc_den_graph *g = new tc_den_graph();
+  g->H = num_states;
+  g->P = num_pdfs;
+  g->A = num_arcs;
+  g->arc_src.assign(arc_src, arc_src + num_arcs);
+  g->arc_dst.assign(arc_dst, arc_dst + num_arcs);
+  g->arc_pdf.resize(num_arcs);
+  g->arc_prob.resize(num_arcs);
+  for (int64_t a = 0; a < num_arcs; ++a) {
+    g->arc_pdf[a] = arc_ilabel[a] - 1;
+    g->arc_prob[a] = (float)std::exp(-(double)arc_weight[a]);  // [K] SetTransitions
+  }
+  // [K] DenominatorGraph::SetInitialProbs: start state only, 100 rounds of per-state-normalised HMM
+  // propagation, averaged; double precision, stored as float.
+  {
+    const int H = num_states;
+    std::vector<double> norm(H), cur(H, 0.0), nxt(H, 0.0), avg(H, 0.0);
+    for (int s = 0; s < H; ++s) norm[s] = std::exp(-(double)final_weight[s]);
+    for (int64_t a = 0; a < num_arcs; ++a) norm[arc_src[a]] += std::exp(-(double)arc_weight[a]);
+    for (int s = 0; s < H; ++s) norm[s] = 1.0 / norm[s];
+    cur[start_state] = 1.0;
+    for (int iter = 0; iter < 100; ++iter) {
+      for (int s = 0; s < H; ++s) avg[s] += cur[s] * (1.0 / 100);
+      for (int64_t a = 0; a < num_arcs; ++a) {
+        int s = arc_src[a];
+        nxt[arc_dst[a]] += cur[s] * norm[s] * std::exp(-(double)arc_weight[a]);
+      }
+      double sum = 0.0;
+      for (int s = 0; s < H; ++s) sum += nxt[s];
+      for (int s = 0; s < H; ++s) {
+        cur[s] = nxt[s] * (1.0 / sum);
+        nxt[s] = 0.0;
+      }
+    }
+    g->initial_probs.resize(H);
+    for (int s = 0; s < H; ++s) g->initial_probs[s] = (float)avg[s];
+  }
+  build_schedules(g);
+  *out = g;
+  return TC_OK;
+}
+
+}  // extern "C"
+
+// --- OpenFst binary VectorFst<StdArc> reader ------------------------------------------------------
+namespace {
+struct Reader {
+  FILE *f;
+  bool ok = true;
+  template <class T>
+  T get() {
+    T v{};
+    if (fread(&v, sizeof(T), 1, f) != 1) ok = false;
+    return v;
+  }
+  std::string str() {
+    int32_t n = get<int32_t>();
+    if (!ok || n < 0 || n > (1 << 20)) {
+      ok = false;
+      return std::string();
+    }
+    std::string s((size_t)n, '\0');
+    if (n && fread(&s[0], 1, (size_t)n, f) != (size_t)n) ok = false;
+    return s;
+  }
+  void skip_symbol_table() {
+    int32_t magic = get<int32_t>();
+    if (magic != 2125658996) {
+      ok = false;
+      return;
+    }
+    str();                   // name
+    get<int64_t>();          // available key
+    int64_t size = get<int64_t>();
+    for (int64_t i = 0; ok && i < size; ++i) {
+      str();
+      get<int64_t>();
+    }
+  }
+};
+}  // namespace
+
+extern "C" {
+
+int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pdfs) {
+  if (!out || !rxfilename) return TC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  FILE *f = fopen(rxfilename, "rb");
+  if (!f) return TC_ERR_IO;
+  Reader r{f};
+  int rc = TC_OK;
+  std::vector<int32_t> src, dst, il;
+  std::vector<float> w, fin;
+  int64_t start = 0, nstates = 0;
+  do {
+    if (r.get<int32_t>() != 2125659606) { rc = TC_ERR_IO; break; }  // kFstMagicNumber
+    std::string fsttype = r.str(), arctype = r.str();
+    int32_t version = r.get<int32_t>(), flags = r.get<int32_t>();
+    r.get<uint64_t>();  // properties
+    start = r.get<int64_t>();
+    nstates = r.get<int64_t>();
+    int64_t narcs = r.get<int64_t>();
+    if (!r.ok || fsttype != "vector" || arctype != "standard" || version < 2 || (flags & 4) /* aligned */ ||
+        nstates <= 0 || nstates > (1 << 28)) {
+      rc = TC_ERR_IO;
+      break;
+    }
+    if (flags & 1) r.skip_symbol_table();
+    if (flags & 2) r.skip_symbol_table();
+    if (narcs > 0) { src.reserve(narcs); dst.reserve(narcs); il.reserve(narcs); w.reserve(narcs); }
+    fin.resize(nstates);
+    for (int64_t s = 0; r.ok && s < nstates; ++s) {
+      fin[s] = r.get<float>();
+      int64_t n = r.get<int64_t>();
+      if (!r.ok || n < 0 || n > (1 << 28)) { r.ok = false; break; }
+      for (int64_t i = 0; r.ok && i < n; ++i) {
+        int32_t ilabel = r.get<int32_t>();
+        r.get<int32_t>();  // olabel (== ilabel in a den.fst)
+        float weight = r.get<float>();
+        int32_t next = r.get<int32_t>();
+        src.push_back((int32_t)s);
+        dst.push_back(next);
+        il.push_back(ilabel);
+        w.push_back(weight);
+      }
+    }
+    if (!r.ok) rc = TC_ERR_IO;
+  } while (0);
+  fclose(f);
+  if (rc != TC_OK) return rc;
+  return tc_den_graph_create(out, (int32_t)nstates, (int64_t)src.size(), src.data(), dst.data(), il.data(), w.data(),
+                             fin.data(), (int32_t)start, num_pdfs);
+}
+
+void tc_den_graph_free(tc_den_graph *g) {
+  if (!g) return;
+  for (auto &kv : g->dev) {
+    if (kv.second.blob) {
+      int cur = 0;
+      if (hipGetDevice(&cur) == hipSuccess) {
+        (void)hipSetDevice(kv.first);
+        (void)hipFree(kv.second.blob);
+        (void)hipSetDevice(cur);
+      }
+    }
+  }
+  delete g;
+}
+
+int32_t tc_den_graph_num_states(const tc_den_graph *g) { return g ? g->H : 0; }
+int64_t tc_den_graph_num_arcs(const tc_den_graph *g) { return g ? g->A : 0; }
+int32_t tc_den_graph_num_pdfs(const tc_den_graph *g) { return g ? g->P : 0; }
+
+int tc_den_graph_initial_probs(const tc_den_graph *g, float *out_host) {
+  if (!g || !out_host) return TC_ERR_INVALID_ARGUMENT;
+  memcpy(out_host, g->initial_probs.data(), sizeof(float) * (size_t)g->H);
+  return TC_OK;
+}
+
+int tc_den_graph_stats(const tc_den_graph *g, int64_t *o) {
+  if (!g || !o) return TC_ERR_INVALID_ARGUMENT;
+  o[0] = g->fwd.padded_arcs;
+  o[1] = g->bwd.padded_arcs;
+  o[2] = g->layout_ok ? layout_lds_bytes(g->layout, 150) : -1;
+  o[3] = kThreads;
+  o[4] = g->fwd.rows;
+  o[5] = g->bwd.rows;
+  return TC_OK;
+}
+
+int tc_den_graph_prepare(tc_den_graph *g, int device) {
+  if (!g) return TC_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (g->dev.count(device)) return TC_OK;
+  int prev = 0;
+  TC_HIP_CHECK(hipGetDevice(&prev));
+  TC_HIP_CHECK(hipSetDevice(device));
+  const int Hs = (g->H + 3) & ~3;
+  auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  struct Part { const void *src; size_t bytes; size_t off; };
+  std::vector<float> pi_pad(Hs + 4, 0.f);
+  std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
+  Part parts[] = {
+      {g->fwd.recs.data(), g->fwd.recs.size() * sizeof(ArcRec), 0},
+      {g->fwd.rowid.data(), g->fwd.rowid.size() * 4, 0},
+      {g->fwd.slots.data(), g->fwd.slots.size() * sizeof(int2), 0},
+      {g->fwd.wave_begin.data(), g->fwd.wave_begin.size() * 4, 0},
+      {g->bwd.recs.data(), g->bwd.recs.size() * sizeof(ArcRec), 0},
+      {g->bwd.rowid.data(), g->bwd.rowid.size() * 4, 0},
+      {g->bwd.slots.data(), g->bwd.slots.size() * sizeof(int2), 0},
+      {g->bwd.wave_begin.data(), g->bwd.wave_begin.size() * 4, 0},
+      {pi_pad.data(), pi_pad.size() * 4, 0},
+  };
+  size_t total = 0;
+  for (auto &p : parts) {
+    p.off = total;
+    total += align(p.bytes);
+  }
+  char *blob = nullptr;
+  hipError_t e = hipMalloc((void **)&blob, total);
+  if (e == hipSuccess) {
+    for (auto &p : parts) {
+      e = hipMemcpy(blob + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) break;
+    }
+  }
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return TC_ERR_HIP;
+  }
+  DenGraphDev d;
+  d.blob = blob;
+  d.fwd = ScheduleDev{(const ArcRec *)(blob + parts[0].off), (const uint32_t *)(blob + parts[1].off),
+                      (const int2 *)(blob + parts[2].off), (const int32_t *)(blob + parts[3].off)};
+  d.bwd = ScheduleDev{(const ArcRec *)(blob + parts[4].off), (const uint32_t *)(blob + parts[5].off),
+                      (const int2 *)(blob + parts[6].off), (const int32_t *)(blob + parts[7].off)};
+  d.pi = (const float *)(blob + parts[8].off);
+  g->dev[device] = d;
+  return TC_OK;
+}
+
+const char *tc_strerror(int code) {
+  switch (code) {
+    case TC_OK: return "ok";
+    case TC_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case TC_ERR_BAD_FST: return "malformed FST";
+    case TC_ERR_UNSUPPORTED: return "problem size not supported by the on-chip layout";
+    case TC_ERR_WORKSPACE: return "workspace missing or too small";
+    case TC_ERR_HIP: return "HIP runtime error";
+    case TC_ERR_IO: return "cannot read OpenFst vector/standard file";
+    case TC_ERR_NOT_SEPARABLE: return "merged supervision FST does not factor per sequence";
+    default: return "unknown error";
+  }
+}
+
+int tc_version(void) { return 100; }
+int tc_last_hip_error(void) { return tc::g_last_hip_error; }
+
+}  // extern "C"

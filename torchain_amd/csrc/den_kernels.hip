@@ -1,0 +1,428 @@
+// Fused denominator forward-backward for gfx950 (MI355X).
+//
+// What it computes: [K] DenominatorComputation::Forward() + Backward() (chain-denominator.cc), the
+// part of the reference's hot call (src/my_lib_chain.cpp:129-131) that the headline metric times.
+//
+// Mapping.  The frame recursion is serial and sequences never interact, so one workgroup (16 waves,
+// one per CU) owns one sequence for all 2T frames and keeps that sequence's per-frame working set in
+// LDS: alpha'_t / beta_{t+1} (gather source), the accumulator for the next frame, exp(y_t) and, in
+// the backward half, gamma_t and alpha'_t.  HBM sees each y row twice (forward, backward), each
+// alpha' frame once out and once back, and each derivative row once.  The transition tables are
+// streamed from L2 as 8-byte records in a lane-major schedule (den_graph.cpp): lane l of a wave walks
+// one state's arc list, so a wave instruction reads 512 contiguous bytes and gathers alpha'/p from
+// LDS.  Row sums are committed with one LDS float add per row; gamma with one LDS float add per arc.
+//
+// Numerics follow the Kaldi CPU arithmetic: linear domain, fp32, per-frame renormalisation by the
+// alpha-sum of the previous frame ("arbitrary_scale"), leaky-HMM mixing, betas carrying 1/tot_prob.
+#include "chain_internal.h"
+
+namespace tc {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over the workgroup; `red` must not be written again before the next barrier
+__device__ __forceinline__ float block_sum(float v, float *red, int wave, int lane) {
+  v = wave_sum(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < kWaves; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float exp_limited(float x) {
+  // [K] later Kaldi: ApplyExpLimited(-30, 30); identical to the 22fbdd ApplyExp() for |y| < 30
+  x = fminf(fmaxf(x, -30.0f), 30.0f);
+  return __expf(x);
+}
+
+__device__ __forceinline__ float4 load_row4(const float *row, int i, int n, int vec) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec) {
+    if (i < n) r = *reinterpret_cast<const float4 *>(row + i);
+  } else {
+    if (i < n) r.x = row[i];
+    if (i + 1 < n) r.y = row[i + 1];
+    if (i + 2 < n) r.z = row[i + 2];
+    if (i + 3 < n) r.w = row[i + 3];
+  }
+  return r;
+}
+
+__device__ __forceinline__ void store_row4(float *row, int i, int n, int vec, float4 v) {
+  if (vec) {
+    if (i < n) *reinterpret_cast<float4 *>(row + i) = v;
+  } else {
+    if (i < n) row[i] = v.x;
+    if (i + 1 < n) row[i + 1] = v.y;
+    if (i + 2 < n) row[i + 2] = v.z;
+    if (i + 3 < n) row[i + 3] = v.w;
+  }
+}
+
+// Walks this wave's slots of the schedule.  FWD: acc(row) += alpha'(src) * w * p(pdf).
+// BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row)/alpha_sum.
+template <bool BWD, bool ALPHA_LDS>
+__device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int lane, const float *__restrict__ SRC,
+                                          const float *__restrict__ PB, float *__restrict__ ACC,
+                                          float *__restrict__ GM, const float *__restrict__ AL,
+                                          const float *__restrict__ hist_t, int H, float inv_asum) {
+  const int sb = __builtin_amdgcn_readfirstlane(sc.wave_begin[wave]);
+  const int se = __builtin_amdgcn_readfirstlane(sc.wave_begin[wave + 1]);
+  for (int sl = sb; sl < se; ++sl) {
+    const int2 d = sc.slots[sl];
+    const int off = __builtin_amdgcn_readfirstlane(d.x);
+    const int steps = __builtin_amdgcn_readfirstlane(d.y);
+    const uint2 *__restrict__ r = reinterpret_cast<const uint2 *>(sc.recs) + off + lane;
+    const uint32_t row = sc.rowid[sl * 64 + lane];
+    float occf = 0.f;
+    if (BWD) {
+      if (ALPHA_LDS)
+        occf = AL[row] * inv_asum;
+      else
+        occf = ((int)row < H ? hist_t[row] : 0.f) * inv_asum;
+    }
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 4 <= steps; k += 4) {
+      uint2 q0 = r[(k + 0) * 64], q1 = r[(k + 1) * 64], q2 = r[(k + 2) * 64], q3 = r[(k + 3) * 64];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint2 q = u == 0 ? q0 : (u == 1 ? q1 : (u == 2 ? q2 : q3));
+        const float w = __uint_as_float(q.x);
+        const uint32_t st = q.y & 0xffffu, pdf = q.y >> 16;
+        if (!BWD) {
+          acc = fmaf(SRC[st] * w, PB[pdf], acc);
+        } else {
+          const float vf = w * SRC[st] * PB[pdf];
+          acc += vf;
+          atomicAdd(&GM[pdf], vf * occf);
+        }
+      }
+    }
+    for (; k < steps; ++k) {
+      const uint2 q = r[k * 64];
+      const float w = __uint_as_float(q.x);
+      const uint32_t st = q.y & 0xffffu, pdf = q.y >> 16;
+      if (!BWD) {
+        acc = fmaf(SRC[st] * w, PB[pdf], acc);
+      } else {
+        const float vf = w * SRC[st] * PB[pdf];
+        acc += vf;
+        atomicAdd(&GM[pdf], vf * occf);
+      }
+    }
+    atomicAdd(&ACC[row], acc);
+  }
+}
+
+template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV>
+__global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p) {
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x;
+  const int H = p.H, P = p.P, S = p.S, T = p.T;
+  const int Hs = p.L.Hs, Ps = p.L.Ps;
+  float *const A0 = lds;                // alpha'_t (forward) / beta_{t+1} (backward): gather source
+  float *const ACC = lds + p.L.off_acc; // next-frame accumulator (+ dummy row at Hs)
+  float *const PB = lds + p.L.off_p;    // exp(y_t)
+  float *const GM = lds + p.L.off_g;    // gamma_t (backward only)
+  float *const AL = lds + p.L.off_al;   // alpha'_t (backward only, when it fits)
+  float *const red = lds + p.L.off_red;
+  float *const asum_h = lds + p.L.off_asum;  // alpha-sum of every frame
+
+  float4 cpi[JV];  // leaky * pi for the states this thread owns
+  float4 pi4[JV];
+  float part = 0.f;
+#pragma unroll
+  for (int j = 0; j < JV; ++j) {
+    const int h0 = 4 * (tid + kThreads * j);
+    pi4[j] = h0 < Hs ? *reinterpret_cast<const float4 *>(p.pi + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    cpi[j] = make_float4(p.leaky * pi4[j].x, p.leaky * pi4[j].y, p.leaky * pi4[j].z, p.leaky * pi4[j].w);
+    part += (pi4[j].x + pi4[j].y) + (pi4[j].z + pi4[j].w);
+  }
+  // ---- t = 0: alpha_0 = pi, alpha'_0 = pi + leaky*pi*sum(pi)   ([K] AlphaFirstFrame + AlphaDash(0))
+  float asum = block_sum(part, red, wave, lane);
+  float *hist = p.alpha_hist + (int64_t)s * Hs;  // frame t lives at hist + t*S*Hs
+  const int64_t hist_step = (int64_t)S * Hs;
+#pragma unroll
+  for (int j = 0; j < JV; ++j) {
+    const int h0 = 4 * (tid + kThreads * j);
+    if (h0 < Hs) {
+      float4 a = make_float4(pi4[j].x + cpi[j].x * asum, pi4[j].y + cpi[j].y * asum, pi4[j].z + cpi[j].z * asum,
+                             pi4[j].w + cpi[j].w * asum);
+      *reinterpret_cast<float4 *>(A0 + h0) = a;
+      *reinterpret_cast<float4 *>(hist + h0) = a;
+      *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (tid < 4) ACC[Hs + tid] = 0.f;
+  float y2 = 0.f;
+  {
+    const float *yrow = p.y + (int64_t)s * p.y_stride;
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * (tid + kThreads * v);
+      if (i0 < Ps) {
+        float4 yv = load_row4(yrow, i0, P, p.y_vec);
+        y2 += (yv.x * yv.x + yv.y * yv.y) + (yv.z * yv.z + yv.w * yv.w);
+        *reinterpret_cast<float4 *>(PB + i0) =
+            make_float4(exp_limited(yv.x), exp_limited(yv.y), exp_limited(yv.z), exp_limited(yv.w));
+      }
+    }
+  }
+  double logsum = 0.0;  // thread 0 only
+  if (tid == 0) asum_h[0] = asum;
+  float inv_prev = 1.0f / asum;
+  float asum_prev = asum;
+
+  // ---- forward frames t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
+  for (int t = 1; t <= T; ++t) {
+    __syncthreads();  // A0, PB, ACC ready
+    float4 yreg[PV];
+    {
+      // prefetch y_t under the arc walk (the last iteration re-reads row T-1: keeps yreg in registers)
+      const float *yrow = p.y + ((int64_t)(t < T ? t : T - 1) * S + s) * p.y_stride;
+#pragma unroll
+      for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
+    }
+    walk_rows<false, true>(p.fwd, wave, lane, A0, PB, ACC, nullptr, nullptr, nullptr, H, 0.f);
+    __syncthreads();  // all row sums committed
+    float4 v4[JV];
+    part = 0.f;
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      const int h0 = 4 * (tid + kThreads * j);
+      v4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h0 < Hs) {
+        float4 a = *reinterpret_cast<float4 *>(ACC + h0);
+        *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);
+        v4[j] = make_float4(a.x * inv_prev, a.y * inv_prev, a.z * inv_prev, a.w * inv_prev);
+        part += (v4[j].x + v4[j].y) + (v4[j].z + v4[j].w);
+      }
+    }
+    asum = block_sum(part, red, wave, lane);
+    float *hist_t = hist + (int64_t)t * hist_step;
+    float part_tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      const int h0 = 4 * (tid + kThreads * j);
+      if (h0 < Hs) {
+        float4 a = make_float4(v4[j].x + cpi[j].x * asum, v4[j].y + cpi[j].y * asum, v4[j].z + cpi[j].z * asum,
+                               v4[j].w + cpi[j].w * asum);
+        *reinterpret_cast<float4 *>(A0 + h0) = a;
+        *reinterpret_cast<float4 *>(hist_t + h0) = a;
+        part_tot += (a.x + a.y) + (a.z + a.w);
+      }
+    }
+    if (t < T) {
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * (tid + kThreads * v);
+        if (i0 < Ps) {
+          float4 yv = yreg[v];
+          y2 += (yv.x * yv.x + yv.y * yv.y) + (yv.z * yv.z + yv.w * yv.w);
+          *reinterpret_cast<float4 *>(PB + i0) =
+              make_float4(exp_limited(yv.x), exp_limited(yv.y), exp_limited(yv.z), exp_limited(yv.w));
+        }
+      }
+    }
+    if (tid == 0) {
+      asum_h[t] = asum;
+      logsum += (double)__logf(asum_prev);  // log of the scale divided out of frame t
+    }
+    asum_prev = asum;
+    inv_prev = 1.0f / asum;
+    if (t == T) part = part_tot;
+  }
+  // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h)
+  const float tot = block_sum(part, red + kWaves, wave, lane);
+  {
+    const double y2d = (double)block_sum(y2, red + 2 * kWaves, wave, lane);
+    if (tid == 0) {
+      p.seq_logprob[s] = logsum + (double)__logf(tot);
+      p.seq_y2[s] = y2d;
+    }
+  }
+  if (!WANT_DERIV) return;
+
+  // ---- backward   ([K] BetaDashLastFrame, Beta(T), then BetaDashGeneralFrame(t) + Beta(t))
+  // beta'_T(h) = 1/tot;  beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h).  The same LDS regions now
+  // hold B (= beta_{t+1}), BACC, P, GAMMA and alpha'_t.
+  const float inv_tot = 1.0f / tot;
+  part = 0.f;
+#pragma unroll
+  for (int j = 0; j < JV; ++j) part += ((cpi[j].x + cpi[j].y) + (cpi[j].z + cpi[j].w)) * inv_tot;
+  float bsum = block_sum(part, red + 3 * kWaves, wave, lane);  // also orders the A0 reuse below
+  float4 areg[JV];
+  float4 ycur[PV], ynext[PV];
+  {
+    const float *hist_t = hist + (int64_t)(T - 1) * hist_step;
+    const float *yrow = p.y + ((int64_t)(T - 1) * S + s) * p.y_stride;
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      const int h0 = 4 * (tid + kThreads * j);
+      if (h0 < Hs) {
+        float4 b = make_float4(h0 < H ? inv_tot + bsum : 0.f, h0 + 1 < H ? inv_tot + bsum : 0.f,
+                               h0 + 2 < H ? inv_tot + bsum : 0.f, h0 + 3 < H ? inv_tot + bsum : 0.f);
+        *reinterpret_cast<float4 *>(A0 + h0) = b;
+        if (ALPHA_LDS) *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + h0);
+      }
+    }
+    if (ALPHA_LDS && tid < 4) AL[Hs + tid] = 0.f;
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * (tid + kThreads * v);
+      ycur[v] = load_row4(yrow, i0, P, p.y_vec);
+      if (i0 < Ps) {
+        *reinterpret_cast<float4 *>(PB + i0) = make_float4(exp_limited(ycur[v].x), exp_limited(ycur[v].y),
+                                                           exp_limited(ycur[v].z), exp_limited(ycur[v].w));
+        *reinterpret_cast<float4 *>(GM + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    __syncthreads();  // B, PB, AL ready; BACC and GAMMA zero
+    const float asum_t = asum_h[t];
+    const float inv_as = 1.0f / asum_t;
+    const float *hist_t = hist + (int64_t)t * hist_step;
+    {
+      // prefetch frame t-1 (y row and alpha') under the arc walk; at t == 0 it re-reads frame 0
+      const int tn = t > 0 ? t - 1 : 0;
+      const float *yrow = p.y + ((int64_t)tn * S + s) * p.y_stride;
+#pragma unroll
+      for (int v = 0; v < PV; ++v) ynext[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
+      if (ALPHA_LDS) {
+        const float *hist_n = hist + (int64_t)tn * hist_step;
+#pragma unroll
+        for (int j = 0; j < JV; ++j) {
+          const int h0 = 4 * (tid + kThreads * j);
+          areg[j] = h0 < Hs ? *reinterpret_cast<const float4 *>(hist_n + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, A0, PB, ACC, GM, AL, hist_t, H, inv_as);
+    __syncthreads();  // beta' sums and gamma committed
+    float4 b4[JV];
+    part = 0.f;
+    float part_ab = 0.f, part_g = 0.f;
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      const int h0 = 4 * (tid + kThreads * j);
+      b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h0 < Hs) {
+        float4 a = *reinterpret_cast<float4 *>(ACC + h0);
+        *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);
+        b4[j] = make_float4(a.x / asum_t, a.y / asum_t, a.z / asum_t, a.w / asum_t);
+        part += (cpi[j].x * b4[j].x + cpi[j].y * b4[j].y) + (cpi[j].z * b4[j].z + cpi[j].w * b4[j].w);
+        if (t == 0) {
+          float4 al = ALPHA_LDS ? *reinterpret_cast<float4 *>(AL + h0)
+                                : *reinterpret_cast<const float4 *>(hist_t + h0);
+          part_ab += (al.x * b4[j].x + al.y * b4[j].y) + (al.z * b4[j].z + al.w * b4[j].w);
+        }
+      }
+    }
+    {
+      float *drow = p.deriv + ((int64_t)t * S + s) * p.deriv_stride;
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * (tid + kThreads * v);
+        if (i0 < Ps) {
+          float4 g = *reinterpret_cast<float4 *>(GM + i0);
+          *reinterpret_cast<float4 *>(GM + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t == 0) part_g += (g.x + g.y) + (g.z + g.w);
+          float4 o = make_float4(p.deriv_weight * g.x - p.l2_scale * ycur[v].x,
+                                 p.deriv_weight * g.y - p.l2_scale * ycur[v].y,
+                                 p.deriv_weight * g.z - p.l2_scale * ycur[v].z,
+                                 p.deriv_weight * g.w - p.l2_scale * ycur[v].w);
+          if (ACCUM) {
+            float4 old = load_row4(drow, i0, P, p.d_vec);
+            o = make_float4(old.x + o.x, old.y + o.y, old.z + o.z, old.w + o.w);
+          }
+          store_row4(drow, i0, P, p.d_vec, o);
+        }
+      }
+    }
+    bsum = block_sum(part, red, wave, lane);
+    if (t == 0) {
+      // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
+      const float ab = block_sum(part_ab, red + kWaves, wave, lane);
+      const float gs = block_sum(part_g, red + 2 * kWaves, wave, lane);
+      if (tid == 0) {
+        p.seq_ab[s] = ab;
+        p.seq_gsum[s] = gs;
+      }
+      break;
+    }
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      const int h0 = 4 * (tid + kThreads * j);
+      if (h0 < Hs) {
+        *reinterpret_cast<float4 *>(A0 + h0) =
+            make_float4(b4[j].x + bsum, b4[j].y + bsum, b4[j].z + bsum, b4[j].w + bsum);
+        if (ALPHA_LDS) *reinterpret_cast<float4 *>(AL + h0) = areg[j];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * (tid + kThreads * v);
+      ycur[v] = ynext[v];
+      if (i0 < Ps)
+        *reinterpret_cast<float4 *>(PB + i0) = make_float4(exp_limited(ycur[v].x), exp_limited(ycur[v].y),
+                                                           exp_limited(ycur[v].z), exp_limited(ycur[v].w));
+    }
+  }
+}
+
+template <int JV, int PV>
+static int launch_jp(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
+  const bool want = p.deriv != nullptr;
+  const bool al = p.L.alpha_in_lds;
+  const bool acc = false;
+  (void)acc;
+  void (*k)(const DenParams) = nullptr;
+  if (!want)
+    k = den_fwd_bwd_kernel<JV, PV, true, false, false>;
+  else if (al)
+    k = den_fwd_bwd_kernel<JV, PV, true, false, true>;
+  else
+    k = den_fwd_bwd_kernel<JV, PV, false, false, true>;
+  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+template <int JV, int PV>
+static int launch_jp_accum(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
+  void (*k)(const DenParams) =
+      p.L.alpha_in_lds ? den_fwd_bwd_kernel<JV, PV, true, true, true> : den_fwd_bwd_kernel<JV, PV, false, true, true>;
+  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+// accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
+int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
+  const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
+  if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
+  const int JV = p.L.JV, PV = p.L.PV;
+#define TC_DISPATCH(J, V)                                                      \
+  if (JV <= J && PV <= V)                                                      \
+    return (accumulate && p.deriv) ? launch_jp_accum<J, V>(p, lds, stream) : launch_jp<J, V>(p, lds, stream);
+  TC_DISPATCH(2, 1)
+  TC_DISPATCH(4, 3)
+#undef TC_DISPATCH
+  return TC_ERR_UNSUPPORTED;
+}
+
+int launch_den(const DenParams &p, hipStream_t stream) { return launch_den_mode(p, 0, stream); }
+
+}  // namespace tc

@@ -1,0 +1,282 @@
+// Numerator forward-backward and the scalar epilogue of the chain objective for gfx950.
+//
+// [K] NumeratorComputation (chain-numerator.cc) runs a serial CPU loop over the merged supervision
+// FST, bracketed by a device gather and a device scatter-add.  The merged FST factors per sequence
+// (supervision.cpp), so here one wavefront owns one sequence and walks its T time levels in LDS,
+// in the log semiring and in double precision like Kaldi; lanes run over the states of a level.
+// Occupation probabilities are summed per unique (frame, pdf) in arc order (the order Kaldi adds
+// them), then added to the derivative with one plain read-modify-write per unique index -- each
+// (row, pdf) is owned by exactly one lane, so no atomics.
+#include <math.h>
+
+#include "chain_internal.h"
+
+namespace tc {
+
+__device__ __forceinline__ double log_add(double x, double y) {
+  // [K] LogAdd(double, double), kMinLogDiffDouble = log(DBL_EPSILON)
+  double diff;
+  if (x < y) {
+    diff = x - y;
+    x = y;
+  } else {
+    diff = y - x;
+  }
+  if (diff >= -36.04365338911715) return x + log1p(exp(diff));
+  return x;
+}
+
+__global__ __launch_bounds__(64) void num_fwd_bwd_kernel(const NumParams p) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *log_alpha = reinterpret_cast<double *>(lds_raw);
+  double *log_beta = log_alpha + p.lds_states;
+  float *ylp = reinterpret_cast<float *>(log_beta + p.lds_states);  // per unique (frame, pdf): y
+  float *occ = ylp + p.lds_uniq;                                    // per arc: occupation prob
+
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int T = p.T, S = p.S;
+  const int sb = p.t.seq_state_off[q], nst = p.t.seq_state_off[q + 1] - sb;
+  const int ab = p.t.seq_arc_off[q];
+  const int ub = p.t.seq_uniq_off[q], nu = p.t.seq_uniq_off[q + 1] - ub;
+  const int *level = p.t.level_begin + (int64_t)q * (T + 2);
+  const int *out_begin = p.t.out_begin + sb + q;
+  const int *in_begin = p.t.in_begin + sb + q;
+  const int *in_arc = p.t.in_arc + ab;
+  const int *arc_src = p.t.arc_src + ab, *arc_dst = p.t.arc_dst + ab, *arc_uniq = p.t.arc_uniq + ab;
+  const float *arc_logw = p.t.arc_logw + ab;
+  const float *final_logw = p.t.final_logw + sb;
+
+  // gather: [K] nnet_output_.Lookup(nnet_output_indexes_, ...); row = t*S + q
+  for (int u = lane; u < nu; u += 64)
+    ylp[u] = p.y[((int64_t)p.t.uniq_t[ub + u] * S + q) * p.y_stride + p.t.uniq_pdf[ub + u]];
+  for (int i = lane; i < nst; i += 64) log_alpha[i] = -INFINITY;
+  __syncthreads();
+  if (lane == 0) log_alpha[0] = 0.0;
+  __syncthreads();
+
+  // forward: level t+1 states take the log-sum over their in-arcs, in arc order
+  for (int t = 0; t < T; ++t) {
+    const int l0 = level[t + 1], l1 = level[t + 2];
+    for (int st = l0 + lane; st < l1; st += 64) {
+      double acc = -INFINITY;
+      for (int i = in_begin[st]; i < in_begin[st + 1]; ++i) {
+        const int a = in_arc[i];
+        const float sc = ylp[arc_uniq[a]] + arc_logw[a];  // float sum, as Kaldi
+        acc = log_add(acc, (double)sc + log_alpha[arc_src[a]]);
+      }
+      log_alpha[st] = acc;
+    }
+    __syncthreads();
+  }
+  // total: log-add over final states in state order (lane 0; a handful of states)
+  double tot = -INFINITY;
+  if (lane == 0) {
+    for (int st = level[T]; st < level[T + 1]; ++st)
+      if (final_logw[st] != -INFINITY) tot = log_add(tot, log_alpha[st] + (double)final_logw[st]);
+    log_beta[0] = tot;  // broadcast slot, overwritten below
+  }
+  __syncthreads();
+  tot = log_beta[0];
+  __syncthreads();
+  if (lane == 0) p.seq_logprob[q] = tot;
+  if (p.deriv == nullptr && p.xent == nullptr) return;
+
+  // backward
+  for (int st = level[T] + lane; st < level[T + 1]; st += 64) log_beta[st] = (double)final_logw[st];
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const int l0 = level[t], l1 = level[t + 1];
+    for (int st = l0 + lane; st < l1; st += 64) {
+      double this_log_beta = -INFINITY;  // interior states are not final
+      const double this_log_alpha = log_alpha[st];
+      for (int a = out_begin[st]; a < out_begin[st + 1]; ++a) {
+        const double next_log_beta = log_beta[arc_dst[a]];
+        const float sc = ylp[arc_uniq[a]] + arc_logw[a];
+        this_log_beta = log_add(this_log_beta, (double)sc + next_log_beta);
+        const float occupation_logprob = (float)(this_log_alpha + (double)sc + next_log_beta - tot);
+        occ[a] = __expf(occupation_logprob);
+      }
+      log_beta[st] = this_log_beta;
+    }
+    __syncthreads();
+  }
+  // scatter: [K] AddElements(weight, indexes, derivs)
+  const int *uniq_begin = p.t.uniq_begin + ub + q;
+  const int *uniq_arc = p.t.uniq_arc + ab;
+  for (int u = lane; u < nu; u += 64) {
+    float sum = 0.f;
+    for (int i = uniq_begin[u]; i < uniq_begin[u + 1]; ++i) sum += occ[uniq_arc[i]];
+    const float v = p.weight * sum;
+    const int64_t row = (int64_t)p.t.uniq_t[ub + u] * S + q;
+    const int pdf = p.t.uniq_pdf[ub + u];
+    if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += v;
+    if (p.xent) p.xent[row * p.xent_stride + pdf] = v;
+  }
+}
+
+int launch_num(const NumParams &p, hipStream_t stream) {
+  const size_t lds = (size_t)p.lds_states * 16 + (size_t)p.lds_uniq * 4 + (size_t)p.lds_arcs * 4;
+  if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
+  TC_HIP_CHECK(hipFuncSetAttribute((const void *)num_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+  hipLaunchKernelGGL(num_fwd_bwd_kernel, dim3(p.S), dim3(64), lds, stream, p);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+// ---- scalar epilogue: [K] ComputeChainObjfAndDeriv after the two computations --------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const double *den_lp, const double *num_lp, const double *y2,
+                                                       const float *ab, const float *gs, int S, int T,
+                                                       float sup_weight, float l2, int have_deriv, float *results,
+                                                       int32_t *fail_flag) {
+  __shared__ double sh[4][256];
+  const int tid = threadIdx.x;
+  double d = 0, n = 0, q = 0, a = 0, g = 0;
+  // fixed-order partial sums: thread i takes sequences i, i+256, ... (deterministic)
+  for (int s = tid; s < S; s += 256) {
+    d += den_lp[s];
+    n += num_lp ? num_lp[s] : 0.0;
+    q += y2[s];
+    if (have_deriv) {
+      a += (double)ab[s];
+      g += (double)gs[s];
+    }
+  }
+  sh[0][tid] = d;
+  sh[1][tid] = n;
+  sh[2][tid] = q;
+  sh[3][tid] = a;
+  __syncthreads();
+  __shared__ double sh_g[256];
+  sh_g[tid] = g;
+  __syncthreads();
+  if (tid == 0) {
+    double D = 0, N = 0, Q = 0, A = 0, G = 0;
+    for (int i = 0; i < 256; ++i) {
+      D += sh[0][i];
+      N += sh[1][i];
+      Q += sh[2][i];
+      A += sh[3][i];
+      G += sh_g[i];
+    }
+    const float num_logprob_weighted = (float)(N * (double)sup_weight);
+    const float den_logprob = (float)D;
+    float objf = num_logprob_weighted - sup_weight * den_logprob;
+    const float weight = sup_weight * (float)S * (float)T;
+    bool ok = true;
+    if (have_deriv) {
+      // [K] BetaGeneralFrameDebug(0)
+      if (fabs(A - (double)S) > 2.0 || !(A - A == 0.0)) ok = false;
+      if (fabs(G - (double)S) > 2.0 || !(G - G == 0.0)) ok = false;
+    }
+    int fail = 0;
+    if (!(objf - objf == 0.0f) || !ok) {
+      objf = -10.0f * weight;
+      fail = 1;
+    }
+    float l2_term = 0.f;
+    if (l2 != 0.0f) l2_term = (float)(-0.5 * (double)(sup_weight * l2) * (double)(float)Q);
+    results[0] = objf;
+    results[1] = l2_term;
+    results[2] = weight;
+    *fail_flag = fail;
+  }
+}
+
+int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
+                    int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, den_lp, num_lp, y2, ab, gs, S, T, sup_weight, l2,
+                     have_deriv, results, fail_flag);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+// Resets the derivative outputs when the finalize step flagged a numerical failure (rare path; exits
+// after one uniform load otherwise).  [K] zeroes both derivatives and only then adds the l2 term, so
+// deriv becomes -l2_scale*y and xent_deriv 0.
+__global__ __launch_bounds__(256) void zero_on_fail_kernel(const int32_t *fail_flag, float *a, int64_t a_stride,
+                                                           float *b, int64_t b_stride, const float *y,
+                                                           int64_t y_stride, float l2_scale, int64_t rows, int cols) {
+  if (*fail_flag == 0) return;
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    if (a) a[r * a_stride + c] = -l2_scale * y[r * y_stride + c];
+    if (b) b[r * b_stride + c] = 0.f;
+  }
+}
+
+int launch_zero_on_fail(const int32_t *fail_flag, float *a, int64_t a_stride, float *b, int64_t b_stride,
+                        const float *y, int64_t y_stride, float l2_scale, int64_t rows, int cols,
+                        hipStream_t stream) {
+  if (!a && !b) return TC_OK;
+  hipLaunchKernelGGL(zero_on_fail_kernel, dim3(1024), dim3(256), 0, stream, fail_flag, a, a_stride, b, b_stride, y, y_stride,
+                     l2_scale, rows, cols);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+// Reduction used by the split entry point tc_den_forward_backward.
+__global__ __launch_bounds__(256) void den_reduce_kernel(const double *den_lp, const float *ab, const float *gs, int S,
+                                                         double *logprob_out, int32_t *status_out) {
+  __shared__ double sh[3][256];
+  const int tid = threadIdx.x;
+  double d = 0, a = 0, g = 0;
+  for (int s = tid; s < S; s += 256) {
+    d += den_lp[s];
+    if (ab) {
+      a += (double)ab[s];
+      g += (double)gs[s];
+    }
+  }
+  sh[0][tid] = d;
+  sh[1][tid] = a;
+  sh[2][tid] = g;
+  __syncthreads();
+  if (tid == 0) {
+    double D = 0, A = 0, G = 0;
+    for (int i = 0; i < 256; ++i) {
+      D += sh[0][i];
+      A += sh[1][i];
+      G += sh[2][i];
+    }
+    if (logprob_out) *logprob_out = D;
+    if (status_out) {
+      int bad = 0;
+      if (!(D - D == 0.0)) bad = 1;
+      if (ab && (fabs(A - (double)S) > 2.0 || fabs(G - (double)S) > 2.0 || !(A - A == 0.0) || !(G - G == 0.0))) bad = 1;
+      *status_out = bad;
+    }
+  }
+}
+
+int launch_den_reduce(const double *den_lp, const float *ab, const float *gs, int S, double *logprob_out,
+                      int32_t *status_out, hipStream_t stream) {
+  hipLaunchKernelGGL(den_reduce_kernel, dim3(1), dim3(256), 0, stream, den_lp, ab, gs, S, logprob_out, status_out);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+__global__ __launch_bounds__(256) void sum_double_kernel(const double *in, int n, double scale, double *out) {
+  __shared__ double sh[256];
+  const int tid = threadIdx.x;
+  double d = 0;
+  for (int i = tid; i < n; i += 256) d += in[i];
+  sh[tid] = d;
+  __syncthreads();
+  if (tid == 0) {
+    double D = 0;
+    for (int i = 0; i < 256; ++i) D += sh[i];
+    *out = D * scale;
+  }
+}
+
+int launch_sum_double(const double *in, int n, double scale, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(256), 0, stream, in, n, scale, out);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+}  // namespace tc

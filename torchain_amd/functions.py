@@ -1,0 +1,135 @@
+"""``chain_loss`` / ``ChainResults``: the autograd wrapper of the reference
+(``torchain/functions.py:9-138``) on top of the HIP C ABI.
+
+Same names, argument meaning, defaults and quirks as the reference:
+
+* ``ChainResults.data`` is a CPU float tensor ``[objf, l2_term, weight]``; ``loss = -objf/weight``
+  (l2 not included, ``functions.py:19``).
+* ``chain_loss`` accepts ``(B, C, T)`` or ``(T*B, C)`` input; 3-D input is permuted to frame-major
+  rows ``t*B + b`` (``functions.py:118-125``).
+* backward returns ``-mmi_grad`` for the input and ``-xent_regularize * xent_grad`` for
+  ``xent_input``; ``grad_output`` is ignored and nothing is divided by ``weight``
+  (``functions.py:106-115``).
+* ``kaldi_way=False`` re-runs the whole objective on ``xent_input`` and overwrites ``results`` and
+  the MMI gradient with that second call's outputs, as the reference does (``functions.py:96-103``).
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import io
+from ._lib import check, lib
+
+
+class ChainResults:
+    def __init__(self):
+        self.data = torch.zeros(3)
+
+    def __repr__(self):
+        return "ChainResults(loss=%f, objf=%f, l2_term=%f, weight=%lf)" % (
+            self.loss, self.data[0], self.data[1], self.data[2])
+
+    @property
+    def loss(self):
+        return -self.data[0] / self.data[2]
+
+
+_workspaces = {}
+
+
+def _workspace(device, stream, nbytes):
+    key = (device.index, stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, nnet_output_deriv,
+                                 xent_output_deriv, l2_regularize, leaky_hmm_coefficient, xent_regularize):
+    """The hot call: replaces ``my_lib.my_lib_ComputeChainObjfAndDeriv`` (``src/my_lib.h:33-42``).
+    ``results`` is the CPU float[3] tensor of ``ChainResults`` and is filled on return."""
+    assert nnet_output.is_cuda, "Only the HIP (ROCm) implementation is available"
+    if nnet_output.dim() != 2 or nnet_output.stride(1) != 1 or nnet_output.dtype != torch.float32:
+        raise ValueError("nnet_output must be a 2-D float32 tensor with unit column stride")
+    den_ptr = den_graph.ptr if isinstance(den_graph, io.DenominatorGraph) else den_graph
+    sup_ptr = supervision.ptr if isinstance(supervision, io.Supervision) else supervision
+    rows, cols = nnet_output.shape
+    device = nnet_output.device
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        n_seq = lib.tc_supervision_num_sequence(sup_ptr)
+        n_frame = lib.tc_supervision_num_frame(sup_ptr)
+        nbytes = lib.tc_chain_workspace_bytes(den_ptr, n_seq, n_frame)
+        if nbytes < 0:
+            check(int(nbytes), "tc_chain_workspace_bytes")
+        ws = _workspace(device, stream, nbytes)
+        res_dev = torch.empty(3, dtype=torch.float32, device=device)
+        for t in (nnet_output_deriv, xent_output_deriv):
+            if t is not None and (t.dim() != 2 or t.stride(1) != 1 or t.shape != nnet_output.shape):
+                raise ValueError("derivative tensors must match nnet_output and have unit column stride")
+        rc = lib.tc_chain_objf_and_deriv(
+            den_ptr, sup_ptr, _ptr(nnet_output), rows, cols, nnet_output.stride(0), _ptr(res_dev),
+            _ptr(nnet_output_deriv), nnet_output_deriv.stride(0) if nnet_output_deriv is not None else 0,
+            _ptr(xent_output_deriv), xent_output_deriv.stride(0) if xent_output_deriv is not None else 0,
+            float(l2_regularize), float(leaky_hmm_coefficient), float(xent_regularize), _ptr(ws), ws.numel(),
+            device.index, C.c_void_p(stream))
+        check(rc, "tc_chain_objf_and_deriv")
+        results.copy_(res_dev)  # 12-byte D2H, the one host sync of the step (reference: >= 4)
+    return results
+
+
+class _ChainLoss(Function):
+    """Lattice-free MMI loss; see the reference docstring ``torchain/functions.py:23-60`` for the
+    meaning of every argument (identical here)."""
+
+    @staticmethod
+    def forward(ctx, input, xent_input, results, den_graph, supervision,
+                l2_regularize, leaky_hmm_coefficient, xent_regularize=0.0, kaldi_way=False):
+        assert input.is_cuda, "Only CUDA implementation is available"
+        mmi_grad = torch.empty_like(input, memory_format=torch.contiguous_format)
+        use_xent = xent_input is not None and xent_regularize != 0.0
+        xent_grad = torch.empty_like(xent_input, memory_format=torch.contiguous_format) if use_xent else None
+        compute_chain_objf_and_deriv(den_graph, supervision, input.detach(), results.data, mmi_grad, xent_grad,
+                                     l2_regularize, leaky_hmm_coefficient, xent_regularize)
+        ctx.mmi_grad = mmi_grad
+        if use_xent:
+            if kaldi_way:
+                ctx.xent_grad = xent_regularize * xent_grad
+            else:
+                compute_chain_objf_and_deriv(den_graph, supervision, xent_input.detach(), results.data, mmi_grad,
+                                             xent_grad, l2_regularize, leaky_hmm_coefficient, xent_regularize)
+                ctx.xent_grad = xent_regularize * xent_grad
+        return input.new_tensor([float(results.loss)])
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        xent_grad = -ctx.xent_grad if hasattr(ctx, "xent_grad") else None
+        return (-ctx.mmi_grad, xent_grad, None, None, None, None, None, None, None)
+
+
+def to2d(x):
+    if x.dim() == 3:  # (B, C, T)
+        n_pdf = x.shape[1]
+        x = x.permute(2, 0, 1).contiguous().view(-1, n_pdf)  # (T * B, C)
+    assert x.dim() == 2
+    return x
+
+
+def chain_loss(input, den_graph, supervision,
+               l2_regularize=0.0, leaky_hmm_coefficient=1e-5,
+               xent_regularize=0.0, xent_input=None, kaldi_way=False):
+    input = to2d(input)
+    if xent_input is not None:
+        xent_input = to2d(xent_input)
+
+    results = ChainResults()
+    loss = _ChainLoss.apply(input, xent_input, results, den_graph, supervision,
+                            l2_regularize, leaky_hmm_coefficient, xent_regularize, kaldi_way)
+    return loss, results
