@@ -10,11 +10,14 @@ from torchain_amd._lib import check, lib
 from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv
 
 
-def rel_err(a, b):
-    """max |a-b| / max |b|  (the '1e-4 relative' of BASELINE.json's north_star, matrix-wise)."""
+def rel_err(a, b, floor=0.0):
+    """max |a-b| / max(max |b|, floor)  (the '1e-4 relative' of BASELINE.json's north_star,
+    matrix-wise).  ``floor`` is the natural scale of the quantity when the reference itself is a
+    difference of larger terms: the derivative is w*(gamma_num - gamma_den) with both posteriors in
+    [0, 1], so its scale is the supervision weight even where the two cancel."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-30))
 
 
 def hip_chain(fst, sup, y, l2=0.0, leaky=1e-5, xent=False, want_deriv=True, device="cuda:0", graph=None,

@@ -26,8 +26,8 @@ def _check_full(oracle, fst, S, T, l2, leaky, weight=1.0, seed=5, zero=False, ro
     assert abs(res[0] - ref["objf"]) <= REL * abs(ref["objf"]), (res, ref["results"])
     assert abs(res[1] - ref["l2_term"]) <= REL * max(abs(ref["l2_term"]), 1e-30), (res, ref["results"])
     assert res[2] == ref["weight"] == weight * S * T  # README.md:12-32 pins weight = w*S*T
-    assert rel_err(out["deriv"], ref["deriv"]) <= REL
-    assert rel_err(out["xent_deriv"], ref["xent_deriv"]) <= REL
+    assert rel_err(out["deriv"], ref["deriv"], floor=weight) <= REL
+    assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=weight) <= REL
     return out, ref
 
 

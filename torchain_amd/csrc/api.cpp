@@ -2,6 +2,7 @@
 // bridge src/my_lib_chain.cpp:104-136: validates the borrowed tensors the way common::make_matrix
 // does (2-D, unit column stride, src/common.hpp:109-117), carves the caller's workspace, and enqueues
 // the kernels on the caller's stream.  No allocation, no host synchronisation, no globals.
+#include <algorithm>
 #include <cstring>
 
 #include "chain_internal.h"
@@ -76,7 +77,8 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
     std::lock_guard<std::mutex> lock(g->mu);
     d = g->dev[device];
   }
-  if (!compute_layout(g->H, g->P, T, &p->L)) return TC_ERR_UNSUPPORTED;
+  if (!compute_layout(g->H, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &p->L))
+    return TC_ERR_UNSUPPORTED;
   p->fwd = d.fwd;
   p->bwd = d.bwd;
   p->pi = d.pi;

@@ -29,23 +29,42 @@ struct ArcRec {
 };
 
 // A "row" is the in-arc list (forward) or out-arc list (backward) of one state, at most kMaxRowLen
-// long.  Rows are sorted by length and dealt 64 at a time into "slots"; lane l of a slot walks row l,
-// so one wave instruction loads 64 consecutive ArcRec (512 B, coalesced).  Slots are balanced over the
-// 16 waves.  Padding records have w = 0 and index 0.
+// long.  Rows are sorted by length and dealt 64 at a time into "slots"; lane l of a slot walks row l.
+// Every wave gets one flat, self-describing stream of 8-byte cells laid out [cell][lane], so a wave
+// instruction loads 64 consecutive cells (512 B, coalesced) and the whole stream can be prefetched
+// many cells ahead with no dependent address computation:
+//   ROW cell  : idx = kRowMarker (bit 31) | state, w bits = accumulator slot of the row that starts
+//               here.  It commits the previous row's sum with a plain LDS store.  All 64 lanes of a
+//               wave hit their ROW cells at the same stream position, so the test is a scalar branch.
+//   arc cell  : {w, state | pdf << 16}, 14-bit state and pdf (both tables must fit LDS anyway)
+//   padding   : arc cell with w = 0, index 0 (adds 0)
+// A stream ends with a ROW(dummy) cell and is padded to a multiple of kStreamUnroll cells; the whole
+// array ends with kStreamUnroll / 2 extra padding cells so the prefetch never needs a bounds check.
+//
+// Every row owns its accumulator slot, so no LDS float atomics are needed (ds_add_f32 costs 192
+// cycles per wave-instruction on gfx950, profiles/microbench): a state whose arc list fits one row
+// uses slot = state; each further chunk of a longer list gets a private slot >= Hs + 4, and the
+// thread that owns the state folds those slots in before it reads the sum ("fix-up" list, sorted by
+// owner thread).
+constexpr uint32_t kRowMarker = 0x80000000u;
+constexpr int kStreamUnroll = 16;
+constexpr int kMaxIndex = 1 << 14;
+
 struct ScheduleHost {
-  std::vector<ArcRec> recs;        // [slot][step][lane]
-  std::vector<uint32_t> rowid;     // [slot][lane]: state the row accumulates into (Hs = dummy)
-  std::vector<int2> slots;         // per slot {record offset, steps}; each wave's slots contiguous
-  std::vector<int32_t> wave_begin; // kWaves + 1
+  std::vector<ArcRec> cells;       // all waves' streams, [cell][lane]
+  std::vector<int2> wave_range;    // kWaves x {first cell, number of cells (multiple of kStreamUnroll)}
+  std::vector<int32_t> fix_begin;  // kThreads + 1: range of fix-up entries owned by each thread
+  std::vector<int2> fix;           // {state, extra slot}
+  int32_t extra_slots = 0;         // accumulator slots beyond Hs + 4
   int64_t real_arcs = 0, padded_arcs = 0;
   int32_t rows = 0;
 };
 
 struct ScheduleDev {
-  const ArcRec *recs;
-  const uint32_t *rowid;
-  const int2 *slots;
-  const int32_t *wave_begin;
+  const ArcRec *cells;
+  const int2 *wave_range;
+  const int32_t *fix_begin;
+  const int2 *fix;
 };
 
 struct DenGraphDev {
@@ -61,6 +80,7 @@ struct DenLayout {
   int off_acc, off_p, off_g, off_al, off_red, off_asum, total_floats;
   bool alpha_in_lds;
   int JV, PV;           // float4s of states / pdfs owned per thread
+  int acc_floats;       // size of the accumulator region: Hs + 4 + extra slots, rounded to 4
 };
 
 struct DenParams {
@@ -153,7 +173,7 @@ struct tc_supervision {
 namespace tc {
 
 int build_schedules(tc_den_graph *g);
-bool compute_layout(int H, int P, int T_hint, DenLayout *L);
+bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L);
 int64_t layout_lds_bytes(const DenLayout &L, int T);
 
 int launch_den(const DenParams &p, hipStream_t stream);

@@ -17,17 +17,18 @@ thread_local int g_last_hip_error = 0;
 static int round4(int x) { return (x + 3) & ~3; }
 
 // Lays the per-frame working set of one sequence out in LDS.  Returns false if it cannot fit.
-bool compute_layout(int H, int P, int T_hint, DenLayout *L) {
+bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L) {
   L->Hs = round4(H);
   L->Ps = round4(P);
   L->JV = (L->Hs / 4 + kThreads - 1) / kThreads;
   L->PV = (L->Ps / 4 + kThreads - 1) / kThreads;
-  if (H > 65535 || P > 65535) return false;  // 16-bit indices in ArcRec
+  if (H > kMaxIndex || P > kMaxIndex) return false;  // 14-bit indices in ArcRec
   for (int with_alpha = 1; with_alpha >= 0; --with_alpha) {
     int off = 0;
     off += L->Hs;  // A / B
     L->off_acc = off;
-    off += L->Hs + 4;  // ACC / BACC (+ dummy row)
+    L->acc_floats = round4(L->Hs + 4 + extra_slots);
+    off += L->acc_floats;  // ACC / BACC (+ dummy row + private slots of split rows)
     L->off_p = off;
     off += L->Ps;
     L->off_g = off;
@@ -54,7 +55,7 @@ int64_t layout_lds_bytes(const DenLayout &L, int T) {
 static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_t *other, const int32_t *pdf,
                       const float *prob, ScheduleHost *out) {
   struct Row {
-    int32_t state, len;
+    int32_t state, len, slot;
     int64_t begin;
   };
   // stable counting sort of arcs by key keeps the FST's arc order inside a row
@@ -65,68 +66,89 @@ static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_
   for (int64_t a = 0; a < A; ++a) order[fill[key[a]]++] = a;
 
   std::vector<Row> rows;
+  std::vector<std::vector<int2>> fix_of_thread(kThreads);
+  int extra = 0;
   for (int h = 0; h < H; ++h) {
     int64_t b = first[h], e = first[h + 1];
+    bool first_chunk = true;
     while (b < e) {
       int len = (int)std::min<int64_t>(kMaxRowLen, e - b);
-      rows.push_back({h, len, b});
+      int slot = h;
+      if (!first_chunk) {
+        slot = Hs + 4 + extra++;
+        fix_of_thread[(h >> 2) % kThreads].push_back(make_int2(h, slot));  // owner of state h (float4 ownership)
+      }
+      rows.push_back({h, len, slot, b});
+      first_chunk = false;
       b += len;
     }
   }
+  out->extra_slots = extra;
+  out->fix.clear();
+  out->fix_begin.assign(kThreads + 1, 0);
+  for (int t = 0; t < kThreads; ++t) {
+    out->fix_begin[t] = (int)out->fix.size();
+    for (auto &f : fix_of_thread[t]) out->fix.push_back(f);
+  }
+  out->fix_begin[kThreads] = (int)out->fix.size();
+  if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
   std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.len > y.len; });
   const int nrows = (int)rows.size();
   const int nslots = (nrows + 63) / 64;
 
-  // longest-processing-time assignment of slots to waves
+  // longest-processing-time assignment of slots to waves (a slot costs its steps + the ROW cell)
   std::vector<std::vector<int>> per_wave(kWaves);
   std::vector<int64_t> load(kWaves, 0);
   for (int sidx = 0; sidx < nslots; ++sidx) {
     int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
     per_wave[w].push_back(sidx);
-    load[w] += rows[(size_t)sidx * 64].len;
+    load[w] += rows[(size_t)sidx * 64].len + 1;
   }
-  out->recs.clear();
-  out->rowid.clear();
-  out->slots.clear();
-  out->wave_begin.assign(kWaves + 1, 0);
+  auto bits = [](uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  out->cells.clear();
+  out->wave_range.assign(kWaves, make_int2(0, 0));
+  int64_t arc_cells = 0;
   for (int w = 0; w < kWaves; ++w) {
-    out->wave_begin[w] = (int)out->slots.size();
+    const size_t first = out->cells.size() / 64;
     for (int sidx : per_wave[w]) {
       const int steps = rows[(size_t)sidx * 64].len;
-      const int off = (int)out->recs.size();
-      out->slots.push_back(make_int2(off, steps));
-      out->recs.resize(out->recs.size() + (size_t)steps * 64, ArcRec{0.f, 0u});
+      const size_t off = out->cells.size();
+      out->cells.resize(off + (size_t)(steps + 1) * 64, ArcRec{0.f, 0u});
+      arc_cells += (int64_t)steps * 64;
       for (int l = 0; l < 64; ++l) {
-        int r = sidx * 64 + l;
-        if (r >= nrows) {
-          out->rowid.push_back((uint32_t)Hs);
-          continue;
-        }
-        out->rowid.push_back((uint32_t)rows[r].state);
+        const int r = sidx * 64 + l;
+        out->cells[off + l] = r < nrows ? ArcRec{bits((uint32_t)rows[r].slot), kRowMarker | (uint32_t)rows[r].state}
+                                        : ArcRec{bits((uint32_t)Hs), kRowMarker};
+        if (r >= nrows) continue;
         for (int k = 0; k < rows[r].len; ++k) {
-          int64_t a = order[rows[r].begin + k];
-          out->recs[(size_t)off + (size_t)k * 64 + l] =
-              ArcRec{prob[a], (uint32_t)other[a] | ((uint32_t)pdf[a] << 16)};
+          const int64_t a = order[rows[r].begin + k];
+          out->cells[off + (size_t)(k + 1) * 64 + l] = ArcRec{prob[a], (uint32_t)other[a] | ((uint32_t)pdf[a] << 16)};
         }
       }
     }
+    // closing ROW(dummy) cell commits the last row; then pad to the unroll factor
+    for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{bits((uint32_t)Hs), kRowMarker});
+    while ((out->cells.size() / 64 - first) % kStreamUnroll != 0)
+      for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
+    out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
   }
-  out->wave_begin[kWaves] = (int)out->slots.size();
+  for (int i = 0; i < 64 * (kStreamUnroll / 2); ++i) out->cells.push_back(ArcRec{0.f, 0u});
   out->real_arcs = A;
-  out->padded_arcs = (int64_t)out->recs.size();
+  out->padded_arcs = arc_cells;
   out->rows = nrows;
-  if (out->recs.empty()) out->recs.push_back(ArcRec{0.f, 0u});
-  if (out->rowid.empty()) out->rowid.push_back((uint32_t)Hs);
-  if (out->slots.empty()) out->slots.push_back(make_int2(0, 0));
 }
 
 int build_schedules(tc_den_graph *g) {
-  g->layout_ok = compute_layout(g->H, g->P, 256, &g->layout);
   const int Hs = round4(g->H);
   // forward: alpha_{t+1}(dst) sums over in-arcs, gathers alpha'_t(src)
   build_one(g->H, Hs, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->fwd);
   // backward: beta'_t(src) sums over out-arcs, gathers beta_{t+1}(dst)
   build_one(g->H, Hs, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->bwd);
+  g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &g->layout);
   return TC_OK;
 }
 
@@ -335,15 +357,15 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   std::vector<float> pi_pad(Hs + 4, 0.f);
   std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
   Part parts[] = {
-      {g->fwd.recs.data(), g->fwd.recs.size() * sizeof(ArcRec), 0},
-      {g->fwd.rowid.data(), g->fwd.rowid.size() * 4, 0},
-      {g->fwd.slots.data(), g->fwd.slots.size() * sizeof(int2), 0},
-      {g->fwd.wave_begin.data(), g->fwd.wave_begin.size() * 4, 0},
-      {g->bwd.recs.data(), g->bwd.recs.size() * sizeof(ArcRec), 0},
-      {g->bwd.rowid.data(), g->bwd.rowid.size() * 4, 0},
-      {g->bwd.slots.data(), g->bwd.slots.size() * sizeof(int2), 0},
-      {g->bwd.wave_begin.data(), g->bwd.wave_begin.size() * 4, 0},
+      {g->fwd.cells.data(), g->fwd.cells.size() * sizeof(ArcRec), 0},
+      {g->fwd.wave_range.data(), g->fwd.wave_range.size() * sizeof(int2), 0},
+      {g->bwd.cells.data(), g->bwd.cells.size() * sizeof(ArcRec), 0},
+      {g->bwd.wave_range.data(), g->bwd.wave_range.size() * sizeof(int2), 0},
       {pi_pad.data(), pi_pad.size() * 4, 0},
+      {g->fwd.fix_begin.data(), g->fwd.fix_begin.size() * 4, 0},
+      {g->fwd.fix.data(), g->fwd.fix.size() * sizeof(int2), 0},
+      {g->bwd.fix_begin.data(), g->bwd.fix_begin.size() * 4, 0},
+      {g->bwd.fix.data(), g->bwd.fix.size() * sizeof(int2), 0},
   };
   size_t total = 0;
   for (auto &p : parts) {
@@ -365,11 +387,11 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   }
   DenGraphDev d;
   d.blob = blob;
-  d.fwd = ScheduleDev{(const ArcRec *)(blob + parts[0].off), (const uint32_t *)(blob + parts[1].off),
-                      (const int2 *)(blob + parts[2].off), (const int32_t *)(blob + parts[3].off)};
-  d.bwd = ScheduleDev{(const ArcRec *)(blob + parts[4].off), (const uint32_t *)(blob + parts[5].off),
-                      (const int2 *)(blob + parts[6].off), (const int32_t *)(blob + parts[7].off)};
-  d.pi = (const float *)(blob + parts[8].off);
+  d.fwd = ScheduleDev{(const ArcRec *)(blob + parts[0].off), (const int2 *)(blob + parts[1].off),
+                      (const int32_t *)(blob + parts[5].off), (const int2 *)(blob + parts[6].off)};
+  d.bwd = ScheduleDev{(const ArcRec *)(blob + parts[2].off), (const int2 *)(blob + parts[3].off),
+                      (const int32_t *)(blob + parts[7].off), (const int2 *)(blob + parts[8].off)};
+  d.pi = (const float *)(blob + parts[4].off);
   g->dev[device] = d;
   return TC_OK;
 }

@@ -37,7 +37,9 @@ __device__ __forceinline__ float block_sum(float v, float *red, int wave, int la
 
 __device__ __forceinline__ float exp_limited(float x) {
   // [K] later Kaldi: ApplyExpLimited(-30, 30); identical to the 22fbdd ApplyExp() for |y| < 30
-  x = fminf(fmaxf(x, -30.0f), 30.0f);
+  // compare-and-clamp (not fminf/fmaxf) so that a NaN input stays NaN and trips the objf check
+  x = x < -30.0f ? -30.0f : x;
+  x = x > 30.0f ? 30.0f : x;
   return __expf(x);
 }
 
@@ -65,59 +67,96 @@ __device__ __forceinline__ void store_row4(float *row, int i, int n, int vec, fl
   }
 }
 
-// Walks this wave's slots of the schedule.  FWD: acc(row) += alpha'(src) * w * p(pdf).
-// BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row)/alpha_sum.
+// One chunk of kChunk cells of a wave's stream.  All gathers of the chunk are issued before the first
+// use (ROW cells carry index 0, so their gathers are harmless broadcasts); only the commit of a
+// finished row sits behind a branch, and that branch is scalar because all 64 lanes hit their ROW
+// cells at the same stream position.
+//   FWD: acc(row) += alpha'(src) * w * p(pdf)
+//   BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
+constexpr int kChunk = kStreamUnroll / 2;
+// gamma_t(pdf) is an occupation posterior (sum over pdfs = 1), accumulated as unsigned fixed point
+// with 31 fractional bits: quantum 4.7e-10, exact (order-independent, bitwise reproducible) sums.
+constexpr float kGammaScale = 2147483648.0f;
+constexpr float kGammaInvScale = 1.0f / 2147483648.0f;
+
+// Folds the private slots of split rows into their state's accumulator; called by the thread that
+// owns the state, after the barrier that follows the arc walk and before it reads the sum.
+__device__ __forceinline__ void fold_split_rows(const ScheduleDev &sc, int fx0, int fx1, float *ACC) {
+  for (int e = fx0; e < fx1; ++e) {
+    const int2 f = sc.fix[e];
+    ACC[f.x] += ACC[f.y];
+  }
+}
+
+struct RowState {
+  uint32_t row;
+  float acc, occf;
+};
+
+template <bool BWD, bool ALPHA_LDS>
+__device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState &rs, const float *__restrict__ SRC,
+                                              const float *__restrict__ PB, float *__restrict__ ACC,
+                                              float *__restrict__ GM, const float *__restrict__ AL,
+                                              const float *__restrict__ hist_t, int H, float inv_asum) {
+  float a[kChunk], pp[kChunk];
+#pragma unroll
+  for (int u = 0; u < kChunk; ++u) {
+    a[u] = SRC[q[u].y & 0x3fffu];
+    pp[u] = PB[(q[u].y >> 16) & 0x3fffu];
+  }
+#pragma unroll
+  for (int u = 0; u < kChunk; ++u) {
+    if ((int)__builtin_amdgcn_readfirstlane(q[u].y) < 0) {  // ROW cell (bit 31)
+      ACC[rs.row] = rs.acc;  // every row owns its slot: plain store, no atomic
+      rs.acc = 0.f;
+      rs.row = q[u].x;
+      if (BWD) {
+        const uint32_t st = q[u].y & 0x3fffu;
+        if (ALPHA_LDS)
+          rs.occf = AL[st] * inv_asum * kGammaScale;
+        else
+          rs.occf = hist_t[st] * inv_asum * kGammaScale;
+      }
+    } else {
+      const float w = __uint_as_float(q[u].x);
+      if (!BWD) {
+        rs.acc = fmaf(a[u] * w, pp[u], rs.acc);
+      } else {
+        const float vf = w * a[u] * pp[u];
+        rs.acc += vf;
+        // gamma in fixed point: integer LDS atomics run at store rate, float ones are lane-serialised
+        atomicAdd(reinterpret_cast<uint32_t *>(GM) + ((q[u].y >> 16) & 0x3fffu), __float2uint_rn(vf * rs.occf));
+      }
+    }
+  }
+}
+
+// Consumes this wave's cell stream with two register buffers in ping-pong: while one chunk is being
+// processed the next one (4 KB per wave) is in flight from L2.
 template <bool BWD, bool ALPHA_LDS>
 __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int lane, const float *__restrict__ SRC,
                                           const float *__restrict__ PB, float *__restrict__ ACC,
                                           float *__restrict__ GM, const float *__restrict__ AL,
                                           const float *__restrict__ hist_t, int H, float inv_asum) {
-  const int sb = __builtin_amdgcn_readfirstlane(sc.wave_begin[wave]);
-  const int se = __builtin_amdgcn_readfirstlane(sc.wave_begin[wave + 1]);
-  for (int sl = sb; sl < se; ++sl) {
-    const int2 d = sc.slots[sl];
-    const int off = __builtin_amdgcn_readfirstlane(d.x);
-    const int steps = __builtin_amdgcn_readfirstlane(d.y);
-    const uint2 *__restrict__ r = reinterpret_cast<const uint2 *>(sc.recs) + off + lane;
-    const uint32_t row = sc.rowid[sl * 64 + lane];
-    float occf = 0.f;
-    if (BWD) {
-      if (ALPHA_LDS)
-        occf = AL[row] * inv_asum;
-      else
-        occf = ((int)row < H ? hist_t[row] : 0.f) * inv_asum;
-    }
-    float acc = 0.f;
-    int k = 0;
-    for (; k + 4 <= steps; k += 4) {
-      uint2 q0 = r[(k + 0) * 64], q1 = r[(k + 1) * 64], q2 = r[(k + 2) * 64], q3 = r[(k + 3) * 64];
+  const int2 range = sc.wave_range[wave];
+  const int first = __builtin_amdgcn_readfirstlane(range.x);
+  const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnroll
+  const uint2 *__restrict__ r = reinterpret_cast<const uint2 *>(sc.cells) + (int64_t)first * 64 + lane;
+  uint2 qa[kChunk], qb[kChunk];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint2 q = u == 0 ? q0 : (u == 1 ? q1 : (u == 2 ? q2 : q3));
-        const float w = __uint_as_float(q.x);
-        const uint32_t st = q.y & 0xffffu, pdf = q.y >> 16;
-        if (!BWD) {
-          acc = fmaf(SRC[st] * w, PB[pdf], acc);
-        } else {
-          const float vf = w * SRC[st] * PB[pdf];
-          acc += vf;
-          atomicAdd(&GM[pdf], vf * occf);
-        }
-      }
-    }
-    for (; k < steps; ++k) {
-      const uint2 q = r[k * 64];
-      const float w = __uint_as_float(q.x);
-      const uint32_t st = q.y & 0xffffu, pdf = q.y >> 16;
-      if (!BWD) {
-        acc = fmaf(SRC[st] * w, PB[pdf], acc);
-      } else {
-        const float vf = w * SRC[st] * PB[pdf];
-        acc += vf;
-        atomicAdd(&GM[pdf], vf * occf);
-      }
-    }
-    atomicAdd(&ACC[row], acc);
+  for (int u = 0; u < kChunk; ++u) qa[u] = r[u * 64];
+  RowState rs;
+  rs.row = ((uint32_t)H + 3u) & ~3u;  // the dummy row, until the stream's first ROW cell
+  rs.acc = 0.f;
+  rs.occf = 0.f;
+  for (int c = 0; c < ncells; c += kStreamUnroll) {
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) qb[u] = r[(c + kChunk + u) * 64];
+    process_chunk<BWD, ALPHA_LDS>(qa, rs, SRC, PB, ACC, GM, AL, hist_t, H, inv_asum);
+    // the stream is followed by kChunk readable padding cells, so this load needs no guard
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) qa[u] = r[(c + kStreamUnroll + u) * 64];
+    process_chunk<BWD, ALPHA_LDS>(qb, rs, SRC, PB, ACC, GM, AL, hist_t, H, inv_asum);
   }
 }
 
@@ -130,9 +169,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const int H = p.H, P = p.P, S = p.S, T = p.T;
   const int Hs = p.L.Hs, Ps = p.L.Ps;
   float *const A0 = lds;                // alpha'_t (forward) / beta_{t+1} (backward): gather source
-  float *const ACC = lds + p.L.off_acc; // next-frame accumulator (+ dummy row at Hs)
+  float *const ACC = lds + p.L.off_acc; // row accumulators: one per state, dummy at Hs, then split-row slots
   float *const PB = lds + p.L.off_p;    // exp(y_t)
-  float *const GM = lds + p.L.off_g;    // gamma_t (backward only)
+  float *const GM = lds + p.L.off_g;    // gamma_t as u32 fixed point (backward only)
   float *const AL = lds + p.L.off_al;   // alpha'_t (backward only, when it fits)
   float *const red = lds + p.L.off_red;
   float *const asum_h = lds + p.L.off_asum;  // alpha-sum of every frame
@@ -178,6 +217,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     }
   }
   double logsum = 0.0;  // thread 0 only
+  const int ffx0 = p.fwd.fix_begin[tid], ffx1 = p.fwd.fix_begin[tid + 1];
   if (tid == 0) asum_h[0] = asum;
   float inv_prev = 1.0f / asum;
   float asum_prev = asum;
@@ -194,6 +234,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     }
     walk_rows<false, true>(p.fwd, wave, lane, A0, PB, ACC, nullptr, nullptr, nullptr, H, 0.f);
     __syncthreads();  // all row sums committed
+    fold_split_rows(p.fwd, ffx0, ffx1, ACC);
     float4 v4[JV];
     part = 0.f;
 #pragma unroll
@@ -202,7 +243,6 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       v4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (h0 < Hs) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
-        *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);
         v4[j] = make_float4(a.x * inv_prev, a.y * inv_prev, a.z * inv_prev, a.w * inv_prev);
         part += (v4[j].x + v4[j].y) + (v4[j].z + v4[j].w);
       }
@@ -262,6 +302,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   float bsum = block_sum(part, red + 3 * kWaves, wave, lane);  // also orders the A0 reuse below
   float4 areg[JV];
   float4 ycur[PV], ynext[PV];
+  const int bfx0 = p.bwd.fix_begin[tid], bfx1 = p.bwd.fix_begin[tid + 1];
   {
     const float *hist_t = hist + (int64_t)(T - 1) * hist_step;
     const float *yrow = p.y + ((int64_t)(T - 1) * S + s) * p.y_stride;
@@ -272,6 +313,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         float4 b = make_float4(h0 < H ? inv_tot + bsum : 0.f, h0 + 1 < H ? inv_tot + bsum : 0.f,
                                h0 + 2 < H ? inv_tot + bsum : 0.f, h0 + 3 < H ? inv_tot + bsum : 0.f);
         *reinterpret_cast<float4 *>(A0 + h0) = b;
+        *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);  // states with no out-arcs
         if (ALPHA_LDS) *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + h0);
       }
     }
@@ -309,6 +351,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     }
     walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, A0, PB, ACC, GM, AL, hist_t, H, inv_as);
     __syncthreads();  // beta' sums and gamma committed
+    fold_split_rows(p.bwd, bfx0, bfx1, ACC);
     float4 b4[JV];
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
@@ -318,7 +361,6 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (h0 < Hs) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
-        *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);
         b4[j] = make_float4(a.x / asum_t, a.y / asum_t, a.z / asum_t, a.w / asum_t);
         part += (cpi[j].x * b4[j].x + cpi[j].y * b4[j].y) + (cpi[j].z * b4[j].z + cpi[j].w * b4[j].w);
         if (t == 0) {
@@ -334,8 +376,10 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       for (int v = 0; v < PV; ++v) {
         const int i0 = 4 * (tid + kThreads * v);
         if (i0 < Ps) {
-          float4 g = *reinterpret_cast<float4 *>(GM + i0);
+          const uint4 gu = *reinterpret_cast<uint4 *>(GM + i0);
           *reinterpret_cast<float4 *>(GM + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 g = make_float4((float)gu.x * kGammaInvScale, (float)gu.y * kGammaInvScale,
+                                       (float)gu.z * kGammaInvScale, (float)gu.w * kGammaInvScale);
           if (t == 0) part_g += (g.x + g.y) + (g.z + g.w);
           float4 o = make_float4(p.deriv_weight * g.x - p.l2_scale * ycur[v].x,
                                  p.deriv_weight * g.y - p.l2_scale * ycur[v].y,
