@@ -98,6 +98,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->leaky = leaky;
   p->deriv_weight = deriv_weight;
   p->l2_scale = l2_scale;
+  p->stamps = (long long *)w.scalar;
   p->y_vec = (cols % 4 == 0 && y_stride % 4 == 0 && aligned16(y)) ? 1 : 0;
   p->d_vec = (deriv && cols % 4 == 0 && deriv_stride % 4 == 0 && aligned16(deriv)) ? 1 : 0;
   return TC_OK;

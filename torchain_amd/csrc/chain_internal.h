@@ -33,11 +33,15 @@ struct ArcRec {
 // Every wave gets one flat, self-describing stream of 8-byte cells laid out [cell][lane], so a wave
 // instruction loads 64 consecutive cells (512 B, coalesced) and the whole stream can be prefetched
 // many cells ahead with no dependent address computation:
-//   ROW cell  : idx = kRowMarker (bit 31) | state, w bits = accumulator slot of the row that starts
-//               here.  It commits the previous row's sum with a plain LDS store.  All 64 lanes of a
-//               wave hit their ROW cells at the same stream position, so the test is a scalar branch.
-//   arc cell  : {w, state | pdf << 16}, 14-bit state and pdf (both tables must fit LDS anyway)
-//   padding   : arc cell with w = 0, index 0 (adds 0)
+//   arc cell  : {w, pdf*4 | state*4 << 16}: the two LDS byte offsets the lane gathers from, ready to
+//               use (exp(y) sits at LDS offset 0, alpha'/beta at a compile-time base that the ds_read
+//               immediate supplies), so address math is one AND and one shift per cell.
+//   ROW cell  : {accumulator slot of the row that starts here, kRowFlag | state*4 << 16}.  It
+//               commits the previous row's sum with a plain LDS store.  All 64 lanes of a wave hit
+//               their ROW cells at the same stream position; the positions are also published as a
+//               bit mask per 16 cells (row_masks) that the wave reads with scalar loads, so the test
+//               costs no vector instruction.
+//   padding   : arc cell with w = 0, offsets 0 (adds 0)
 // A stream ends with a ROW(dummy) cell and is padded to a multiple of kStreamUnroll cells; the whole
 // array ends with kStreamUnroll / 2 extra padding cells so the prefetch never needs a bounds check.
 //
@@ -46,13 +50,14 @@ struct ArcRec {
 // uses slot = state; each further chunk of a longer list gets a private slot >= Hs + 4, and the
 // thread that owns the state folds those slots in before it reads the sum ("fix-up" list, sorted by
 // owner thread).
-constexpr uint32_t kRowMarker = 0x80000000u;
+constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are free (offsets are multiples of 4)
 constexpr int kStreamUnroll = 16;
 constexpr int kMaxIndex = 1 << 14;
 
 struct ScheduleHost {
   std::vector<ArcRec> cells;       // all waves' streams, [cell][lane]
   std::vector<int2> wave_range;    // kWaves x {first cell, number of cells (multiple of kStreamUnroll)}
+  std::vector<uint32_t> row_masks; // one word per kStreamUnroll cells: bit u set <=> cell u is a ROW cell
   std::vector<int32_t> fix_begin;  // kThreads + 1: range of fix-up entries owned by each thread
   std::vector<int2> fix;           // {state, extra slot}
   int32_t extra_slots = 0;         // accumulator slots beyond Hs + 4
@@ -63,6 +68,7 @@ struct ScheduleHost {
 struct ScheduleDev {
   const ArcRec *cells;
   const int2 *wave_range;
+  const uint32_t *row_masks;
   const int32_t *fix_begin;
   const int2 *fix;
 };
@@ -73,13 +79,14 @@ struct DenGraphDev {
   void *blob = nullptr;
 };
 
-// LDS layout of the fused kernel, in floats.  Forward uses [A | ACC | P]; backward reuses the same
-// space as [B | BACC | P | GAMMA | ALPHA?].
+// LDS layout of the fused kernel, in floats: [P | A | ACC | GAMMA | ALPHA? | red | asum].  exp(y)
+// (P) starts at offset 0 and its region has the compile-time size PV * 4096 of the kernel
+// instantiation, so the gather source A (alpha' forward, beta backward) has a compile-time base.
 struct DenLayout {
   int Hs, Ps;           // H, P rounded up to a multiple of 4
-  int off_acc, off_p, off_g, off_al, off_red, off_asum, total_floats;
+  int off_a, off_acc, off_g, off_al, off_red, off_asum, total_floats;
   bool alpha_in_lds;
-  int JV, PV;           // float4s of states / pdfs owned per thread
+  int JV, PV;           // template instantiation: float4s of states / pdfs owned per thread
   int acc_floats;       // size of the accumulator region: Hs + 4 + extra slots, rounded to 4
 };
 
@@ -99,6 +106,7 @@ struct DenParams {
   float leaky, deriv_weight, l2_scale;
   int y_vec, d_vec;     // rows 16-byte aligned -> float4 path
   DenLayout L;
+  long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
 };
 
 }  // namespace tc

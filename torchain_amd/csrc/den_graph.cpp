@@ -20,17 +20,25 @@ static int round4(int x) { return (x + 3) & ~3; }
 bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L) {
   L->Hs = round4(H);
   L->Ps = round4(P);
-  L->JV = (L->Hs / 4 + kThreads - 1) / kThreads;
-  L->PV = (L->Ps / 4 + kThreads - 1) / kThreads;
-  if (H > kMaxIndex || P > kMaxIndex) return false;  // 14-bit indices in ArcRec
+  const int jv = (L->Hs / 4 + kThreads - 1) / kThreads, pv = (L->Ps / 4 + kThreads - 1) / kThreads;
+  if (H > kMaxIndex || P > kMaxIndex) return false;  // 16-bit byte offsets in ArcRec
+  // the two kernel instantiations (den_kernels.hip): <JV=2, PV=1> and <JV=4, PV=3>
+  if (jv <= 2 && pv <= 1) {
+    L->JV = 2;
+    L->PV = 1;
+  } else if (jv <= 4 && pv <= 3) {
+    L->JV = 4;
+    L->PV = 3;
+  } else {
+    return false;
+  }
   for (int with_alpha = 1; with_alpha >= 0; --with_alpha) {
-    int off = 0;
+    int off = L->PV * 4 * kThreads;  // P region, compile-time size
+    L->off_a = off;
     off += L->Hs;  // A / B
     L->off_acc = off;
     L->acc_floats = round4(L->Hs + 4 + extra_slots);
     off += L->acc_floats;  // ACC / BACC (+ dummy row + private slots of split rows)
-    L->off_p = off;
-    off += L->Ps;
     L->off_g = off;
     off += L->Ps;
     L->off_al = off;
@@ -121,22 +129,35 @@ static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_
       arc_cells += (int64_t)steps * 64;
       for (int l = 0; l < 64; ++l) {
         const int r = sidx * 64 + l;
-        out->cells[off + l] = r < nrows ? ArcRec{bits((uint32_t)rows[r].slot), kRowMarker | (uint32_t)rows[r].state}
-                                        : ArcRec{bits((uint32_t)Hs), kRowMarker};
+        out->cells[off + l] = r < nrows ? ArcRec{bits((uint32_t)rows[r].slot), kRowFlag | ((uint32_t)rows[r].state << 18)}
+                                        : ArcRec{bits((uint32_t)Hs), kRowFlag};
         if (r >= nrows) continue;
         for (int k = 0; k < rows[r].len; ++k) {
           const int64_t a = order[rows[r].begin + k];
-          out->cells[off + (size_t)(k + 1) * 64 + l] = ArcRec{prob[a], (uint32_t)other[a] | ((uint32_t)pdf[a] << 16)};
+          out->cells[off + (size_t)(k + 1) * 64 + l] = ArcRec{prob[a], ((uint32_t)pdf[a] << 2) | ((uint32_t)other[a] << 18)};
         }
       }
     }
     // closing ROW(dummy) cell commits the last row; then pad to the unroll factor
-    for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{bits((uint32_t)Hs), kRowMarker});
+    for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{bits((uint32_t)Hs), kRowFlag});
     while ((out->cells.size() / 64 - first) % kStreamUnroll != 0)
       for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
   }
   for (int i = 0; i < 64 * (kStreamUnroll / 2); ++i) out->cells.push_back(ArcRec{0.f, 0u});
+  // ROW positions as one mask word per kStreamUnroll cells (+1 word so the prefetch needs no guard)
+  const size_t ncell = out->cells.size() / 64;
+  out->row_masks.assign(ncell / kStreamUnroll + 2, 0u);
+  for (size_t c = 0; c < ncell; ++c)
+    if (out->cells[c * 64].idx & kRowFlag) out->row_masks[c / kStreamUnroll] |= 1u << (c % kStreamUnroll);
+  // final memory layout: a lane's cells 2p and 2p+1 adjacent (16 bytes), i.e. [pair][lane][2], so the
+  // kernel streams with 16-byte loads (1 KB per wave instruction)
+  {
+    std::vector<ArcRec> paired(out->cells.size());
+    for (size_t c = 0; c < ncell; ++c)
+      for (int l = 0; l < 64; ++l) paired[((c >> 1) * 64 + l) * 2 + (c & 1)] = out->cells[c * 64 + l];
+    out->cells.swap(paired);
+  }
   out->real_arcs = A;
   out->padded_arcs = arc_cells;
   out->rows = nrows;
@@ -366,6 +387,8 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
       {g->fwd.fix.data(), g->fwd.fix.size() * sizeof(int2), 0},
       {g->bwd.fix_begin.data(), g->bwd.fix_begin.size() * 4, 0},
       {g->bwd.fix.data(), g->bwd.fix.size() * sizeof(int2), 0},
+      {g->fwd.row_masks.data(), g->fwd.row_masks.size() * 4, 0},
+      {g->bwd.row_masks.data(), g->bwd.row_masks.size() * 4, 0},
   };
   size_t total = 0;
   for (auto &p : parts) {
@@ -388,9 +411,11 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   DenGraphDev d;
   d.blob = blob;
   d.fwd = ScheduleDev{(const ArcRec *)(blob + parts[0].off), (const int2 *)(blob + parts[1].off),
-                      (const int32_t *)(blob + parts[5].off), (const int2 *)(blob + parts[6].off)};
+                      (const uint32_t *)(blob + parts[9].off), (const int32_t *)(blob + parts[5].off),
+                      (const int2 *)(blob + parts[6].off)};
   d.bwd = ScheduleDev{(const ArcRec *)(blob + parts[2].off), (const int2 *)(blob + parts[3].off),
-                      (const int32_t *)(blob + parts[7].off), (const int2 *)(blob + parts[8].off)};
+                      (const uint32_t *)(blob + parts[10].off), (const int32_t *)(blob + parts[7].off),
+                      (const int2 *)(blob + parts[8].off)};
   d.pi = (const float *)(blob + parts[4].off);
   g->dev[device] = d;
   return TC_OK;

@@ -18,6 +18,26 @@
 
 namespace tc {
 
+// In-kernel phase stamps (diagnostic build only: make EXTRA=-DTC_PHASE_STAMPS).  Thread 0 of every
+// wave of workgroup 0 accumulates shader cycles per phase; the totals go to a scratch area of the
+// workspace that nothing else reads.  Never quote the run time of such a build.
+#ifdef TC_PHASE_STAMPS
+#define TC_STAMP_DECL long long st_prev = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TC_STAMP(i)                      \
+  {                                      \
+    const long long st_now = clock64();  \
+    st_acc[i] += st_now - st_prev;       \
+    st_prev = st_now;                    \
+  }
+#define TC_STAMP_FLUSH(ptr)                                                         \
+  if (blockIdx.x == 0 && lane == 0 && wave < 2)                                     \
+    for (int i = 0; i < 8; ++i) (ptr)[wave * 8 + i] = st_acc[i];
+#else
+#define TC_STAMP_DECL
+#define TC_STAMP(i)
+#define TC_STAMP_FLUSH(ptr)
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -68,9 +88,9 @@ __device__ __forceinline__ void store_row4(float *row, int i, int n, int vec, fl
 }
 
 // One chunk of kChunk cells of a wave's stream.  All gathers of the chunk are issued before the first
-// use (ROW cells carry index 0, so their gathers are harmless broadcasts); only the commit of a
-// finished row sits behind a branch, and that branch is scalar because all 64 lanes hit their ROW
-// cells at the same stream position.
+// use (ROW cells carry valid offsets, so their gathers are harmless); only the commit of a finished
+// row sits behind a branch, and that branch is scalar: `mask` (bit u <=> cell u is a ROW cell) comes
+// from the schedule through scalar loads.
 //   FWD: acc(row) += alpha'(src) * w * p(pdf)
 //   BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
 constexpr int kChunk = kStreamUnroll / 2;
@@ -93,29 +113,38 @@ struct RowState {
   float acc, occf;
 };
 
+__device__ __forceinline__ float lds_at(const float *base, uint32_t byte_off) {
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 template <bool BWD, bool ALPHA_LDS>
-__device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState &rs, const float *__restrict__ SRC,
-                                              const float *__restrict__ PB, float *__restrict__ ACC,
-                                              float *__restrict__ GM, const float *__restrict__ AL,
-                                              const float *__restrict__ hist_t, int H, float inv_asum) {
+__device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t mask, RowState &rs,
+                                              const float *__restrict__ SRC, const float *__restrict__ PB,
+                                              float *__restrict__ ACC, float *__restrict__ GM,
+                                              const float *__restrict__ AL, const float *__restrict__ hist_t,
+                                              float inv_asum) {
   float a[kChunk], pp[kChunk];
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
-    a[u] = SRC[q[u].y & 0x3fffu];
-    pp[u] = PB[(q[u].y >> 16) & 0x3fffu];
+#ifdef TC_EXP_NOCONFLICT  // ablation: every lane gathers its own bank (results are wrong)
+    a[u] = lds_at(SRC, (threadIdx.x & 63) * 4 + u * 256);
+    pp[u] = lds_at(PB, (threadIdx.x & 63) * 4 + u * 256);
+#else
+    a[u] = lds_at(SRC, q[u].y >> 16);
+    pp[u] = lds_at(PB, q[u].y & 0xfffcu);
+#endif
   }
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
-    if ((int)__builtin_amdgcn_readfirstlane(q[u].y) < 0) {  // ROW cell (bit 31)
+    if (mask & (1u << u)) {  // ROW cell: scalar branch
       ACC[rs.row] = rs.acc;  // every row owns its slot: plain store, no atomic
       rs.acc = 0.f;
       rs.row = q[u].x;
       if (BWD) {
-        const uint32_t st = q[u].y & 0x3fffu;
         if (ALPHA_LDS)
-          rs.occf = AL[st] * inv_asum * kGammaScale;
+          rs.occf = lds_at(AL, q[u].y >> 16) * inv_asum * kGammaScale;
         else
-          rs.occf = hist_t[st] * inv_asum * kGammaScale;
+          rs.occf = hist_t[q[u].y >> 18] * inv_asum * kGammaScale;
       }
     } else {
       const float w = __uint_as_float(q[u].x);
@@ -125,7 +154,8 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState
         const float vf = w * a[u] * pp[u];
         rs.acc += vf;
         // gamma in fixed point: integer LDS atomics run at store rate, float ones are lane-serialised
-        atomicAdd(reinterpret_cast<uint32_t *>(GM) + ((q[u].y >> 16) & 0x3fffu), __float2uint_rn(vf * rs.occf));
+        atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + (q[u].y & 0xfffcu)),
+                  __float2uint_rn(vf * rs.occf));
       }
     }
   }
@@ -134,29 +164,52 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState
 // Consumes this wave's cell stream with two register buffers in ping-pong: while one chunk is being
 // processed the next one (4 KB per wave) is in flight from L2.
 template <bool BWD, bool ALPHA_LDS>
-__device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int lane, const float *__restrict__ SRC,
-                                          const float *__restrict__ PB, float *__restrict__ ACC,
-                                          float *__restrict__ GM, const float *__restrict__ AL,
-                                          const float *__restrict__ hist_t, int H, float inv_asum) {
+__device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int lane, int dummy_row,
+                                          const float *__restrict__ SRC, const float *__restrict__ PB,
+                                          float *__restrict__ ACC, float *__restrict__ GM,
+                                          const float *__restrict__ AL, const float *__restrict__ hist_t,
+                                          float inv_asum) {
   const int2 range = sc.wave_range[wave];
-  const int first = __builtin_amdgcn_readfirstlane(range.x);
+  const int first = __builtin_amdgcn_readfirstlane(range.x);   // multiple of kStreamUnroll
   const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnroll
-  const uint2 *__restrict__ r = reinterpret_cast<const uint2 *>(sc.cells) + (int64_t)first * 64 + lane;
+  // cells are stored [pair][lane][2]: one 16-byte load brings a lane's cells 2p and 2p+1
+  const uint4 *__restrict__ r = reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / 2) * 64 + lane;
+  const uint32_t *__restrict__ mk = sc.row_masks + first / kStreamUnroll;
   uint2 qa[kChunk], qb[kChunk];
 #pragma unroll
-  for (int u = 0; u < kChunk; ++u) qa[u] = r[u * 64];
+  for (int u = 0; u < kChunk / 2; ++u) {
+    const uint4 v = r[u * 64];
+    qa[2 * u] = make_uint2(v.x, v.y);
+    qa[2 * u + 1] = make_uint2(v.z, v.w);
+  }
+  uint32_t m = __builtin_amdgcn_readfirstlane(mk[0]);
   RowState rs;
-  rs.row = ((uint32_t)H + 3u) & ~3u;  // the dummy row, until the stream's first ROW cell
+  rs.row = (uint32_t)dummy_row;  // until the stream's first ROW cell
   rs.acc = 0.f;
   rs.occf = 0.f;
   for (int c = 0; c < ncells; c += kStreamUnroll) {
+    const uint32_t m_next = __builtin_amdgcn_readfirstlane(mk[c / kStreamUnroll + 1]);
+#ifdef TC_EXP_NOLOAD  // ablation: re-read the same two chunks every iteration (L1-resident; wrong results)
+    const int cc = 0;
+#else
+    const int cc = c;
+#endif
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) qb[u] = r[(c + kChunk + u) * 64];
-    process_chunk<BWD, ALPHA_LDS>(qa, rs, SRC, PB, ACC, GM, AL, hist_t, H, inv_asum);
+    for (int u = 0; u < kChunk / 2; ++u) {
+      const uint4 v = r[((cc + kChunk) / 2 + u) * 64];
+      qb[2 * u] = make_uint2(v.x, v.y);
+      qb[2 * u + 1] = make_uint2(v.z, v.w);
+    }
+    process_chunk<BWD, ALPHA_LDS>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
     // the stream is followed by kChunk readable padding cells, so this load needs no guard
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) qa[u] = r[(c + kStreamUnroll + u) * 64];
-    process_chunk<BWD, ALPHA_LDS>(qb, rs, SRC, PB, ACC, GM, AL, hist_t, H, inv_asum);
+    for (int u = 0; u < kChunk / 2; ++u) {
+      const uint4 v = r[((cc + kStreamUnroll) / 2 + u) * 64];
+      qa[2 * u] = make_uint2(v.x, v.y);
+      qa[2 * u + 1] = make_uint2(v.z, v.w);
+    }
+    process_chunk<BWD, ALPHA_LDS>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    m = m_next;
   }
 }
 
@@ -168,9 +221,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const int s = blockIdx.x;
   const int H = p.H, P = p.P, S = p.S, T = p.T;
   const int Hs = p.L.Hs, Ps = p.L.Ps;
-  float *const A0 = lds;                // alpha'_t (forward) / beta_{t+1} (backward): gather source
+  float *const PB = lds;                          // exp(y_t), at LDS offset 0
+  float *const A0 = lds + PV * 4 * kThreads;      // alpha'_t (forward) / beta_{t+1} (backward): gather source
   float *const ACC = lds + p.L.off_acc; // row accumulators: one per state, dummy at Hs, then split-row slots
-  float *const PB = lds + p.L.off_p;    // exp(y_t)
   float *const GM = lds + p.L.off_g;    // gamma_t as u32 fixed point (backward only)
   float *const AL = lds + p.L.off_al;   // alpha'_t (backward only, when it fits)
   float *const red = lds + p.L.off_red;
@@ -223,8 +276,11 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   float asum_prev = asum;
 
   // ---- forward frames t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
+  TC_STAMP_DECL
   for (int t = 1; t <= T; ++t) {
+    TC_STAMP(0)
     __syncthreads();  // A0, PB, ACC ready
+    TC_STAMP(1)
     float4 yreg[PV];
     {
       // prefetch y_t under the arc walk (the last iteration re-reads row T-1: keeps yreg in registers)
@@ -232,8 +288,10 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
-    walk_rows<false, true>(p.fwd, wave, lane, A0, PB, ACC, nullptr, nullptr, nullptr, H, 0.f);
+    walk_rows<false, true>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
+    TC_STAMP(2)
     __syncthreads();  // all row sums committed
+    TC_STAMP(3)
     fold_split_rows(p.fwd, ffx0, ffx1, ACC);
     float4 v4[JV];
     part = 0.f;
@@ -248,6 +306,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     asum = block_sum(part, red, wave, lane);
+    TC_STAMP(4)
     float *hist_t = hist + (int64_t)t * hist_step;
     float part_tot = 0.f;
 #pragma unroll
@@ -281,6 +340,8 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     inv_prev = 1.0f / asum;
     if (t == T) part = part_tot;
   }
+  TC_STAMP(0)
+  TC_STAMP_FLUSH(p.stamps)
   // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h)
   const float tot = block_sum(part, red + kWaves, wave, lane);
   {
@@ -349,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         }
       }
     }
-    walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, A0, PB, ACC, GM, AL, hist_t, H, inv_as);
+    walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, Hs, A0, PB, ACC, GM, AL, hist_t, inv_as);
     __syncthreads();  // beta' sums and gamma committed
     fold_split_rows(p.bwd, bfx0, bfx1, ACC);
     float4 b4[JV];
