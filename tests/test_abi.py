@@ -1,0 +1,144 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/torchain_hip.h declares,
+and its host-only entry points (handles, accessors, validation, den.fst reader) behave.  No compute
+calls here (those need a GPU: tests/test_gpu_parity.py)."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from torchain_amd import io, synth
+from torchain_amd._lib import LIB_PATH, TorchainHipError, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "torchain_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = declared_symbols()
+    assert len(syms) >= 20, syms
+    raw = C.CDLL(LIB_PATH)
+    missing = [s for s in syms if not hasattr(raw, s)]
+    assert not missing, missing
+
+
+def test_header_cites_the_reference_interface():
+    text = open(HEADER).read()
+    for ref in ("src/my_lib.h:33-42", "src/my_lib.h:29", "src/my_lib.h:21", "src/my_lib.h:23-25",
+                "src/my_lib_chain.cpp:104-136"):
+        assert ref in text, ref
+
+
+def test_version_and_strerror():
+    assert lib.tc_version() >= 100
+    assert lib.tc_strerror(0) == b"ok"
+    assert b"FST" in lib.tc_strerror(-2)
+
+
+def test_den_graph_handle_and_initial_probs(oracle):
+    fst = synth.random_den_fst(50, 4, 30, seed=1)
+    g = io.DenominatorGraph(fst, fst.num_pdfs)
+    assert (g.num_states, g.num_arcs, g.n_pdf) == (50, 200, 30)
+    ref = oracle.DenGraph(fst).initial_probs()
+    np.testing.assert_allclose(g.initial_probs(), ref, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(g.initial_probs(), synth.initial_probs_f64(fst), rtol=1e-5, atol=1e-9)
+    st = g.stats()
+    assert st["fwd_rows"] == 50 and st["bwd_rows"] == 50 and st["threads"] == 1024 and st["lds_bytes"] > 0
+
+
+def test_den_graph_schedule_covers_every_arc_once():
+    """Row splitting on a skewed graph: padded slots >= arcs, more rows than states."""
+    fst = synth.skewed_den_fst(300, 6000, 120, seed=4)
+    st = io.DenominatorGraph(fst, fst.num_pdfs).stats()
+    assert st["fwd_slots"] >= 6000 and st["bwd_slots"] >= 6000
+    assert st["fwd_rows"] > 300 or st["bwd_rows"] > 300
+
+
+def test_den_graph_rejects_bad_fst():
+    fst = synth.random_den_fst(10, 2, 5, seed=1)
+    bad = fst._replace(ilabel=fst.ilabel + 100)  # pdf out of range ([K] KALDI_ASSERT)
+    with pytest.raises(TorchainHipError) as e:
+        io.DenominatorGraph(bad, 5)
+    assert e.value.code == -2
+    bad = fst._replace(src=fst.src[::-1].copy())  # not state-major
+    with pytest.raises(TorchainHipError):
+        io.DenominatorGraph(bad, 5)
+    bad = fst._replace(dst=(fst.dst + 100).astype(np.int32))
+    with pytest.raises(TorchainHipError):
+        io.DenominatorGraph(bad, 5)
+
+
+def write_openfst_vector(path, fst, with_symbols=False):
+    """Writes an OpenFst binary VectorFst<StdArc> (what fst::ReadFstKaldi reads for a plain file)."""
+    def s(b):
+        return struct.pack("<i", len(b)) + b
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", 2125659606) + s(b"vector") + s(b"standard"))
+        f.write(struct.pack("<iiQqqq", 2, 0, 0, int(fst.start), fst.num_states, len(fst.src)))
+        first = np.searchsorted(fst.src, np.arange(fst.num_states + 1))
+        for st in range(fst.num_states):
+            f.write(struct.pack("<fq", float(fst.final[st]), int(first[st + 1] - first[st])))
+            for a in range(first[st], first[st + 1]):
+                f.write(struct.pack("<iifi", int(fst.ilabel[a]), int(fst.ilabel[a]), float(fst.weight[a]),
+                                    int(fst.dst[a])))
+
+
+def test_den_fst_file_reader(tmp_path):
+    """io.DenominatorGraph(path, n_pdf) as in the reference (io.py:51-54 -> my_lib_example.cpp:129-134)."""
+    fst = synth.skewed_den_fst(40, 300, 25, seed=2)
+    path = str(tmp_path / "den.fst")
+    write_openfst_vector(path, fst)
+    g_file = io.DenominatorGraph(path, fst.num_pdfs)
+    g_mem = io.DenominatorGraph(fst, fst.num_pdfs)
+    assert g_file.num_states == 40 and g_file.num_arcs == 300
+    np.testing.assert_array_equal(g_file.initial_probs(), g_mem.initial_probs())
+    with pytest.raises(TorchainHipError) as e:
+        io.DenominatorGraph(str(tmp_path / "missing.fst"), 25)
+    assert e.value.code == -6
+    open(str(tmp_path / "junk.fst"), "wb").write(b"not an fst at all")
+    with pytest.raises(TorchainHipError):
+        io.DenominatorGraph(str(tmp_path / "junk.fst"), 25)
+
+
+def test_supervision_handle_accessors():
+    fst = synth.random_den_fst(30, 3, 20, seed=3)
+    sup = synth.random_supervision(fst, 4, 9, 3, seed=1, weight=0.5)
+    h = io.Supervision.from_synth(sup)
+    assert (h.n_pdf, h.n_batch, h.n_frame) == (20, 4, 9)
+    assert h.shape == (4, 9, 20) and h.weight == 0.5
+    with pytest.raises(ValueError):
+        io.Supervision(C.c_void_p())  # null handle, reference io.py:23-24
+
+
+def test_supervision_rejects_malformed_fst():
+    fst = synth.random_den_fst(30, 3, 20, seed=3)
+    sup = synth.random_supervision(fst, 3, 6, 2, seed=2)
+    with pytest.raises(TorchainHipError) as e:  # wrong number of frames
+        io.Supervision.from_fst(1.0, 3, 7, 20, sup.arc_begin, sup.ilabel, sup.arc_weight, sup.nextstate, sup.final)
+    assert e.value.code == -2
+    il = sup.ilabel.copy()
+    il[0] = 0  # epsilon
+    with pytest.raises(TorchainHipError):
+        io.Supervision.from_fst(1.0, 3, 6, 20, sup.arc_begin, il, sup.arc_weight, sup.nextstate, sup.final)
+
+
+def test_supervision_not_separable_is_reported():
+    """A merged FST whose boundary states do not carry proportional copies of the next sequence's
+    start arcs does not factor per sequence."""
+    # two sequences of one frame each; the two boundary states have different out-arc labels
+    arc_begin = np.array([0, 2, 3, 4, 4], np.int32)
+    ilabel = np.array([1, 2, 1, 2], np.int32)
+    nxt = np.array([1, 2, 3, 3], np.int32)
+    w = np.zeros(4, np.float32)
+    final = np.array([np.inf, np.inf, np.inf, 0.0], np.float32)
+    with pytest.raises(TorchainHipError) as e:
+        io.Supervision.from_fst(1.0, 2, 1, 3, arc_begin, ilabel, w, nxt, final)
+    assert e.value.code == -7
