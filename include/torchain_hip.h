@@ -136,8 +136,10 @@ int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_outpu
 
 /* Diagnostics for bench.py / DESIGN.md: copies a few schedule statistics of the graph
  * (out[0]=padded forward arc slots, out[1]=padded backward arc slots, out[2]=LDS bytes of the fused
- * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows). */
-int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out6);
+ * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows,
+ * out[6], out[7] = forward / backward LDS bank-conflict factor of the placed arc gathers x 1000, where
+ * 1000 means conflict-free). */
+int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out8);
 
 #ifdef __cplusplus
 }

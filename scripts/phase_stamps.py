@@ -39,3 +39,8 @@ for with_deriv in (False, True):
     for i in range(5):
         print("   %-20s %9.0f %9.0f" % (names[i], st[0, i] / T, st[1, i] / T))
     print("   total per frame      %9.0f" % (st[0, :5].sum() / T))
+    if with_deriv:
+        print("  backward loop:")
+        for i in range(5):
+            print("   %-20s %9.0f %9.0f" % (names[i], st[2, i] / T, st[3, i] / T))
+        print("   total per frame      %9.0f" % (st[2, :5].sum() / T))

@@ -61,6 +61,7 @@ struct ScheduleHost {
   std::vector<int32_t> fix_begin;  // kThreads + 1: range of fix-up entries owned by each thread
   std::vector<int2> fix;           // {state, extra slot}
   int32_t extra_slots = 0;         // accumulator slots beyond Hs + 4
+  int64_t conflict_cost = 0, conflict_free_cost = 0;  // LDS cycles of the arc gathers: as placed / if conflict-free
   int64_t real_arcs = 0, padded_arcs = 0;
   int32_t rows = 0;
 };

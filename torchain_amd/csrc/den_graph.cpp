@@ -2,6 +2,7 @@
 // kaldi::chain::DenominatorGraph at src/my_lib_example.cpp:129-134), the wavefront schedules the HIP
 // kernels stream, the OpenFst binary reader, and the per-device immutable copies.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,10 +59,190 @@ int64_t layout_lds_bytes(const DenLayout &L, int T) {
   return 4 * (int64_t)(L.off_asum + round4(T + 1));
 }
 
+// Bank-conflict-aware placement for one 32-lane half of a slot.  ds_read_b32 / ds_add_u32 service a
+// wave in two 32-lane groups, one LDS cycle per distinct address per bank (bank = dword index mod 32;
+// profiles/microbench: 2.3 cycles conflict-free, 7.0 for uniformly random gathers).  The sum over a
+// row is order-independent and padding may sit anywhere, so for every step we pick, per lane, the arc
+// of its row whose state-bank and pdf-bank are still free in that step; a few swap passes then remove
+// what the greedy pass left.  pos[l][k] = index into lane l's arc list, or -1 for padding.
+// Returns the cost sum_k (max state-bank multiplicity + max pdf-bank multiplicity).
+static int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
+                        const int32_t *pdf, std::vector<std::vector<int>> *pos_out) {
+  const int L = (int)lane_arcs.size();
+  auto bst = [&](int64_t a) { return other[a] & 31; };
+  auto bpd = [&](int64_t a) { return pdf[a] & 31; };
+  std::vector<std::vector<int>> pos(L, std::vector<int>(steps, -1));
+  std::vector<std::vector<char>> used(L);
+  std::vector<int> remaining(L);
+  for (int l = 0; l < L; ++l) {
+    used[l].assign(lane_arcs[l].size(), 0);
+    remaining[l] = (int)lane_arcs[l].size();
+  }
+  std::vector<std::array<int, 32>> cs(steps), cp(steps);
+  for (int k = 0; k < steps; ++k) {
+    cs[k].fill(0);
+    cp[k].fill(0);
+    std::vector<int> lanes(L);
+    for (int l = 0; l < L; ++l) lanes[l] = l;
+    // rows that can no longer defer go first, then the fuller rows
+    std::stable_sort(lanes.begin(), lanes.end(), [&](int x, int y) { return remaining[x] > remaining[y]; });
+    for (int l : lanes) {
+      if (remaining[l] == 0) continue;
+      const int slack = (steps - k) - remaining[l];
+      int best = -1, best_cost = 1 << 30;
+      for (int i = 0; i < (int)lane_arcs[l].size(); ++i) {
+        if (used[l][i]) continue;
+        const int64_t a = lane_arcs[l][i];
+        const int c = cs[k][bst(a)] + cp[k][bpd(a)];
+        if (c < best_cost) {
+          best_cost = c;
+          best = i;
+        }
+      }
+      if (slack > 0 && best_cost > 0) continue;  // pad here, try again at a later step
+      used[l][best] = 1;
+      remaining[l]--;
+      pos[l][k] = best;
+      cs[k][bst(lane_arcs[l][best])]++;
+      cp[k][bpd(lane_arcs[l][best])]++;
+    }
+  }
+  // improvement: swap two entries of one lane between steps when it removes conflicting pairs
+  // (smooth objective: number of same-bank pairs per step, for both gathers)
+  for (int pass = 0; pass < 8; ++pass) {
+    bool any = false;
+    for (int l = 0; l < L; ++l)
+      for (int k1 = 0; k1 < steps; ++k1)
+        for (int k2 = k1 + 1; k2 < steps; ++k2) {
+          const int i1 = pos[l][k1], i2 = pos[l][k2];
+          if (i1 == i2) continue;
+          // pairs removed/added: moving arc a from step x to step y changes the pair count by
+          // (count_y(b) - (count_x(b) - 1)) per attribute
+          int delta = 0;
+          auto delta_move = [&](int idx, int from, int to, int other_idx) {
+            if (idx < 0) return;
+            const int64_t a = lane_arcs[l][idx];
+            int s_to = cs[to][bst(a)], p_to = cp[to][bpd(a)];
+            if (other_idx >= 0) {  // the arc leaving `to` in the same swap
+              const int64_t o = lane_arcs[l][other_idx];
+              if (bst(o) == bst(a)) s_to--;
+              if (bpd(o) == bpd(a)) p_to--;
+            }
+            delta += s_to - (cs[from][bst(a)] - 1);
+            delta += p_to - (cp[from][bpd(a)] - 1);
+          };
+          delta_move(i1, k1, k2, i2);
+          delta_move(i2, k2, k1, i1);
+          if (delta < 0) {
+            auto apply = [&](int idx, int from, int to) {
+              if (idx < 0) return;
+              const int64_t a = lane_arcs[l][idx];
+              cs[from][bst(a)]--;
+              cp[from][bpd(a)]--;
+              cs[to][bst(a)]++;
+              cp[to][bpd(a)]++;
+            };
+            apply(i1, k1, k2);
+            apply(i2, k2, k1);
+            std::swap(pos[l][k1], pos[l][k2]);
+            any = true;
+          }
+        }
+    if (!any) break;
+  }
+  int total = 0;
+  for (int k = 0; k < steps; ++k) {
+    int ms = 0, mp = 0;
+    for (int b = 0; b < 32; ++b) {
+      ms = std::max(ms, cs[k][b]);
+      mp = std::max(mp, cp[k][b]);
+    }
+    total += std::max(ms, 1) + std::max(mp, 1);
+    if (getenv("TC_SCHED_DEBUG")) {
+      static long long n = 0, sst = 0, spd = 0;
+      n++; sst += std::max(ms, 1); spd += std::max(mp, 1);
+      if (n % 2000 == 0) fprintf(stderr, "[sched] steps=%lld avg max-mult state=%.3f pdf=%.3f\n", n, (double)sst / n, (double)spd / n);
+    }
+  }
+  *pos_out = pos;
+  return total;
+}
+
+// Regroups rows of equal length so that consecutive blocks of 32 rows (one half-wave of a slot) have
+// distinct "dominant" pdf banks -- in chain graphs most arcs of a row carry one pdf, so this alone
+// makes the exp(y) gathers and the gamma atomics of a half-wave conflict-free -- and, among the
+// candidates of a bank bucket, a balanced spread of state banks, so that arrange_half can find
+// conflict-free steps.  Works on [begin, end) of the row order, all of one length.
+template <class Row>
+static void group_rows_by_bank(std::vector<Row> &rows, size_t begin, size_t end, const std::vector<int64_t> &order,
+                               const int32_t *other, const int32_t *pdf) {
+  const size_t n = end - begin;
+  if (n < 64) return;
+  std::vector<std::vector<size_t>> bucket(32);
+  std::vector<std::array<uint8_t, 32>> st_hist(n);
+  for (size_t i = 0; i < n; ++i) {
+    const Row &r = rows[begin + i];
+    int cnt[32] = {0};
+    st_hist[i].fill(0);
+    for (int k = 0; k < r.len; ++k) {
+      const int64_t a = order[r.begin + k];
+      cnt[pdf[a] & 31]++;
+      st_hist[i][other[a] & 31]++;
+    }
+    int best = 0;
+    for (int b = 1; b < 32; ++b)
+      if (cnt[b] > cnt[best]) best = b;
+    bucket[best].push_back(i);
+  }
+  std::vector<Row> out;
+  out.reserve(n);
+  std::vector<char> taken(n, 0);
+  size_t left = n;
+  while (left > 0) {
+    int hist[32] = {0};
+    int got = 0;
+    // one row per non-empty bucket, fullest buckets first so that they drain evenly
+    std::vector<int> border(32);
+    for (int b = 0; b < 32; ++b) border[b] = b;
+    std::stable_sort(border.begin(), border.end(), [&](int x, int y) { return bucket[x].size() > bucket[y].size(); });
+    for (int round = 0; round < 4 && got < 32; ++round)
+      for (int b : border) {
+        if (got >= 32) break;
+        auto &bk = bucket[b];
+        if (bk.empty()) continue;
+        if (round == 0 || bk.size() > left / 32) {  // later rounds only take from over-full buckets
+          // among the last few candidates pick the one that adds least to the crowded state banks
+          size_t best_j = bk.size() - 1;
+          int best_cost = 1 << 30;
+          for (size_t j = bk.size(); j-- > 0 && bk.size() - j <= 8;) {
+            int c = 0;
+            for (int q = 0; q < 32; ++q) c += st_hist[bk[j]][q] * hist[q];
+            if (c < best_cost) {
+              best_cost = c;
+              best_j = j;
+            }
+          }
+          const size_t i = bk[best_j];
+          bk.erase(bk.begin() + best_j);
+          for (int q = 0; q < 32; ++q) hist[q] += st_hist[i][q];
+          out.push_back(rows[begin + i]);
+          taken[i] = 1;
+          ++got;
+          --left;
+        }
+      }
+    if (got == 0) break;
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (!taken[i]) out.push_back(rows[begin + i]);
+  for (size_t i = 0; i < n; ++i) rows[begin + i] = out[i];
+}
+
 // Builds the row/slot schedule for one direction.  key[a] is the state whose sum arc a belongs to
 // (destination for the forward pass, source for the backward pass), other[a] the state it gathers.
-static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_t *other, const int32_t *pdf,
-                      const float *prob, ScheduleHost *out) {
+static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key, const int32_t *other,
+                      const int32_t *pdf, const float *prob, ScheduleHost *out) {
+  out->conflict_cost = out->conflict_free_cost = 0;
   struct Row {
     int32_t state, len, slot;
     int64_t begin;
@@ -101,6 +282,12 @@ static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_
   out->fix_begin[kThreads] = (int)out->fix.size();
   if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
   std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.len > y.len; });
+  for (size_t b = 0; b < rows.size();) {
+    size_t e = b;
+    while (e < rows.size() && rows[e].len == rows[b].len) ++e;
+    group_rows_by_bank(rows, b, e, order, other, pdf);
+    b = e;
+  }
   const int nrows = (int)rows.size();
   const int nslots = (nrows + 63) / 64;
 
@@ -127,19 +314,39 @@ static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_
       const size_t off = out->cells.size();
       out->cells.resize(off + (size_t)(steps + 1) * 64, ArcRec{0.f, 0u});
       arc_cells += (int64_t)steps * 64;
-      for (int l = 0; l < 64; ++l) {
-        const int r = sidx * 64 + l;
-        out->cells[off + l] = r < nrows ? ArcRec{bits((uint32_t)rows[r].slot), kRowFlag | ((uint32_t)rows[r].state << 18)}
-                                        : ArcRec{bits((uint32_t)Hs), kRowFlag};
-        if (r >= nrows) continue;
-        for (int k = 0; k < rows[r].len; ++k) {
-          const int64_t a = order[rows[r].begin + k];
-          out->cells[off + (size_t)(k + 1) * 64 + l] = ArcRec{prob[a], ((uint32_t)pdf[a] << 2) | ((uint32_t)other[a] << 18)};
+      for (int half = 0; half < 2; ++half) {
+        std::vector<std::vector<int64_t>> lane_arcs(32);
+        for (int l = 0; l < 32; ++l) {
+          const int r = sidx * 64 + half * 32 + l;
+          if (r < nrows)
+            for (int k = 0; k < rows[r].len; ++k) lane_arcs[l].push_back(order[rows[r].begin + k]);
+        }
+        std::vector<std::vector<int>> pos;
+        out->conflict_cost += arrange_half(lane_arcs, steps, other, pdf, &pos);
+        out->conflict_free_cost += 2 * steps;
+        for (int l = 0; l < 32; ++l) {
+          const int lane = half * 32 + l;
+          const int r = sidx * 64 + lane;
+          // ROW cell: {slot | state << 16, flag}; its (unused) gather offsets are lane-aligned, i.e. conflict-free
+          const uint32_t free_st = (uint32_t)(H >= 32 ? l : 0), free_pdf = (uint32_t)(num_pdfs >= 32 ? l : 0);
+          const uint32_t dummy_idx = (free_pdf << 2) | (free_st << 18);
+          out->cells[off + lane] =
+              r < nrows ? ArcRec{bits((uint32_t)rows[r].slot | ((uint32_t)rows[r].state << 16)), kRowFlag | dummy_idx}
+                        : ArcRec{bits((uint32_t)Hs), kRowFlag | dummy_idx};
+          for (int k = 0; k < steps; ++k) {
+            ArcRec &cell = out->cells[off + (size_t)(k + 1) * 64 + lane];
+            if (pos[l][k] >= 0) {
+              const int64_t a = lane_arcs[l][pos[l][k]];
+              cell = ArcRec{prob[a], ((uint32_t)pdf[a] << 2) | ((uint32_t)other[a] << 18)};
+            } else {
+              cell = ArcRec{0.f, dummy_idx};  // padding: w = 0, lane-aligned offsets
+            }
+          }
         }
       }
     }
     // closing ROW(dummy) cell commits the last row; then pad to the unroll factor
-    for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{bits((uint32_t)Hs), kRowFlag});
+    for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{bits((uint32_t)Hs), kRowFlag});  // offsets 0: broadcast
     while ((out->cells.size() / 64 - first) % kStreamUnroll != 0)
       for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
@@ -166,9 +373,9 @@ static void build_one(int H, int Hs, int64_t A, const int32_t *key, const int32_
 int build_schedules(tc_den_graph *g) {
   const int Hs = round4(g->H);
   // forward: alpha_{t+1}(dst) sums over in-arcs, gathers alpha'_t(src)
-  build_one(g->H, Hs, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->fwd);
+  build_one(g->H, Hs, g->P, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->fwd);
   // backward: beta'_t(src) sums over out-arcs, gathers beta_{t+1}(dst)
-  build_one(g->H, Hs, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->bwd);
+  build_one(g->H, Hs, g->P, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->bwd);
   g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &g->layout);
   return TC_OK;
 }
@@ -362,6 +569,8 @@ int tc_den_graph_stats(const tc_den_graph *g, int64_t *o) {
   o[3] = kThreads;
   o[4] = g->fwd.rows;
   o[5] = g->bwd.rows;
+  o[6] = g->fwd.conflict_free_cost ? 1000 * g->fwd.conflict_cost / g->fwd.conflict_free_cost : 0;
+  o[7] = g->bwd.conflict_free_cost ? 1000 * g->bwd.conflict_cost / g->bwd.conflict_free_cost : 0;
   return TC_OK;
 }
 

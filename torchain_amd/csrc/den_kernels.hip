@@ -139,12 +139,12 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
     if (mask & (1u << u)) {  // ROW cell: scalar branch
       ACC[rs.row] = rs.acc;  // every row owns its slot: plain store, no atomic
       rs.acc = 0.f;
-      rs.row = q[u].x;
+      rs.row = q[u].x & 0xffffu;  // ROW cell x = slot | state << 16
       if (BWD) {
         if (ALPHA_LDS)
-          rs.occf = lds_at(AL, q[u].y >> 16) * inv_asum * kGammaScale;
+          rs.occf = lds_at(AL, (q[u].x >> 14) & 0x3fffcu) * inv_asum * kGammaScale;
         else
-          rs.occf = hist_t[q[u].y >> 18] * inv_asum * kGammaScale;
+          rs.occf = hist_t[q[u].x >> 16] * inv_asum * kGammaScale;
       }
     } else {
       const float w = __uint_as_float(q[u].x);
@@ -390,8 +390,14 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
   }
+  TC_STAMP(0)
+#ifdef TC_PHASE_STAMPS
+  for (int i = 0; i < 8; ++i) st_acc[i] = 0;
+#endif
   for (int t = T - 1; t >= 0; --t) {
+    TC_STAMP(0)
     __syncthreads();  // B, PB, AL ready; BACC and GAMMA zero
+    TC_STAMP(1)
     const float asum_t = asum_h[t];
     const float inv_as = 1.0f / asum_t;
     const float *hist_t = hist + (int64_t)t * hist_step;
@@ -411,7 +417,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, Hs, A0, PB, ACC, GM, AL, hist_t, inv_as);
+    TC_STAMP(2)
     __syncthreads();  // beta' sums and gamma committed
+    TC_STAMP(3)
     fold_split_rows(p.bwd, bfx0, bfx1, ACC);
     float4 b4[JV];
     part = 0.f;
@@ -455,6 +463,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     bsum = block_sum(part, red, wave, lane);
+    TC_STAMP(4)
     if (t == 0) {
       // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
       const float ab = block_sum(part_ab, red + kWaves, wave, lane);
@@ -463,6 +472,10 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         p.seq_ab[s] = ab;
         p.seq_gsum[s] = gs;
       }
+#ifdef TC_PHASE_STAMPS
+      if (blockIdx.x == 0 && lane == 0 && wave < 2)
+        for (int i = 0; i < 8; ++i) p.stamps[16 + wave * 8 + i] = st_acc[i];
+#endif
       break;
     }
 #pragma unroll
