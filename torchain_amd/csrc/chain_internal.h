@@ -18,6 +18,10 @@ namespace tc {
 // the frame recursion is serial, so everything a sequence needs per frame lives in that CU's LDS.
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
+// the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
+constexpr int kJvSmall = 2048 / kThreads, kPvSmall = 1024 / kThreads, kJvLarge = 4096 / kThreads, kPvLarge = 3072 / kThreads;
+// the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
+// the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 constexpr int kMaxRowLen = 32;             // longer in/out-arc lists are split into virtual rows
 constexpr int kLdsLimitBytes = 160 * 1024; // gfx950 LDS per CU / per workgroup
 

@@ -24,12 +24,12 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L) {
   const int jv = (L->Hs / 4 + kThreads - 1) / kThreads, pv = (L->Ps / 4 + kThreads - 1) / kThreads;
   if (H > kMaxIndex || P > kMaxIndex) return false;  // 16-bit byte offsets in ArcRec
   // the two kernel instantiations (den_kernels.hip): <JV=2, PV=1> and <JV=4, PV=3>
-  if (jv <= 2 && pv <= 1) {
-    L->JV = 2;
-    L->PV = 1;
-  } else if (jv <= 4 && pv <= 3) {
-    L->JV = 4;
-    L->PV = 3;
+  if (jv <= kJvSmall && pv <= kPvSmall) {
+    L->JV = kJvSmall;
+    L->PV = kPvSmall;
+  } else if (jv <= kJvLarge && pv <= kPvLarge) {
+    L->JV = kJvLarge;
+    L->PV = kPvLarge;
   } else {
     return false;
   }

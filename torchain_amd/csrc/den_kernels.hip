@@ -136,7 +136,8 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
   }
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
-    if (mask & (1u << u)) {  // ROW cell: scalar branch
+    float w = __uint_as_float(q[u].x);
+    if (__builtin_expect((mask >> u) & 1u, 0)) {  // ROW cell: rare, scalar branch around this block only
       ACC[rs.row] = rs.acc;  // every row owns its slot: plain store, no atomic
       rs.acc = 0.f;
       rs.row = q[u].x & 0xffffu;  // ROW cell x = slot | state << 16
@@ -146,17 +147,17 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
         else
           rs.occf = hist_t[q[u].x >> 16] * inv_asum * kGammaScale;
       }
+      w = 0.f;  // the arc math below then adds nothing for this cell
+    }
+    if (!BWD) {
+      rs.acc = fmaf(a[u] * w, pp[u], rs.acc);
     } else {
-      const float w = __uint_as_float(q[u].x);
-      if (!BWD) {
-        rs.acc = fmaf(a[u] * w, pp[u], rs.acc);
-      } else {
-        const float vf = w * a[u] * pp[u];
-        rs.acc += vf;
-        // gamma in fixed point: integer LDS atomics run at store rate, float ones are lane-serialised
-        atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + (q[u].y & 0xfffcu)),
-                  __float2uint_rn(vf * rs.occf));
-      }
+      const float vf = w * a[u] * pp[u];
+      rs.acc += vf;
+      // gamma in fixed point: integer LDS atomics run at store rate, float ones are lane-serialised
+      // (a ROW cell adds 0 at its lane-aligned dummy offset)
+      atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + (q[u].y & 0xfffcu)),
+                __float2uint_rn(vf * rs.occf));
     }
   }
 }
@@ -187,8 +188,25 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
   rs.row = (uint32_t)dummy_row;  // until the stream's first ROW cell
   rs.acc = 0.f;
   rs.occf = 0.f;
+#ifdef TC_EXP_HALFLOAD  // ablation: every loaded chunk is processed twice, half the loads (wrong results)
+  for (int c = 0; c < ncells; c += 2 * kStreamUnroll) {
+#else
   for (int c = 0; c < ncells; c += kStreamUnroll) {
+#endif
     const uint32_t m_next = __builtin_amdgcn_readfirstlane(mk[c / kStreamUnroll + 1]);
+#ifndef TC_EXP_NOPRIO
+    // Self-balancing: a wave's issue priority falls as it advances through its stream, so the waves
+    // that lag (the arbiter otherwise favours the oldest) outrank the leaders and all 16 reach the
+    // barrier together instead of leaving a tail with few active waves.
+    if (4 * c < ncells)
+      __builtin_amdgcn_s_setprio(3);
+    else if (2 * c < ncells)
+      __builtin_amdgcn_s_setprio(2);
+    else if (4 * c < 3 * ncells)
+      __builtin_amdgcn_s_setprio(1);
+    else
+      __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef TC_EXP_NOLOAD  // ablation: re-read the same two chunks every iteration (L1-resident; wrong results)
     const int cc = 0;
 #else
@@ -201,6 +219,9 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
       qb[2 * u + 1] = make_uint2(v.z, v.w);
     }
     process_chunk<BWD, ALPHA_LDS>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+#ifdef TC_EXP_HALFLOAD
+    process_chunk<BWD, ALPHA_LDS>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+#endif
     // the stream is followed by kChunk readable padding cells, so this load needs no guard
 #pragma unroll
     for (int u = 0; u < kChunk / 2; ++u) {
@@ -209,8 +230,14 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
       qa[2 * u + 1] = make_uint2(v.z, v.w);
     }
     process_chunk<BWD, ALPHA_LDS>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+#ifdef TC_EXP_HALFLOAD
+    process_chunk<BWD, ALPHA_LDS>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+#endif
     m = m_next;
   }
+#ifndef TC_EXP_NOPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV>
@@ -535,8 +562,8 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
 #define TC_DISPATCH(J, V)                                                      \
   if (JV <= J && PV <= V)                                                      \
     return (accumulate && p.deriv) ? launch_jp_accum<J, V>(p, lds, stream) : launch_jp<J, V>(p, lds, stream);
-  TC_DISPATCH(2, 1)
-  TC_DISPATCH(4, 3)
+  TC_DISPATCH(kJvSmall, kPvSmall)
+  TC_DISPATCH(kJvLarge, kPvLarge)
 #undef TC_DISPATCH
   return TC_ERR_UNSUPPORTED;
 }
