@@ -138,8 +138,9 @@ int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_outpu
  * (out[0]=padded forward arc slots, out[1]=padded backward arc slots, out[2]=LDS bytes of the fused
  * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows,
  * out[6], out[7] = forward / backward LDS bank-conflict factor of the placed arc gathers x 1000, where
- * 1000 means conflict-free). */
-int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out8);
+ * 1000 means conflict-free; out[8] = 1 when the graph is "tied" -- all non-self-loop arcs entering a
+ * state carry one pdf -- and runs the factorised kernel). */
+int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ fst = synth.config_den_fst(cfgname)
 H = fst.num_states
 dev = torch.device("cuda", 0)
 graph = io.DenominatorGraph(fst, P).prepare(dev)
+print(graph.stats())
 y = torch.randn(S * T, P, device=dev)
 deriv = torch.empty_like(y)
 nbytes = lib.tc_chain_workspace_bytes(graph.ptr, S, T)
@@ -25,22 +26,17 @@ stream = torch.cuda.current_stream()
 a256 = lambda x: (x + 255) & ~255
 Hs = (H + 3) & ~3
 off = a256((T + 1) * S * Hs * 4) + 3 * a256(S * 8) + 2 * a256(S * 4) + 256
-for with_deriv in (False, True):
-    for _ in range(2):
-        rc = lib.tc_den_forward_backward(
-            graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), cfg["leaky"], -1.0, 0.0, 0,
-            C.c_void_p(deriv.data_ptr()) if with_deriv else None, deriv.stride(0), None, None,
-            C.c_void_p(ws.data_ptr()), nbytes, 0, C.c_void_p(stream.cuda_stream))
-        check(rc, "den")
-    torch.cuda.synchronize()
-    st = ws[off:off + 256].cpu().numpy().view(np.int64).reshape(4, 8)
-    print("with_deriv=%s  (cycles per frame, wave 0 / wave 1)" % with_deriv)
-    names = ["tail(pass2,PB)", "barrier1", "walk", "barrier2", "fold+pass1+reduce", "-", "-", "-"]
+names = ["tail", "barrier1", "walk", "barrier2", "pass1+reduce"]
+for _ in range(2):
+    rc = lib.tc_den_forward_backward(
+        graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), cfg["leaky"], -1.0, 0.0, 0,
+        C.c_void_p(deriv.data_ptr()), deriv.stride(0), None, None,
+        C.c_void_p(ws.data_ptr()), nbytes, 0, C.c_void_p(stream.cuda_stream))
+    check(rc, "den")
+torch.cuda.synchronize()
+st = ws[off:off + 2048].cpu().numpy().view(np.int64).reshape(2, 16, 8) / T
+for ph, name in enumerate(("forward", "backward")):
+    print(name, "cycles per frame; columns = waves 0..15")
     for i in range(5):
-        print("   %-20s %9.0f %9.0f" % (names[i], st[0, i] / T, st[1, i] / T))
-    print("   total per frame      %9.0f" % (st[0, :5].sum() / T))
-    if with_deriv:
-        print("  backward loop:")
-        for i in range(5):
-            print("   %-20s %9.0f %9.0f" % (names[i], st[2, i] / T, st[3, i] / T))
-        print("   total per frame      %9.0f" % (st[2, :5].sum() / T))
+        print("  %-13s" % names[i], " ".join("%6.0f" % v for v in st[ph, :, i]))
+    print("  total        ", " ".join("%6.0f" % v for v in st[ph, :, :5].sum(axis=1)))

@@ -42,7 +42,7 @@ Workspace carve(char *base, int H, int S, int T) {
   w.ab = (float *)take((size_t)S * 4);
   w.gs = (float *)take((size_t)S * 4);
   w.fail = (int32_t *)take(256);
-  w.scalar = (double *)take(256);
+  w.scalar = (double *)take(4096);  // also the stamp area of diagnostic builds
   w.total = off;
   return w;
 }
@@ -77,8 +77,13 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
     std::lock_guard<std::mutex> lock(g->mu);
     d = g->dev[device];
   }
-  if (!compute_layout(g->H, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &p->L))
+  bool tied = g->tied;
+  if (!compute_layout(g->H, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
+    if (tied) return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit
     return TC_ERR_UNSUPPORTED;
+  }
+  p->tied_fs = tied ? d.tied_fs : nullptr;
+  p->tied_w = tied ? d.tied_w : nullptr;
   p->fwd = d.fwd;
   p->bwd = d.bwd;
   p->pi = d.pi;

@@ -55,7 +55,7 @@ struct ArcRec {
 // thread that owns the state folds those slots in before it reads the sum ("fix-up" list, sorted by
 // owner thread).
 constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are free (offsets are multiples of 4)
-constexpr int kStreamUnroll = 16;
+constexpr int kStreamUnroll = 16;  // two chunks of 8 cells in ping-pong
 constexpr int kMaxIndex = 1 << 14;
 
 struct ScheduleHost {
@@ -81,6 +81,8 @@ struct ScheduleDev {
 struct DenGraphDev {
   ScheduleDev fwd, bwd;
   const float *pi;  // initial probs padded to Hs
+  const uint32_t *tied_fs = nullptr;  // tied graphs: per state, forward-pdf*4 | self-loop-pdf*4 << 16
+  const float *tied_w = nullptr;      // tied graphs: per state, self-loop probability (0 if none)
   void *blob = nullptr;
 };
 
@@ -91,6 +93,7 @@ struct DenLayout {
   int Hs, Ps;           // H, P rounded up to a multiple of 4
   int off_a, off_acc, off_g, off_al, off_red, off_asum, total_floats;
   bool alpha_in_lds;
+  int off_p2;           // tied graphs, backward: second exp(y) buffer (frame t-1 while frame t is in use)
   int JV, PV;           // template instantiation: float4s of states / pdfs owned per thread
   int acc_floats;       // size of the accumulator region: Hs + 4 + extra slots, rounded to 4
 };
@@ -111,6 +114,8 @@ struct DenParams {
   float leaky, deriv_weight, l2_scale;
   int y_vec, d_vec;     // rows 16-byte aligned -> float4 path
   DenLayout L;
+  const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
+  const float *tied_w;
   long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
 };
 
@@ -123,6 +128,14 @@ struct tc_den_graph {
   std::vector<float> arc_prob;
   std::vector<float> initial_probs;
   tc::ScheduleHost fwd, bwd;
+  // "Tied" graph: every non-self-loop arc entering a state carries the same pdf and a state has at most
+  // one self-loop (chain topology after Kaldi's self-loop reordering: forward-pdf on entry, self-loop
+  // pdf on the loop).  Then exp(y) factors out of the arc sums: the schedules hold only the
+  // non-self-loop arcs, the forward walk gathers alpha' alone, the backward walk gathers
+  // Y(g) = beta(g) * p(f(g)) alone, and the self-loops are applied per state by the owning thread.
+  bool tied = false;
+  std::vector<uint32_t> tied_fs;
+  std::vector<float> tied_w;
   tc::DenLayout layout;
   bool layout_ok = false;
   std::mutex mu;
@@ -186,7 +199,7 @@ struct tc_supervision {
 namespace tc {
 
 int build_schedules(tc_den_graph *g);
-bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L);
+bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L);
 int64_t layout_lds_bytes(const DenLayout &L, int T);
 
 int launch_den(const DenParams &p, hipStream_t stream);

@@ -18,7 +18,7 @@ thread_local int g_last_hip_error = 0;
 static int round4(int x) { return (x + 3) & ~3; }
 
 // Lays the per-frame working set of one sequence out in LDS.  Returns false if it cannot fit.
-bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L) {
+bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L) {
   L->Hs = round4(H);
   L->Ps = round4(P);
   const int jv = (L->Hs / 4 + kThreads - 1) / kThreads, pv = (L->Ps / 4 + kThreads - 1) / kThreads;
@@ -43,7 +43,9 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, DenLayout *L) {
     L->off_g = off;
     off += L->Ps;
     L->off_al = off;
-    if (with_alpha) off += L->Hs + 4;
+    if (with_alpha || tied) off += L->Hs + 4;  // tied graphs: owner-private parking of alpha'_{t+1}
+    L->off_p2 = off;
+    if (tied) off += L->PV * 4 * kThreads;
     L->off_red = off;
     off += 4 * kWaves;
     L->off_asum = off;
@@ -351,7 +353,7 @@ static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key
       for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
   }
-  for (int i = 0; i < 64 * (kStreamUnroll / 2); ++i) out->cells.push_back(ArcRec{0.f, 0u});
+  for (int i = 0; i < 64 * kStreamUnroll; ++i) out->cells.push_back(ArcRec{0.f, 0u});
   // ROW positions as one mask word per kStreamUnroll cells (+1 word so the prefetch needs no guard)
   const size_t ncell = out->cells.size() / 64;
   out->row_masks.assign(ncell / kStreamUnroll + 2, 0u);
@@ -372,11 +374,69 @@ static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key
 
 int build_schedules(tc_den_graph *g) {
   const int Hs = round4(g->H);
+  // ---- is the graph tied?  (see tc_den_graph::tied)
+  // Per state g: every non-self-loop in-arc carries one pdf f(g); self-loops that also carry f(g) are
+  // ordinary members of that class; at most one further self-loop (pdf s(g)) is "special" and is applied
+  // by the thread that owns g instead of travelling in the schedules.
+  std::vector<char> special(g->A, 0);
+  {
+    const int H = g->H;
+    std::vector<int32_t> fpdf(H, -1), spdf(H, -1);
+    std::vector<float> wself(H, 0.f);
+    bool tied = true;
+    for (int64_t a = 0; a < g->A && tied; ++a) {
+      const int s = g->arc_src[a], d = g->arc_dst[a], p = g->arc_pdf[a];
+      if (s == d) continue;
+      if (fpdf[d] >= 0 && fpdf[d] != p) tied = false;
+      fpdf[d] = p;
+    }
+    for (int64_t a = 0; a < g->A && tied; ++a) {
+      const int s = g->arc_src[a], d = g->arc_dst[a], p = g->arc_pdf[a];
+      if (s != d) continue;
+      if (fpdf[d] >= 0 && p == fpdf[d]) continue;  // forward class
+      if (spdf[d] < 0) {
+        spdf[d] = p;
+        wself[d] = g->arc_prob[a];
+        special[a] = 1;
+      } else if (fpdf[d] < 0) {
+        fpdf[d] = p;
+      } else {
+        tied = false;
+      }
+    }
+    if (getenv("TC_FORCE_GENERAL")) tied = false;
+    g->tied = tied;
+    g->tied_fs.assign(Hs + 4, 0u);
+    g->tied_w.assign(Hs + 4, 0.f);
+    if (tied)
+      for (int h = 0; h < H; ++h) {
+        g->tied_fs[h] = (uint32_t)(std::max(fpdf[h], 0) * 4) | ((uint32_t)(std::max(spdf[h], 0) * 4) << 16);
+        g->tied_w[h] = wself[h];
+      }
+  }
+  if (g->tied) {
+    // schedules over everything but the special self-loops
+    std::vector<int32_t> src, dst, pdf;
+    std::vector<float> prob;
+    for (int64_t a = 0; a < g->A; ++a)
+      if (!special[a]) {
+        src.push_back(g->arc_src[a]);
+        dst.push_back(g->arc_dst[a]);
+        pdf.push_back(g->arc_pdf[a]);
+        prob.push_back(g->arc_prob[a]);
+      }
+    const int64_t A2 = (int64_t)src.size();
+    build_one(g->H, Hs, g->P, A2, dst.data(), src.data(), pdf.data(), prob.data(), &g->fwd);
+    build_one(g->H, Hs, g->P, A2, src.data(), dst.data(), pdf.data(), prob.data(), &g->bwd);
+    g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), true, &g->layout);
+    if (g->layout_ok) return TC_OK;
+    g->tied = false;  // the second exp(y) buffer does not fit: use the general kernel
+  }
   // forward: alpha_{t+1}(dst) sums over in-arcs, gathers alpha'_t(src)
   build_one(g->H, Hs, g->P, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->fwd);
   // backward: beta'_t(src) sums over out-arcs, gathers beta_{t+1}(dst)
   build_one(g->H, Hs, g->P, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), &g->bwd);
-  g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &g->layout);
+  g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
   return TC_OK;
 }
 
@@ -571,6 +631,7 @@ int tc_den_graph_stats(const tc_den_graph *g, int64_t *o) {
   o[5] = g->bwd.rows;
   o[6] = g->fwd.conflict_free_cost ? 1000 * g->fwd.conflict_cost / g->fwd.conflict_free_cost : 0;
   o[7] = g->bwd.conflict_free_cost ? 1000 * g->bwd.conflict_cost / g->bwd.conflict_free_cost : 0;
+  o[8] = g->tied ? 1 : 0;
   return TC_OK;
 }
 
@@ -598,6 +659,8 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
       {g->bwd.fix.data(), g->bwd.fix.size() * sizeof(int2), 0},
       {g->fwd.row_masks.data(), g->fwd.row_masks.size() * 4, 0},
       {g->bwd.row_masks.data(), g->bwd.row_masks.size() * 4, 0},
+      {g->tied_fs.data(), g->tied_fs.size() * 4, 0},
+      {g->tied_w.data(), g->tied_w.size() * 4, 0},
   };
   size_t total = 0;
   for (auto &p : parts) {
@@ -626,6 +689,10 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
                       (const uint32_t *)(blob + parts[10].off), (const int32_t *)(blob + parts[7].off),
                       (const int2 *)(blob + parts[8].off)};
   d.pi = (const float *)(blob + parts[4].off);
+  if (g->tied) {
+    d.tied_fs = (const uint32_t *)(blob + parts[11].off);
+    d.tied_w = (const float *)(blob + parts[12].off);
+  }
   g->dev[device] = d;
   return TC_OK;
 }

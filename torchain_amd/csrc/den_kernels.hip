@@ -30,7 +30,7 @@ namespace tc {
     st_prev = st_now;                    \
   }
 #define TC_STAMP_FLUSH(ptr)                                                         \
-  if (blockIdx.x == 0 && lane == 0 && wave < 2)                                     \
+  if (blockIdx.x == 0 && lane == 0)                                                 \
     for (int i = 0; i < 8; ++i) (ptr)[wave * 8 + i] = st_acc[i];
 #else
 #define TC_STAMP_DECL
@@ -91,8 +91,10 @@ __device__ __forceinline__ void store_row4(float *row, int i, int n, int vec, fl
 // use (ROW cells carry valid offsets, so their gathers are harmless); only the commit of a finished
 // row sits behind a branch, and that branch is scalar: `mask` (bit u <=> cell u is a ROW cell) comes
 // from the schedule through scalar loads.
-//   FWD: acc(row) += alpha'(src) * w * p(pdf)
-//   BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
+//   general graph  FWD: acc(row) += alpha'(src) * w * p(pdf)
+//                  BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
+//   tied graph     FWD: acc(row) += alpha'(src) * w                      (p(f(row)) applied by the owner)
+//                  BWD: vf = w * Y(dst), Y = beta * p(f(dst));  acc(row) += vf;  gamma(f(dst)) += vf * ...
 constexpr int kChunk = kStreamUnroll / 2;
 // gamma_t(pdf) is an occupation posterior (sum over pdfs = 1), accumulated as unsigned fixed point
 // with 31 fractional bits: quantum 4.7e-10, exact (order-independent, bitwise reproducible) sums.
@@ -117,7 +119,12 @@ __device__ __forceinline__ float lds_at(const float *base, uint32_t byte_off) {
   return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-template <bool BWD, bool ALPHA_LDS>
+__device__ __forceinline__ void gamma_add(float *GM, uint32_t byte_off, float v) {
+  // integer LDS atomics run at store rate; float ones are lane-serialised on gfx950
+  atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + byte_off), __float2uint_rn(v));
+}
+
+template <bool BWD, bool ALPHA_LDS, bool TIED>
 __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t mask, RowState &rs,
                                               const float *__restrict__ SRC, const float *__restrict__ PB,
                                               float *__restrict__ ACC, float *__restrict__ GM,
@@ -126,13 +133,8 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
   float a[kChunk], pp[kChunk];
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
-#ifdef TC_EXP_NOCONFLICT  // ablation: every lane gathers its own bank (results are wrong)
-    a[u] = lds_at(SRC, (threadIdx.x & 63) * 4 + u * 256);
-    pp[u] = lds_at(PB, (threadIdx.x & 63) * 4 + u * 256);
-#else
     a[u] = lds_at(SRC, q[u].y >> 16);
-    pp[u] = lds_at(PB, q[u].y & 0xfffcu);
-#endif
+    if (!TIED) pp[u] = lds_at(PB, q[u].y & 0xfffcu);
   }
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
@@ -150,21 +152,25 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
       w = 0.f;  // the arc math below then adds nothing for this cell
     }
     if (!BWD) {
-      rs.acc = fmaf(a[u] * w, pp[u], rs.acc);
+      rs.acc = TIED ? fmaf(a[u], w, rs.acc) : fmaf(a[u] * w, pp[u], rs.acc);
     } else {
-      const float vf = w * a[u] * pp[u];
+      const float vf = TIED ? w * a[u] : w * a[u] * pp[u];
       rs.acc += vf;
-      // gamma in fixed point: integer LDS atomics run at store rate, float ones are lane-serialised
-      // (a ROW cell adds 0 at its lane-aligned dummy offset)
-      atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + (q[u].y & 0xfffcu)),
-                __float2uint_rn(vf * rs.occf));
+#ifdef TC_EXP_NOGAMMA  // ablation: no gamma atomics in the walk (wrong derivatives)
+      rs.acc += vf * rs.occf * 1e-30f;
+#else
+      gamma_add(GM, q[u].y & 0xfffcu, vf * rs.occf);  // a ROW cell adds 0 at its lane-aligned dummy offset
+#endif
     }
   }
 }
 
 // Consumes this wave's cell stream with two register buffers in ping-pong: while one chunk is being
-// processed the next one (4 KB per wave) is in flight from L2.
-template <bool BWD, bool ALPHA_LDS>
+// processed the next one (4 KB per wave, 64 KB per CU) is in flight from L2.  The row mask of the NEXT
+// iteration is fetched at the top of this one and only made scalar at the bottom, so its L2 round trip
+// is never waited for on its own (vmcnt retires in order: waiting for it early would drain the
+// prefetched chunk as well).
+template <bool BWD, bool ALPHA_LDS, bool TIED>
 __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int lane, int dummy_row,
                                           const float *__restrict__ SRC, const float *__restrict__ PB,
                                           float *__restrict__ ACC, float *__restrict__ GM,
@@ -177,24 +183,23 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
   const uint4 *__restrict__ r = reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / 2) * 64 + lane;
   const uint32_t *__restrict__ mk = sc.row_masks + first / kStreamUnroll;
   uint2 qa[kChunk], qb[kChunk];
+  auto load_chunk = [&](uint2 (&q)[kChunk], int cell0) {
 #pragma unroll
-  for (int u = 0; u < kChunk / 2; ++u) {
-    const uint4 v = r[u * 64];
-    qa[2 * u] = make_uint2(v.x, v.y);
-    qa[2 * u + 1] = make_uint2(v.z, v.w);
-  }
-  uint32_t m = __builtin_amdgcn_readfirstlane(mk[0]);
+    for (int u = 0; u < kChunk / 2; ++u) {
+      const uint4 v = r[(cell0 / 2 + u) * 64];
+      q[2 * u] = make_uint2(v.x, v.y);
+      q[2 * u + 1] = make_uint2(v.z, v.w);
+    }
+  };
+  uint32_t m_raw = mk[0];
+  load_chunk(qa, 0);
+  uint32_t m = __builtin_amdgcn_readfirstlane(m_raw);
   RowState rs;
   rs.row = (uint32_t)dummy_row;  // until the stream's first ROW cell
   rs.acc = 0.f;
   rs.occf = 0.f;
-#ifdef TC_EXP_HALFLOAD  // ablation: every loaded chunk is processed twice, half the loads (wrong results)
-  for (int c = 0; c < ncells; c += 2 * kStreamUnroll) {
-#else
   for (int c = 0; c < ncells; c += kStreamUnroll) {
-#endif
-    const uint32_t m_next = __builtin_amdgcn_readfirstlane(mk[c / kStreamUnroll + 1]);
-#ifndef TC_EXP_NOPRIO
+    m_raw = mk[c / kStreamUnroll + 1];  // oldest load of this iteration; consumed at the bottom
     // Self-balancing: a wave's issue priority falls as it advances through its stream, so the waves
     // that lag (the arbiter otherwise favours the oldest) outrank the leaders and all 16 reach the
     // barrier together instead of leaving a tail with few active waves.
@@ -206,41 +211,24 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
       __builtin_amdgcn_s_setprio(1);
     else
       __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef TC_EXP_NOLOAD  // ablation: re-read the same two chunks every iteration (L1-resident; wrong results)
-    const int cc = 0;
-#else
-    const int cc = c;
-#endif
-#pragma unroll
-    for (int u = 0; u < kChunk / 2; ++u) {
-      const uint4 v = r[((cc + kChunk) / 2 + u) * 64];
-      qb[2 * u] = make_uint2(v.x, v.y);
-      qb[2 * u + 1] = make_uint2(v.z, v.w);
-    }
-    process_chunk<BWD, ALPHA_LDS>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
-#ifdef TC_EXP_HALFLOAD
-    process_chunk<BWD, ALPHA_LDS>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
-#endif
-    // the stream is followed by kChunk readable padding cells, so this load needs no guard
-#pragma unroll
-    for (int u = 0; u < kChunk / 2; ++u) {
-      const uint4 v = r[((cc + kStreamUnroll) / 2 + u) * 64];
-      qa[2 * u] = make_uint2(v.x, v.y);
-      qa[2 * u + 1] = make_uint2(v.z, v.w);
-    }
-    process_chunk<BWD, ALPHA_LDS>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
-#ifdef TC_EXP_HALFLOAD
-    process_chunk<BWD, ALPHA_LDS>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
-#endif
-    m = m_next;
+    // the stream is followed by kStreamUnroll readable padding cells, so these loads need no guard
+    load_chunk(qb, c + kChunk);
+    process_chunk<BWD, ALPHA_LDS, TIED>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    load_chunk(qa, c + kStreamUnroll);
+    process_chunk<BWD, ALPHA_LDS, TIED>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    m = __builtin_amdgcn_readfirstlane(m_raw);
   }
-#ifndef TC_EXP_NOPRIO
   __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
-template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV>
+// Tied graphs: per-state self-loop and forward-pdf terms, applied by the thread that owns the state.
+//   fs = forward-pdf*4 | self-loop-pdf*4 << 16 (LDS byte offsets into exp(y)), ws = self-loop prob.
+__device__ __forceinline__ float tied_alpha(const float *PB, uint32_t fs, float ws, float F, float a_self) {
+  // alpha_{t+1}(g) * asum_t = p(f(g)) * sum_{h != g} w * alpha'_t(h)  +  p(s(g)) * w_s * alpha'_t(g)
+  return fmaf(lds_at(PB, fs & 0xffffu), F, lds_at(PB, fs >> 16) * (ws * a_self));
+}
+
+template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV, bool TIED>
 __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p) {
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -315,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
-    walk_rows<false, true>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
+    walk_rows<false, true, TIED>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
     __syncthreads();  // all row sums committed
     TC_STAMP(3)
@@ -328,6 +316,13 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       v4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (h0 < Hs) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
+        if (TIED) {
+          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          const float4 ws = *reinterpret_cast<const float4 *>(p.tied_w + h0);
+          const float4 al = *reinterpret_cast<float4 *>(A0 + h0);  // alpha'_t of the owned states
+          a = make_float4(tied_alpha(PB, fs.x, ws.x, a.x, al.x), tied_alpha(PB, fs.y, ws.y, a.y, al.y),
+                          tied_alpha(PB, fs.z, ws.z, a.z, al.z), tied_alpha(PB, fs.w, ws.w, a.w, al.w));
+        }
         v4[j] = make_float4(a.x * inv_prev, a.y * inv_prev, a.z * inv_prev, a.w * inv_prev);
         part += (v4[j].x + v4[j].y) + (v4[j].z + v4[j].w);
       }
@@ -390,30 +385,57 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   float bsum = block_sum(part, red + 3 * kWaves, wave, lane);  // also orders the A0 reuse below
   float4 areg[JV];
   float4 ycur[PV], ynext[PV];
+  float4 bown[JV];  // tied graphs: beta_{t+1} of the owned states (the LDS gather source holds Y instead)
+  float4 acur[JV];  // tied graphs: alpha'_t of the owned states (alpha'_{t+1} is parked in the thread's own AL slots)
   const int bfx0 = p.bwd.fix_begin[tid], bfx1 = p.bwd.fix_begin[tid + 1];
+  // tied graphs keep two exp(y) buffers in the backward pass: frame t (self-loop terms of the owner
+  // pass) and frame t-1 (written under the arc walk, needed to form Y for the next frame)
+  float *PBcur = PB, *PBnext = lds + p.L.off_p2;
   {
     const float *hist_t = hist + (int64_t)(T - 1) * hist_step;
     const float *yrow = p.y + ((int64_t)(T - 1) * S + s) * p.y_stride;
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
+      bown[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (h0 < Hs) {
         float4 b = make_float4(h0 < H ? inv_tot + bsum : 0.f, h0 + 1 < H ? inv_tot + bsum : 0.f,
                                h0 + 2 < H ? inv_tot + bsum : 0.f, h0 + 3 < H ? inv_tot + bsum : 0.f);
-        *reinterpret_cast<float4 *>(A0 + h0) = b;
+        bown[j] = b;
+        if (!TIED) *reinterpret_cast<float4 *>(A0 + h0) = b;
         *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);  // states with no out-arcs
-        if (ALPHA_LDS) *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + h0);
+        if (TIED) {
+          acur[j] = *reinterpret_cast<const float4 *>(hist_t + h0);
+          *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + hist_step + h0);
+        } else if (ALPHA_LDS) {
+          *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + h0);
+        }
+      } else if (TIED) {
+        acur[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    if (ALPHA_LDS && tid < 4) AL[Hs + tid] = 0.f;
+    if (!TIED && ALPHA_LDS && tid < 4) AL[Hs + tid] = 0.f;
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
       const int i0 = 4 * (tid + kThreads * v);
       ycur[v] = load_row4(yrow, i0, P, p.y_vec);
       if (i0 < Ps) {
-        *reinterpret_cast<float4 *>(PB + i0) = make_float4(exp_limited(ycur[v].x), exp_limited(ycur[v].y),
-                                                           exp_limited(ycur[v].z), exp_limited(ycur[v].w));
+        *reinterpret_cast<float4 *>(PBcur + i0) = make_float4(exp_limited(ycur[v].x), exp_limited(ycur[v].y),
+                                                              exp_limited(ycur[v].z), exp_limited(ycur[v].w));
         *reinterpret_cast<float4 *>(GM + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (TIED) {
+      __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = beta_T(g) * p_{T-1}(f(g))
+#pragma unroll
+      for (int j = 0; j < JV; ++j) {
+        const int h0 = 4 * (tid + kThreads * j);
+        if (h0 < Hs) {
+          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          *reinterpret_cast<float4 *>(A0 + h0) =
+              make_float4(bown[j].x * lds_at(PBcur, fs.x & 0xffffu), bown[j].y * lds_at(PBcur, fs.y & 0xffffu),
+                          bown[j].z * lds_at(PBcur, fs.z & 0xffffu), bown[j].w * lds_at(PBcur, fs.w & 0xffffu));
+        }
       }
     }
   }
@@ -423,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #endif
   for (int t = T - 1; t >= 0; --t) {
     TC_STAMP(0)
-    __syncthreads();  // B, PB, AL ready; BACC and GAMMA zero
+    __syncthreads();  // B (or Y), PB, AL ready; BACC and GAMMA zero
     TC_STAMP(1)
     const float asum_t = asum_h[t];
     const float inv_as = 1.0f / asum_t;
@@ -434,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       const float *yrow = p.y + ((int64_t)tn * S + s) * p.y_stride;
 #pragma unroll
       for (int v = 0; v < PV; ++v) ynext[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
-      if (ALPHA_LDS) {
+      if (ALPHA_LDS || TIED) {
         const float *hist_n = hist + (int64_t)tn * hist_step;
 #pragma unroll
         for (int j = 0; j < JV; ++j) {
@@ -443,7 +465,20 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         }
       }
     }
-    walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, Hs, A0, PB, ACC, GM, AL, hist_t, inv_as);
+    if (TIED)  // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
+      walk_rows<false, true, true>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, nullptr, nullptr, nullptr, 0.f);
+    else
+      walk_rows<true, ALPHA_LDS, false>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
+    if (TIED) {
+      // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * (tid + kThreads * v);
+        if (i0 < Ps)
+          *reinterpret_cast<float4 *>(PBnext + i0) = make_float4(exp_limited(ynext[v].x), exp_limited(ynext[v].y),
+                                                                 exp_limited(ynext[v].z), exp_limited(ynext[v].w));
+      }
+    }
     TC_STAMP(2)
     __syncthreads();  // beta' sums and gamma committed
     TC_STAMP(3)
@@ -457,15 +492,42 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (h0 < Hs) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
+        float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TIED)
+          al = acur[j];
+        else if (t == 0)
+          al = ALPHA_LDS ? *reinterpret_cast<float4 *>(AL + h0) : *reinterpret_cast<const float4 *>(hist_t + h0);
+        if (TIED) {
+          // Everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
+          //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
+          //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
+          //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
+          // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history.  The self-loop arc also
+          // adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
+          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          const float4 ws = *reinterpret_cast<const float4 *>(p.tied_w + h0);
+          const float asum_up = asum_h[t + 1];
+          const float4 aup = *reinterpret_cast<float4 *>(AL + h0);  // alpha'_{t+1}, written by this thread
+          auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float &ax) {
+            const float ps_ws = lds_at(PBcur, fsx >> 16) * wsx;
+            const float selfpart = ps_ws * alx * inv_as;           // self-loop part of alpha_{t+1}(g)
+            const float alpha_up = aupx - cpx * asum_up;            // alpha_{t+1}(g)
+            ax += ps_ws * bo;                                       // vf_s into beta'_t(g) * asum_t
+            gamma_add(GM, fsx >> 16, kGammaScale * (bo * selfpart));
+            gamma_add(GM, fsx & 0xffffu, kGammaScale * (bo * fmaxf(alpha_up - selfpart, 0.f)));
+          };
+          one(fs.x, ws.x, bown[j].x, al.x, aup.x, cpi[j].x, a.x);
+          one(fs.y, ws.y, bown[j].y, al.y, aup.y, cpi[j].y, a.y);
+          one(fs.z, ws.z, bown[j].z, al.z, aup.z, cpi[j].z, a.z);
+          one(fs.w, ws.w, bown[j].w, al.w, aup.w, cpi[j].w, a.w);
+        }
         b4[j] = make_float4(a.x / asum_t, a.y / asum_t, a.z / asum_t, a.w / asum_t);
         part += (cpi[j].x * b4[j].x + cpi[j].y * b4[j].y) + (cpi[j].z * b4[j].z + cpi[j].w * b4[j].w);
-        if (t == 0) {
-          float4 al = ALPHA_LDS ? *reinterpret_cast<float4 *>(AL + h0)
-                                : *reinterpret_cast<const float4 *>(hist_t + h0);
-          part_ab += (al.x * b4[j].x + al.y * b4[j].y) + (al.z * b4[j].z + al.w * b4[j].w);
-        }
+        if (t == 0) part_ab += (al.x * b4[j].x + al.y * b4[j].y) + (al.z * b4[j].z + al.w * b4[j].w);
       }
     }
+    bsum = block_sum(part, red, wave, lane);  // its barrier also completes gamma_t (owner-side adds of tied graphs)
+    TC_STAMP(4)
     {
       float *drow = p.deriv + ((int64_t)t * S + s) * p.deriv_stride;
 #pragma unroll
@@ -489,8 +551,6 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         }
       }
     }
-    bsum = block_sum(part, red, wave, lane);
-    TC_STAMP(4)
     if (t == 0) {
       // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
       const float ab = block_sum(part_ab, red + kWaves, wave, lane);
@@ -500,54 +560,61 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         p.seq_gsum[s] = gs;
       }
 #ifdef TC_PHASE_STAMPS
-      if (blockIdx.x == 0 && lane == 0 && wave < 2)
-        for (int i = 0; i < 8; ++i) p.stamps[16 + wave * 8 + i] = st_acc[i];
+      if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) p.stamps[128 + wave * 8 + i] = st_acc[i];
 #endif
       break;
     }
+    // beta_t = beta'_t + leaky-sum; next frame's gather source (beta_t, or Y_{t-1} = beta_t * p_{t-1}(f) when tied)
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
       if (h0 < Hs) {
-        *reinterpret_cast<float4 *>(A0 + h0) =
-            make_float4(b4[j].x + bsum, b4[j].y + bsum, b4[j].z + bsum, b4[j].w + bsum);
-        if (ALPHA_LDS) *reinterpret_cast<float4 *>(AL + h0) = areg[j];
+        const float4 b = make_float4(b4[j].x + bsum, b4[j].y + bsum, b4[j].z + bsum, b4[j].w + bsum);
+        if (TIED) {
+          bown[j] = b;
+          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          *reinterpret_cast<float4 *>(A0 + h0) =
+              make_float4(b.x * lds_at(PBnext, fs.x & 0xffffu), b.y * lds_at(PBnext, fs.y & 0xffffu),
+                          b.z * lds_at(PBnext, fs.z & 0xffffu), b.w * lds_at(PBnext, fs.w & 0xffffu));
+        } else {
+          *reinterpret_cast<float4 *>(A0 + h0) = b;
+        }
+        if (TIED) {
+          *reinterpret_cast<float4 *>(AL + h0) = acur[j];
+          acur[j] = areg[j];
+        } else if (ALPHA_LDS) {
+          *reinterpret_cast<float4 *>(AL + h0) = areg[j];
+        }
       }
     }
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
       const int i0 = 4 * (tid + kThreads * v);
       ycur[v] = ynext[v];
-      if (i0 < Ps)
+      if (!TIED && i0 < Ps)
         *reinterpret_cast<float4 *>(PB + i0) = make_float4(exp_limited(ycur[v].x), exp_limited(ycur[v].y),
                                                            exp_limited(ycur[v].z), exp_limited(ycur[v].w));
+    }
+    if (TIED) {
+      float *tmp = PBcur;
+      PBcur = PBnext;
+      PBnext = tmp;
     }
   }
 }
 
-template <int JV, int PV>
-static int launch_jp(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
+template <int JV, int PV, bool TIED>
+static int launch_jpt(const DenParams &p, int accumulate, size_t lds_bytes, hipStream_t stream) {
   const bool want = p.deriv != nullptr;
   const bool al = p.L.alpha_in_lds;
-  const bool acc = false;
-  (void)acc;
   void (*k)(const DenParams) = nullptr;
   if (!want)
-    k = den_fwd_bwd_kernel<JV, PV, true, false, false>;
-  else if (al)
-    k = den_fwd_bwd_kernel<JV, PV, true, false, true>;
+    k = den_fwd_bwd_kernel<JV, PV, true, false, false, TIED>;
+  else if (accumulate)
+    k = al ? den_fwd_bwd_kernel<JV, PV, true, true, true, TIED> : den_fwd_bwd_kernel<JV, PV, false, true, true, TIED>;
   else
-    k = den_fwd_bwd_kernel<JV, PV, false, false, true>;
-  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
-  TC_HIP_CHECK(hipGetLastError());
-  return TC_OK;
-}
-
-template <int JV, int PV>
-static int launch_jp_accum(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
-  void (*k)(const DenParams) =
-      p.L.alpha_in_lds ? den_fwd_bwd_kernel<JV, PV, true, true, true> : den_fwd_bwd_kernel<JV, PV, false, true, true>;
+    k = al ? den_fwd_bwd_kernel<JV, PV, true, false, true, TIED> : den_fwd_bwd_kernel<JV, PV, false, false, true, TIED>;
   TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
   TC_HIP_CHECK(hipGetLastError());
@@ -559,9 +626,10 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
-#define TC_DISPATCH(J, V)                                                      \
-  if (JV <= J && PV <= V)                                                      \
-    return (accumulate && p.deriv) ? launch_jp_accum<J, V>(p, lds, stream) : launch_jp<J, V>(p, lds, stream);
+  const bool tied = p.tied_fs != nullptr;
+#define TC_DISPATCH(J, V)                                                                  \
+  if (JV <= J && PV <= V)                                                                  \
+    return tied ? launch_jpt<J, V, true>(p, accumulate, lds, stream) : launch_jpt<J, V, false>(p, accumulate, lds, stream);
   TC_DISPATCH(kJvSmall, kPvSmall)
   TC_DISPATCH(kJvLarge, kPvLarge)
 #undef TC_DISPATCH

@@ -81,10 +81,10 @@ class DenominatorGraph:
         return self
 
     def stats(self):
-        out = np.zeros(8, np.int64)
+        out = np.zeros(9, np.int64)
         check(lib.tc_den_graph_stats(self.ptr, _p(out)), "tc_den_graph_stats")
         keys = ("fwd_slots", "bwd_slots", "lds_bytes", "threads", "fwd_rows", "bwd_rows", "fwd_conflict_x1000",
-                "bwd_conflict_x1000")
+                "bwd_conflict_x1000", "tied")
         return dict(zip(keys, (int(x) for x in out)))
 
 
