@@ -55,11 +55,15 @@ struct ArcRec {
 // thread that owns the state folds those slots in before it reads the sum ("fix-up" list, sorted by
 // owner thread).
 constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are free (offsets are multiples of 4)
-constexpr int kStreamUnroll = 16;  // two chunks of 8 cells in ping-pong
+// cells per loop iteration = cells per row-mask word: two 8-cell chunks in ping-pong (a third buffer was
+// measured: no gain, and it pushes the fused kernel past 128 VGPRs)
+constexpr int kStreamUnroll = 16;
+constexpr int kStreamUnrollTied = 16;
 constexpr int kMaxIndex = 1 << 14;
 
 struct ScheduleHost {
-  std::vector<ArcRec> cells;       // all waves' streams, [cell][lane]
+  std::vector<ArcRec> cells;       // all waves' streams, [cell][lane] (final layout [pair][lane][2])
+  std::vector<uint32_t> cells6;    // tied graphs: 6-byte cells, [pair][lane]{w0, w1, off0 | off1 << 16}
   std::vector<int2> wave_range;    // kWaves x {first cell, number of cells (multiple of kStreamUnroll)}
   std::vector<uint32_t> row_masks; // one word per kStreamUnroll cells: bit u set <=> cell u is a ROW cell
   std::vector<int32_t> fix_begin;  // kThreads + 1: range of fix-up entries owned by each thread

@@ -95,7 +95,7 @@ __device__ __forceinline__ void store_row4(float *row, int i, int n, int vec, fl
 //                  BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
 //   tied graph     FWD: acc(row) += alpha'(src) * w                      (p(f(row)) applied by the owner)
 //                  BWD: vf = w * Y(dst), Y = beta * p(f(dst));  acc(row) += vf;  gamma(f(dst)) += vf * ...
-constexpr int kChunk = kStreamUnroll / 2;
+constexpr int kChunk = 8;
 // gamma_t(pdf) is an occupation posterior (sum over pdfs = 1), accumulated as unsigned fixed point
 // with 31 fractional bits: quantum 4.7e-10, exact (order-independent, bitwise reproducible) sums.
 constexpr float kGammaScale = 2147483648.0f;
@@ -156,11 +156,7 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
     } else {
       const float vf = TIED ? w * a[u] : w * a[u] * pp[u];
       rs.acc += vf;
-#ifdef TC_EXP_NOGAMMA  // ablation: no gamma atomics in the walk (wrong derivatives)
-      rs.acc += vf * rs.occf * 1e-30f;
-#else
       gamma_add(GM, q[u].y & 0xfffcu, vf * rs.occf);  // a ROW cell adds 0 at its lane-aligned dummy offset
-#endif
     }
   }
 }
@@ -216,6 +212,85 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
     process_chunk<BWD, ALPHA_LDS, TIED>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
     load_chunk(qa, c + kStreamUnroll);
     process_chunk<BWD, ALPHA_LDS, TIED>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    m = __builtin_amdgcn_readfirstlane(m_raw);
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// ---- tied graphs: 6-byte cells --------------------------------------------------------------
+// A pair of cells is {w0, w1, off0 | off1 << 16}: fp32 weights and 16-bit LDS byte offsets (gather
+// offset of an arc; accumulator offset of a ROW cell, whose weight is 0).  Both tied walks are the same
+// operation -- acc(row) += w * SRC[off] -- with SRC = alpha'_t (forward) or Y_t (backward).
+struct Pair6 {
+  uint32_t w0, w1, off;
+};
+
+// LDS access by absolute byte address: the kernel has no static __shared__, so the dynamic LDS block
+// starts at address 0 and the compiler need not add a (relocated) base to every gather address.
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ float lds_abs(uint32_t byte_addr) { return *reinterpret_cast<lds_float *>(byte_addr); }
+__device__ __forceinline__ void lds_abs_store(uint32_t byte_addr, float v) {
+  *reinterpret_cast<lds_float *>(byte_addr) = v;
+}
+
+// SRC_BASE / acc_base are absolute LDS byte addresses of the gather source and of the accumulators.
+template <uint32_t SRC_BASE>
+__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t mask, uint32_t &row_off,
+                                               float &acc, uint32_t acc_base) {
+  float a[kChunk];
+#pragma unroll
+  for (int u = 0; u < kChunk / 2; ++u) {
+    a[2 * u] = lds_abs(SRC_BASE + (q[u].off & 0xffffu));
+    a[2 * u + 1] = lds_abs(SRC_BASE + (q[u].off >> 16));
+  }
+#pragma unroll
+  for (int u = 0; u < kChunk; ++u) {
+    const float w = __uint_as_float((u & 1) ? q[u / 2].w1 : q[u / 2].w0);
+    if (__builtin_expect((mask >> u) & 1u, 0)) {  // ROW cell: commit the finished row (its own w is 0)
+      const uint32_t off = (u & 1) ? (q[u / 2].off >> 16) : (q[u / 2].off & 0xffffu);
+      lds_abs_store(acc_base + row_off, acc);
+      // in-place updates (no phi copies on the common path)
+      asm volatile("v_mov_b32 %0, 0" : "+v"(acc));
+      asm volatile("v_mov_b32 %0, %1" : "+v"(row_off) : "v"(off));
+    }
+    acc = fmaf(a[u], w, acc);
+  }
+}
+
+// Two register buffers in ping-pong, as in walk_rows.
+template <uint32_t SRC_BASE>
+__device__ __forceinline__ void walk_rows6(const ScheduleDev &sc, int wave, int lane, int dummy_row,
+                                           uint32_t acc_base) {
+  const int2 range = sc.wave_range[wave];
+  const int first = __builtin_amdgcn_readfirstlane(range.x);   // multiple of kStreamUnrollTied
+  const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnrollTied
+  const Pair6 *__restrict__ r = reinterpret_cast<const Pair6 *>(sc.cells) + (int64_t)(first / 2) * 64 + lane;
+  const uint32_t *__restrict__ mk = sc.row_masks + first / kStreamUnrollTied;
+  Pair6 qa[kChunk / 2], qb[kChunk / 2];
+  auto load_chunk = [&](Pair6 (&q)[kChunk / 2], int cell0) {
+#pragma unroll
+    for (int u = 0; u < kChunk / 2; ++u) q[u] = r[(cell0 / 2 + u) * 64];
+  };
+  uint32_t m_raw = mk[0];
+  load_chunk(qa, 0);
+  uint32_t m = __builtin_amdgcn_readfirstlane(m_raw);
+  uint32_t row_off = (uint32_t)dummy_row * 4u;
+  float acc = 0.f;
+  for (int c = 0; c < ncells; c += kStreamUnrollTied) {
+    m_raw = mk[c / kStreamUnrollTied + 1];  // oldest load of this iteration; consumed at the bottom
+    if (4 * c < ncells)                     // progress-based priority: see walk_rows
+      __builtin_amdgcn_s_setprio(3);
+    else if (2 * c < ncells)
+      __builtin_amdgcn_s_setprio(2);
+    else if (4 * c < 3 * ncells)
+      __builtin_amdgcn_s_setprio(1);
+    else
+      __builtin_amdgcn_s_setprio(0);
+    // the stream is followed by kStreamUnrollTied readable padding cells, so these loads need no guard
+    load_chunk(qb, c + kChunk);
+    process_chunk6<SRC_BASE>(qa, m & 0xffu, row_off, acc, acc_base);
+    load_chunk(qa, c + 2 * kChunk);
+    process_chunk6<SRC_BASE>(qb, (m >> 8) & 0xffu, row_off, acc, acc_base);
     m = __builtin_amdgcn_readfirstlane(m_raw);
   }
   __builtin_amdgcn_s_setprio(0);
@@ -303,7 +378,10 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
-    walk_rows<false, true, TIED>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
+    if (TIED)
+      walk_rows6<PV * 16 * kThreads>(p.fwd, wave, lane, Hs, (uint32_t)p.L.off_acc * 4u);
+    else
+      walk_rows<false, true, false>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
     __syncthreads();  // all row sums committed
     TC_STAMP(3)
@@ -466,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     if (TIED)  // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
-      walk_rows<false, true, true>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, nullptr, nullptr, nullptr, 0.f);
+      walk_rows6<PV * 16 * kThreads>(p.bwd, wave, lane, Hs, (uint32_t)p.L.off_acc * 4u);
     else
       walk_rows<true, ALPHA_LDS, false>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
     if (TIED) {
