@@ -27,6 +27,9 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
   if (jv <= kJvSmall && pv <= kPvSmall) {
     L->JV = kJvSmall;
     L->PV = kPvSmall;
+  } else if (jv <= kJvSmall && pv <= kPvLarge) {
+    L->JV = kJvSmall;
+    L->PV = kPvLarge;
   } else if (jv <= kJvLarge && pv <= kPvLarge) {
     L->JV = kJvLarge;
     L->PV = kPvLarge;

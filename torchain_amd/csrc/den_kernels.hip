@@ -5,12 +5,17 @@
 //
 // Mapping.  The frame recursion is serial and sequences never interact, so one workgroup (16 waves,
 // one per CU) owns one sequence for all 2T frames and keeps that sequence's per-frame working set in
-// LDS: alpha'_t / beta_{t+1} (gather source), the accumulator for the next frame, exp(y_t) and, in
-// the backward half, gamma_t and alpha'_t.  HBM sees each y row twice (forward, backward), each
+// LDS: exp(y_t), alpha'_t / beta_{t+1} (gather source), one accumulator per row and, in the backward
+// half, gamma_t (u32 fixed point) and alpha'_t.  HBM sees each y row twice (forward, backward), each
 // alpha' frame once out and once back, and each derivative row once.  The transition tables are
-// streamed from L2 as 8-byte records in a lane-major schedule (den_graph.cpp): lane l of a wave walks
-// one state's arc list, so a wave instruction reads 512 contiguous bytes and gathers alpha'/p from
-// LDS.  Row sums are committed with one LDS float add per row; gamma with one LDS float add per arc.
+// streamed from L2 as a per-wave cell stream in a lane-major schedule (den_graph.cpp): lane l of a
+// wave walks one state's arc list, a wave instruction loads 64 lanes x 12 or 16 contiguous bytes, and
+// the lanes gather alpha' (and exp(y)) from LDS.  There are no LDS float atomics (192 cycles per
+// wave-instruction on gfx950): every row owns its accumulator slot and gamma is integer fixed point.
+// Two code paths: the general kernel (any graph; two gathers per arc, one gamma atomic per arc in the
+// backward walk) and the "tied" kernel for chain-structured graphs (all non-self-loop arcs into a
+// state share a pdf): one gather per arc in both walks, no atomics in the walks, self-loops and gamma
+// handled per state by the owning thread.
 //
 // Numerics follow the Kaldi CPU arithmetic: linear domain, fp32, per-frame renormalisation by the
 // alpha-sum of the previous frame ("arbitrary_scale"), leaky-HMM mixing, betas carrying 1/tot_prob.
@@ -706,9 +711,10 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   const int JV = p.L.JV, PV = p.L.PV;
   const bool tied = p.tied_fs != nullptr;
 #define TC_DISPATCH(J, V)                                                                  \
-  if (JV <= J && PV <= V)                                                                  \
+  if (JV == J && PV == V)                                                                  \
     return tied ? launch_jpt<J, V, true>(p, accumulate, lds, stream) : launch_jpt<J, V, false>(p, accumulate, lds, stream);
   TC_DISPATCH(kJvSmall, kPvSmall)
+  TC_DISPATCH(kJvSmall, kPvLarge)
   TC_DISPATCH(kJvLarge, kPvLarge)
 #undef TC_DISPATCH
   return TC_ERR_UNSUPPORTED;
