@@ -246,7 +246,7 @@ static void group_rows_by_bank(std::vector<Row> &rows, size_t begin, size_t end,
 // Builds the row/slot schedule for one direction.  key[a] is the state whose sum arc a belongs to
 // (destination for the forward pass, source for the backward pass), other[a] the state it gathers.
 static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key, const int32_t *other,
-                      const int32_t *pdf, const float *prob, int unroll, ScheduleHost *out) {
+                      const int32_t *pdf, const float *prob, int unroll, bool even_rows, ScheduleHost *out) {
   out->conflict_cost = out->conflict_free_cost = 0;
   struct Row {
     int32_t state, len, slot;
@@ -302,7 +302,7 @@ static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key
   for (int sidx = 0; sidx < nslots; ++sidx) {
     int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
     per_wave[w].push_back(sidx);
-    load[w] += rows[(size_t)sidx * 64].len + 1;
+    load[w] += (rows[(size_t)sidx * 64].len + 1 + (even_rows ? 1 : 0)) & (even_rows ? ~1 : ~0);
   }
   auto bits = [](uint32_t u) {
     float f;
@@ -315,7 +315,10 @@ static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key
   for (int w = 0; w < kWaves; ++w) {
     const size_t first = out->cells.size() / 64;
     for (int sidx : per_wave[w]) {
-      const int steps = rows[(size_t)sidx * 64].len;
+      // even_rows (tied kernel, which consumes cells in pairs): a slot occupies an even number of cells,
+      // so every ROW cell sits at an even stream position; the odd slot gets one more padding step
+      int steps = rows[(size_t)sidx * 64].len;
+      if (even_rows && ((steps + 1) & 1)) ++steps;
       const size_t off = out->cells.size();
       out->cells.resize(off + (size_t)(steps + 1) * 64, ArcRec{0.f, 0u});
       arc_cells += (int64_t)steps * 64;
@@ -429,8 +432,8 @@ int build_schedules(tc_den_graph *g) {
         prob.push_back(g->arc_prob[a]);
       }
     const int64_t A2 = (int64_t)src.size();
-    build_one(g->H, Hs, g->P, A2, dst.data(), src.data(), pdf.data(), prob.data(), kStreamUnrollTied, &g->fwd);
-    build_one(g->H, Hs, g->P, A2, src.data(), dst.data(), pdf.data(), prob.data(), kStreamUnrollTied, &g->bwd);
+    build_one(g->H, Hs, g->P, A2, dst.data(), src.data(), pdf.data(), prob.data(), kStreamUnrollTied, true, &g->fwd);
+    build_one(g->H, Hs, g->P, A2, src.data(), dst.data(), pdf.data(), prob.data(), kStreamUnrollTied, true, &g->bwd);
     g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), true, &g->layout);
     // Tied walks use neither the pdf offset nor (in the ROW cell) the state, so a cell shrinks to a
     // 32-bit weight plus a 16-bit LDS byte offset (gather offset for an arc, accumulator offset for a
@@ -449,6 +452,7 @@ int build_schedules(tc_den_graph *g) {
               if (c.idx & kRowFlag) {
                 w[k] = 0u;                     // 0.0f: the unconditional FMA adds nothing
                 off[k] = (x & 0xffffu) * 4u;   // accumulator slot -> byte offset
+                off[k] |= kRowFlag;            // in-band ROW flag (ROW cells sit at even positions: k == 0)
               } else {
                 w[k] = x;
                 off[k] = c.idx >> 16;          // state * 4
@@ -466,9 +470,9 @@ int build_schedules(tc_den_graph *g) {
     g->tied = false;  // the second exp(y) buffer does not fit: use the general kernel
   }
   // forward: alpha_{t+1}(dst) sums over in-arcs, gathers alpha'_t(src)
-  build_one(g->H, Hs, g->P, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), kStreamUnroll, &g->fwd);
+  build_one(g->H, Hs, g->P, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), kStreamUnroll, false, &g->fwd);
   // backward: beta'_t(src) sums over out-arcs, gathers beta_{t+1}(dst)
-  build_one(g->H, Hs, g->P, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), kStreamUnroll, &g->bwd);
+  build_one(g->H, Hs, g->P, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), kStreamUnroll, false, &g->bwd);
   g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
   return TC_OK;
 }

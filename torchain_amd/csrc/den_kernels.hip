@@ -239,26 +239,36 @@ __device__ __forceinline__ void lds_abs_store(uint32_t byte_addr, float v) {
 }
 
 // SRC_BASE / acc_base are absolute LDS byte addresses of the gather source and of the accumulators.
+// Cells are consumed a PAIR at a time: (w0, w1) are adjacent in the stream and the two gathered values
+// land in adjacent registers, so one packed FMA (v_pk_fma_f32) serves both cells, and because the
+// schedule puts ROW cells at even positions only, one scalar test serves both as well.  A ROW cell's
+// own weight is 0, so the packed FMA needs no special case for it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <uint32_t SRC_BASE>
-__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t mask, uint32_t &row_off,
-                                               float &acc, uint32_t acc_base) {
-  float a[kChunk];
+__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t &row_off, v2f &acc,
+                                               uint32_t acc_base) {
+  v2f a[kChunk / 2];
 #pragma unroll
   for (int u = 0; u < kChunk / 2; ++u) {
-    a[2 * u] = lds_abs(SRC_BASE + (q[u].off & 0xffffu));
-    a[2 * u + 1] = lds_abs(SRC_BASE + (q[u].off >> 16));
+    a[u].x = lds_abs(SRC_BASE + (q[u].off & 0xfffcu));
+    a[u].y = lds_abs(SRC_BASE + (q[u].off >> 16));
   }
 #pragma unroll
-  for (int u = 0; u < kChunk; ++u) {
-    const float w = __uint_as_float((u & 1) ? q[u / 2].w1 : q[u / 2].w0);
-    if (__builtin_expect((mask >> u) & 1u, 0)) {  // ROW cell: commit the finished row (its own w is 0)
-      const uint32_t off = (u & 1) ? (q[u / 2].off >> 16) : (q[u / 2].off & 0xffffu);
-      lds_abs_store(acc_base + row_off, acc);
+  for (int u = 0; u < kChunk / 2; ++u) {
+    // the ROW flag travels in-band (bit 0 of the even cell's offset) and is the same in all 64 lanes,
+    // so no separate mask stream -- and no extra dependent L2 load per loop iteration -- is needed
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(q[u].off) & 1u, 0)) {
+      lds_abs_store(acc_base + row_off, acc.x + acc.y);  // commit the finished row
+      const uint32_t off = q[u].off & 0xfffcu;
       // in-place updates (no phi copies on the common path)
-      asm volatile("v_mov_b32 %0, 0" : "+v"(acc));
+      asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "+v"(acc.x), "+v"(acc.y));
       asm volatile("v_mov_b32 %0, %1" : "+v"(row_off) : "v"(off));
     }
-    acc = fmaf(a[u], w, acc);
+    v2f w;
+    w.x = __uint_as_float(q[u].w0);
+    w.y = __uint_as_float(q[u].w1);
+    acc = __builtin_elementwise_fma(a[u], w, acc);
   }
 }
 
@@ -270,20 +280,16 @@ __device__ __forceinline__ void walk_rows6(const ScheduleDev &sc, int wave, int 
   const int first = __builtin_amdgcn_readfirstlane(range.x);   // multiple of kStreamUnrollTied
   const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnrollTied
   const Pair6 *__restrict__ r = reinterpret_cast<const Pair6 *>(sc.cells) + (int64_t)(first / 2) * 64 + lane;
-  const uint32_t *__restrict__ mk = sc.row_masks + first / kStreamUnrollTied;
   Pair6 qa[kChunk / 2], qb[kChunk / 2];
   auto load_chunk = [&](Pair6 (&q)[kChunk / 2], int cell0) {
 #pragma unroll
     for (int u = 0; u < kChunk / 2; ++u) q[u] = r[(cell0 / 2 + u) * 64];
   };
-  uint32_t m_raw = mk[0];
   load_chunk(qa, 0);
-  uint32_t m = __builtin_amdgcn_readfirstlane(m_raw);
   uint32_t row_off = (uint32_t)dummy_row * 4u;
-  float acc = 0.f;
+  v2f acc = {0.f, 0.f};
   for (int c = 0; c < ncells; c += kStreamUnrollTied) {
-    m_raw = mk[c / kStreamUnrollTied + 1];  // oldest load of this iteration; consumed at the bottom
-    if (4 * c < ncells)                     // progress-based priority: see walk_rows
+    if (4 * c < ncells)  // progress-based priority: see walk_rows
       __builtin_amdgcn_s_setprio(3);
     else if (2 * c < ncells)
       __builtin_amdgcn_s_setprio(2);
@@ -293,10 +299,9 @@ __device__ __forceinline__ void walk_rows6(const ScheduleDev &sc, int wave, int 
       __builtin_amdgcn_s_setprio(0);
     // the stream is followed by kStreamUnrollTied readable padding cells, so these loads need no guard
     load_chunk(qb, c + kChunk);
-    process_chunk6<SRC_BASE>(qa, m & 0xffu, row_off, acc, acc_base);
+    process_chunk6<SRC_BASE>(qa, row_off, acc, acc_base);
     load_chunk(qa, c + 2 * kChunk);
-    process_chunk6<SRC_BASE>(qb, (m >> 8) & 0xffu, row_off, acc, acc_base);
-    m = __builtin_amdgcn_readfirstlane(m_raw);
+    process_chunk6<SRC_BASE>(qb, row_off, acc, acc_base);
   }
   __builtin_amdgcn_s_setprio(0);
 }
