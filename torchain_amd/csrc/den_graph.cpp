@@ -458,10 +458,14 @@ int build_schedules(tc_den_graph *g) {
                 off[k] = c.idx >> 16;          // state * 4
               }
             }
-            uint32_t *o = &sc->cells6[(pr * 64 + l) * 3];
-            o[0] = w[0];
-            o[1] = w[1];
-            o[2] = off[0] | (off[1] << 16);
+            // memory layout: a chunk of 8 cells (4 pairs) of one lane is three 16-byte blocks
+            // {w0..w3}, {w4..w7}, {off01, off23, off45, off67}, stored [chunk][block][lane], so the walk
+            // issues three coalesced 16-byte loads (1 KB per wave instruction) per chunk
+            const size_t chunk = pr / 4, k = pr % 4;
+            uint32_t *base = &sc->cells6[chunk * 3 * 64 * 4];
+            base[((k / 2) * 64 + l) * 4 + (k % 2) * 2 + 0] = w[0];
+            base[((k / 2) * 64 + l) * 4 + (k % 2) * 2 + 1] = w[1];
+            base[(2 * 64 + l) * 4 + k] = off[0] | (off[1] << 16);
           }
       }
       return TC_OK;

@@ -279,11 +279,16 @@ __device__ __forceinline__ void walk_rows6(const ScheduleDev &sc, int wave, int 
   const int2 range = sc.wave_range[wave];
   const int first = __builtin_amdgcn_readfirstlane(range.x);   // multiple of kStreamUnrollTied
   const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnrollTied
-  const Pair6 *__restrict__ r = reinterpret_cast<const Pair6 *>(sc.cells) + (int64_t)(first / 2) * 64 + lane;
+  // the stream is stored [chunk of 8 cells][3 blocks][lane]{16 bytes}: see den_graph.cpp
+  const uint4 *__restrict__ r = reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / kChunk) * 3 * 64 + lane;
   Pair6 qa[kChunk / 2], qb[kChunk / 2];
   auto load_chunk = [&](Pair6 (&q)[kChunk / 2], int cell0) {
-#pragma unroll
-    for (int u = 0; u < kChunk / 2; ++u) q[u] = r[(cell0 / 2 + u) * 64];
+    const uint4 *rc = r + (int64_t)(cell0 / kChunk) * 3 * 64;
+    const uint4 wa = rc[0], wb = rc[64], oc = rc[128];
+    q[0] = Pair6{wa.x, wa.y, oc.x};
+    q[1] = Pair6{wa.z, wa.w, oc.y};
+    q[2] = Pair6{wb.x, wb.y, oc.z};
+    q[3] = Pair6{wb.z, wb.w, oc.w};
   };
   load_chunk(qa, 0);
   uint32_t row_off = (uint32_t)dummy_row * 4u;
