@@ -40,11 +40,11 @@ struct ArcRec {
 //   arc cell  : {w, pdf*4 | state*4 << 16}: the two LDS byte offsets the lane gathers from, ready to
 //               use (exp(y) sits at LDS offset 0, alpha'/beta at a compile-time base that the ds_read
 //               immediate supplies), so address math is one AND and one shift per cell.
-//   ROW cell  : {accumulator slot of the row that starts here, kRowFlag | state*4 << 16}.  It
-//               commits the previous row's sum with a plain LDS store.  All 64 lanes of a wave hit
-//               their ROW cells at the same stream position; the positions are also published as a
-//               bit mask per 16 cells (row_masks) that the wave reads with scalar loads, so the test
-//               costs no vector instruction.
+//   ROW cell  : {accumulator slot | state << 16 of the row that starts here, kRowFlag | dummy offsets}.
+//               It commits the previous row's sum with a plain LDS store.  All 64 lanes of a wave hit
+//               their ROW cells at the same stream position, so the flag test (v_readfirstlane of
+//               the cell's own offset word) feeds a scalar branch.  The flag is deliberately in-band:
+//               a separate mask array cost one dependent L2 round trip per loop iteration.
 //   padding   : arc cell with w = 0, offsets 0 (adds 0)
 // A stream ends with a ROW(dummy) cell and is padded to a multiple of kStreamUnroll cells; the whole
 // array ends with kStreamUnroll / 2 extra padding cells so the prefetch never needs a bounds check.
@@ -65,7 +65,6 @@ struct ScheduleHost {
   std::vector<ArcRec> cells;       // all waves' streams, [cell][lane] (final layout [pair][lane][2])
   std::vector<uint32_t> cells6;    // tied graphs: 6-byte cells, [pair][lane]{w0, w1, off0 | off1 << 16}
   std::vector<int2> wave_range;    // kWaves x {first cell, number of cells (multiple of kStreamUnroll)}
-  std::vector<uint32_t> row_masks; // one word per kStreamUnroll cells: bit u set <=> cell u is a ROW cell
   std::vector<int32_t> fix_begin;  // kThreads + 1: range of fix-up entries owned by each thread
   std::vector<int2> fix;           // {state, extra slot}
   int32_t extra_slots = 0;         // accumulator slots beyond Hs + 4
@@ -77,7 +76,6 @@ struct ScheduleHost {
 struct ScheduleDev {
   const ArcRec *cells;
   const int2 *wave_range;
-  const uint32_t *row_masks;
   const int32_t *fix_begin;
   const int2 *fix;
 };

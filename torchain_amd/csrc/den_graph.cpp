@@ -360,11 +360,7 @@ static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
   }
   for (int i = 0; i < 64 * unroll; ++i) out->cells.push_back(ArcRec{0.f, 0u});
-  // ROW positions as one mask word per unroll cells (+1 word so the prefetch needs no guard)
   const size_t ncell = out->cells.size() / 64;
-  out->row_masks.assign(ncell / unroll + 2, 0u);
-  for (size_t c = 0; c < ncell; ++c)
-    if (out->cells[c * 64].idx & kRowFlag) out->row_masks[c / unroll] |= 1u << (c % unroll);
   // final memory layout: a lane's cells 2p and 2p+1 adjacent (16 bytes), i.e. [pair][lane][2], so the
   // kernel streams with 16-byte loads (1 KB per wave instruction)
   {
@@ -700,8 +696,6 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
       {g->fwd.fix.data(), g->fwd.fix.size() * sizeof(int2), 0},
       {g->bwd.fix_begin.data(), g->bwd.fix_begin.size() * 4, 0},
       {g->bwd.fix.data(), g->bwd.fix.size() * sizeof(int2), 0},
-      {g->fwd.row_masks.data(), g->fwd.row_masks.size() * 4, 0},
-      {g->bwd.row_masks.data(), g->bwd.row_masks.size() * 4, 0},
       {g->tied_fs.data(), g->tied_fs.size() * 4, 0},
       {g->tied_w.data(), g->tied_w.size() * 4, 0},
   };
@@ -726,15 +720,15 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   DenGraphDev d;
   d.blob = blob;
   d.fwd = ScheduleDev{(const ArcRec *)(blob + parts[0].off), (const int2 *)(blob + parts[1].off),
-                      (const uint32_t *)(blob + parts[9].off), (const int32_t *)(blob + parts[5].off),
+                      (const int32_t *)(blob + parts[5].off),
                       (const int2 *)(blob + parts[6].off)};
   d.bwd = ScheduleDev{(const ArcRec *)(blob + parts[2].off), (const int2 *)(blob + parts[3].off),
-                      (const uint32_t *)(blob + parts[10].off), (const int32_t *)(blob + parts[7].off),
+                      (const int32_t *)(blob + parts[7].off),
                       (const int2 *)(blob + parts[8].off)};
   d.pi = (const float *)(blob + parts[4].off);
   if (g->tied) {
-    d.tied_fs = (const uint32_t *)(blob + parts[11].off);
-    d.tied_w = (const float *)(blob + parts[12].off);
+    d.tied_fs = (const uint32_t *)(blob + parts[9].off);
+    d.tied_w = (const float *)(blob + parts[10].off);
   }
   g->dev[device] = d;
   return TC_OK;

@@ -130,7 +130,7 @@ __device__ __forceinline__ void gamma_add(float *GM, uint32_t byte_off, float v)
 }
 
 template <bool BWD, bool ALPHA_LDS, bool TIED>
-__device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t mask, RowState &rs,
+__device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState &rs,
                                               const float *__restrict__ SRC, const float *__restrict__ PB,
                                               float *__restrict__ ACC, float *__restrict__ GM,
                                               const float *__restrict__ AL, const float *__restrict__ hist_t,
@@ -144,7 +144,9 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], uint32_t
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
     float w = __uint_as_float(q[u].x);
-    if (__builtin_expect((mask >> u) & 1u, 0)) {  // ROW cell: rare, scalar branch around this block only
+    // the ROW flag is in-band (bit 0 of the offset word, identical in all 64 lanes): testing the cell
+    // itself avoids a separate mask stream and its dependent L2 load in every loop iteration
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(q[u].y) & 1u, 0)) {  // rare, scalar branch
       ACC[rs.row] = rs.acc;  // every row owns its slot: plain store, no atomic
       rs.acc = 0.f;
       rs.row = q[u].x & 0xffffu;  // ROW cell x = slot | state << 16
@@ -182,7 +184,6 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
   const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnroll
   // cells are stored [pair][lane][2]: one 16-byte load brings a lane's cells 2p and 2p+1
   const uint4 *__restrict__ r = reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / 2) * 64 + lane;
-  const uint32_t *__restrict__ mk = sc.row_masks + first / kStreamUnroll;
   uint2 qa[kChunk], qb[kChunk];
   auto load_chunk = [&](uint2 (&q)[kChunk], int cell0) {
 #pragma unroll
@@ -192,15 +193,12 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
       q[2 * u + 1] = make_uint2(v.z, v.w);
     }
   };
-  uint32_t m_raw = mk[0];
   load_chunk(qa, 0);
-  uint32_t m = __builtin_amdgcn_readfirstlane(m_raw);
   RowState rs;
   rs.row = (uint32_t)dummy_row;  // until the stream's first ROW cell
   rs.acc = 0.f;
   rs.occf = 0.f;
   for (int c = 0; c < ncells; c += kStreamUnroll) {
-    m_raw = mk[c / kStreamUnroll + 1];  // oldest load of this iteration; consumed at the bottom
     // Self-balancing: a wave's issue priority falls as it advances through its stream, so the waves
     // that lag (the arbiter otherwise favours the oldest) outrank the leaders and all 16 reach the
     // barrier together instead of leaving a tail with few active waves.
@@ -214,10 +212,9 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
       __builtin_amdgcn_s_setprio(0);
     // the stream is followed by kStreamUnroll readable padding cells, so these loads need no guard
     load_chunk(qb, c + kChunk);
-    process_chunk<BWD, ALPHA_LDS, TIED>(qa, m & 0xffu, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    process_chunk<BWD, ALPHA_LDS, TIED>(qa, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
     load_chunk(qa, c + kStreamUnroll);
-    process_chunk<BWD, ALPHA_LDS, TIED>(qb, m >> 8, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
-    m = __builtin_amdgcn_readfirstlane(m_raw);
+    process_chunk<BWD, ALPHA_LDS, TIED>(qb, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
   }
   __builtin_amdgcn_s_setprio(0);
 }
