@@ -26,8 +26,10 @@ struct Workspace {
   size_t total;
 };
 
-Workspace carve(char *base, int H, int S, int T) {
-  const int Hs = (H + 3) & ~3;
+// Hs: stored states per frame of the alpha history (layout positions for tied graphs: build_owner)
+int hist_states(const tc_den_graph *g) { return g->tied ? g->layout.Hs : ((g->H + 3) & ~3); }
+
+Workspace carve(char *base, int Hs, int S, int T) {
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -78,7 +80,9 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
     d = g->dev[device];
   }
   bool tied = g->tied;
-  if (!compute_layout(g->H, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
+  // tied graphs address states by layout position (a multiple of 4096 of them, phantoms included)
+  const int nstates = tied ? g->layout.Hs : g->H;
+  if (!compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
     if (tied) return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit
     return TC_ERR_UNSUPPORTED;
   }
@@ -98,7 +102,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->seq_gsum = w.gs;
   p->S = S;
   p->T = T;
-  p->H = g->H;
+  p->H = nstates;
   p->P = g->P;
   p->leaky = leaky;
   p->deriv_weight = deriv_weight;
@@ -144,7 +148,7 @@ extern "C" {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, g->H, S, T).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -153,7 +157,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, g->H, S, T);
+  Workspace w = carve((char *)workspace, hist_states(g), S, T);
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -196,7 +200,7 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, g->H, sup->S, sup->T);
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T);
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;

@@ -71,6 +71,11 @@ struct ScheduleHost {
   int64_t conflict_cost = 0, conflict_free_cost = 0;  // LDS cycles of the arc gathers: as placed / if conflict-free
   int64_t real_arcs = 0, padded_arcs = 0;
   int32_t rows = 0;
+  // owner-computes schedules of tied graphs (den_graph.cpp: build_owner)
+  std::vector<uint32_t> masks;        // [wave][mask_stride]: bit i of word j <=> a row ends after pair 8 j + i
+  int32_t mask_stride = 0;
+  std::vector<int32_t> extra_first;   // per wave: index of its first secondary-row slot group
+  int32_t nfix = 0;                   // number of fix-up entries (0: no barrier after the walk)
 };
 
 struct ScheduleDev {
@@ -78,6 +83,9 @@ struct ScheduleDev {
   const int2 *wave_range;
   const int32_t *fix_begin;
   const int2 *fix;
+  const uint32_t *masks = nullptr;      // owner-computes schedules only
+  const int32_t *extra_first = nullptr;
+  int32_t mask_stride = 0, nfix = 0;
 };
 
 struct DenGraphDev {
@@ -136,8 +144,10 @@ struct tc_den_graph {
   // non-self-loop arcs, the forward walk gathers alpha' alone, the backward walk gathers
   // Y(g) = beta(g) * p(f(g)) alone, and the self-loops are applied per state by the owning thread.
   bool tied = false;
-  std::vector<uint32_t> tied_fs;
+  std::vector<uint32_t> tied_fs;      // position order once build_owner has run
   std::vector<float> tied_w;
+  std::vector<int32_t> pos;           // tied graphs: state -> LDS position (see build_owner)
+  std::vector<float> pi_pos;          // initial probs in position order
   tc::DenLayout layout;
   bool layout_ok = false;
   std::mutex mu;

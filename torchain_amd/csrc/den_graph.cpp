@@ -75,7 +75,8 @@ static int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int 
                         const int32_t *pdf, std::vector<std::vector<int>> *pos_out) {
   const int L = (int)lane_arcs.size();
   auto bst = [&](int64_t a) { return other[a] & 31; };
-  auto bpd = [&](int64_t a) { return pdf[a] & 31; };
+  auto bpd = [&](int64_t a) { return pdf ? (pdf[a] & 31) : 0; };
+  const int use_pdf = pdf ? 1 : 0;
   std::vector<std::vector<int>> pos(L, std::vector<int>(steps, -1));
   std::vector<std::vector<char>> used(L);
   std::vector<int> remaining(L);
@@ -98,7 +99,7 @@ static int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int 
       for (int i = 0; i < (int)lane_arcs[l].size(); ++i) {
         if (used[l][i]) continue;
         const int64_t a = lane_arcs[l][i];
-        const int c = cs[k][bst(a)] + cp[k][bpd(a)];
+        const int c = cs[k][bst(a)] + use_pdf * cp[k][bpd(a)];
         if (c < best_cost) {
           best_cost = c;
           best = i;
@@ -134,7 +135,7 @@ static int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int 
               if (bpd(o) == bpd(a)) p_to--;
             }
             delta += s_to - (cs[from][bst(a)] - 1);
-            delta += p_to - (cp[from][bpd(a)] - 1);
+            if (use_pdf) delta += p_to - (cp[from][bpd(a)] - 1);
           };
           delta_move(i1, k1, k2, i2);
           delta_move(i2, k2, k1, i1);
@@ -162,7 +163,7 @@ static int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int 
       ms = std::max(ms, cs[k][b]);
       mp = std::max(mp, cp[k][b]);
     }
-    total += std::max(ms, 1) + std::max(mp, 1);
+    total += std::max(ms, 1) + use_pdf * std::max(mp, 1);
     if (getenv("TC_SCHED_DEBUG")) {
       static long long n = 0, sst = 0, spd = 0;
       n++; sst += std::max(ms, 1); spd += std::max(mp, 1);
@@ -374,6 +375,273 @@ static void build_one(int H, int Hs, int num_pdfs, int64_t A, const int32_t *key
   out->rows = nrows;
 }
 
+// ---- tied graphs: "owner-computes" schedules -------------------------------------------------------
+// The thread that owns a state (float4 ownership: LDS position p belongs to thread (p / 4) % 1024, its
+// row index k = 4 * (p / 4096) + p % 4) also walks that state's arc list, in both directions, so a row
+// sum never leaves its thread: no accumulator exchange through LDS, no barrier between the walk and the
+// per-state pass, no ROW cells in the stream.  The 64 lanes of a wave run their k-th rows in lockstep
+// (a (wave, k) "slot" costs the longest of its 64 rows), so states are PERMUTED: sorted by primary
+// in- and out-degree and dealt 64 at a time, which makes the rows of a slot (nearly) equally long in
+// both directions.  Everything per-state the kernel touches (pi, tied tables, alpha history) is stored
+// in position order; positions never leave the library.  Row ends are wave-uniform and known in
+// advance: one mask bit per pair of cells, eight pairs per mask word, read through the scalar cache.
+// Arc lists longer than kMaxRowLen keep their first kMaxRowLen arcs at home; the rest become secondary
+// rows (k >= K) of whichever waves have room, commit to private slots behind the accumulators and are
+// folded in by the owner after a barrier that only such graphs pay.
+struct OwnerTask {
+  int32_t state;   // original state id (or -1: empty)
+  int64_t begin;   // range into the direction's arc order
+  int32_t len;
+};
+
+static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std::vector<OwnerTask>>> &slots,
+                              const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
+                              ScheduleHost *out) {
+  // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows
+  out->conflict_cost = out->conflict_free_cost = 0;
+  out->cells.clear();
+  out->wave_range.assign(kWaves, make_int2(0, 0));
+  std::vector<std::vector<uint32_t>> wave_masks(kWaves);
+  int64_t arc_cells = 0;
+  int nrows = 0;
+  for (int w = 0; w < kWaves; ++w) {
+    const size_t first = out->cells.size() / 64;
+    size_t pairs_before = 0;
+    std::vector<char> row_end;  // per pair of this wave
+    for (size_t k = 0; k < slots[w].size(); ++k) {
+      const auto &tasks = slots[w][k];
+      int steps = 2;
+      for (const OwnerTask &t : tasks) steps = std::max(steps, (t.len + 1) & ~1);
+      const size_t off = out->cells.size();
+      out->cells.resize(off + (size_t)steps * 64, ArcRec{0.f, 0u});
+      arc_cells += (int64_t)steps * 64;
+      for (int half = 0; half < 2; ++half) {
+        std::vector<std::vector<int64_t>> lane_arcs(32);
+        for (int l = 0; l < 32; ++l) {
+          const OwnerTask &t = tasks[half * 32 + l];
+          for (int i = 0; i < t.len; ++i) lane_arcs[l].push_back(order[t.begin + i]);
+          if (t.len > 0) ++nrows;
+        }
+        std::vector<std::vector<int>> pos;
+        out->conflict_cost += arrange_half(lane_arcs, steps, opos, nullptr, &pos);
+        out->conflict_free_cost += steps;
+        for (int l = 0; l < 32; ++l) {
+          const int lane = half * 32 + l;
+          for (int i = 0; i < steps; ++i) {
+            ArcRec &cell = out->cells[off + (size_t)i * 64 + lane];
+            if (pos[l][i] >= 0) {
+              const int64_t a = lane_arcs[l][pos[l][i]];
+              cell = ArcRec{prob[a], (uint32_t)opos[a] << 18};
+            } else {
+              cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? l : 0) << 18};  // padding: w = 0, conflict-free offset
+            }
+          }
+        }
+      }
+      pairs_before += steps / 2;
+      row_end.resize(pairs_before, 0);
+      row_end[pairs_before - 1] = 1;
+    }
+    while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0)
+      for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
+    out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
+    auto &mw = wave_masks[w];
+    mw.assign((row_end.size() + 7) / 8, 0u);
+    for (size_t i = 0; i < row_end.size(); ++i)
+      if (row_end[i]) mw[i / 8] |= 1u << (i % 8);
+  }
+  // readable padding: the kernels request up to four chunks past a wave's range
+  for (int i = 0; i < 64 * 32; ++i) out->cells.push_back(ArcRec{0.f, 0u});
+  size_t stride = 1;
+  for (auto &mw : wave_masks) stride = std::max(stride, mw.size());
+  stride += 2;  // the walk prefetches one word ahead
+  out->mask_stride = (int32_t)stride;
+  out->masks.assign(stride * kWaves, 0u);
+  for (int w = 0; w < kWaves; ++w) std::copy(wave_masks[w].begin(), wave_masks[w].end(), out->masks.begin() + w * stride);
+  out->real_arcs = (int64_t)order.size();
+  out->padded_arcs = arc_cells;
+  out->rows = nrows;
+  // 6-byte cells, [chunk of 8 cells][3 blocks][lane]{16 bytes}: {w0..w3}, {w4..w7}, {off01, off23, off45, off67}
+  const size_t ncell = out->cells.size() / 64;
+  out->cells6.assign(ncell / 8 * 3 * 64 * 4, 0u);
+  for (size_t c = 0; c < ncell; ++c)
+    for (int l = 0; l < 64; ++l) {
+      const ArcRec &cell = out->cells[c * 64 + l];
+      uint32_t x;
+      memcpy(&x, &cell.w, 4);
+      const size_t chunk = c / 8, i = c % 8;
+      uint32_t *base = &out->cells6[chunk * 3 * 64 * 4];
+      base[((i / 4) * 64 + l) * 4 + (i % 4)] = x;
+      uint32_t &o = base[(2 * 64 + l) * 4 + i / 2];
+      const uint32_t off16 = cell.idx >> 16;  // position * 4
+      o |= (i & 1) ? off16 << 16 : off16;
+    }
+  out->cells.clear();
+  out->cells.shrink_to_fit();
+}
+
+// Returns false when the graph cannot use the owner-computes kernel (too many states for the 16-bit
+// offsets or the working set does not fit LDS); the caller then falls back to the general kernel.
+static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
+  const int H = g->H;
+  const int Npos = 4096 * ((H + 4095) / 4096);
+  if (Npos > kMaxIndex) return false;
+  const int K = Npos / kThreads;
+  std::vector<int32_t> src, dst;
+  std::vector<float> prob;
+  for (int64_t a = 0; a < g->A; ++a)
+    if (!special[a]) {
+      src.push_back(g->arc_src[a]);
+      dst.push_back(g->arc_dst[a]);
+      prob.push_back(g->arc_prob[a]);
+    }
+  const int64_t A2 = (int64_t)src.size();
+  auto sort_by = [&](const std::vector<int32_t> &key, std::vector<int64_t> *first, std::vector<int64_t> *order) {
+    first->assign(H + 1, 0);
+    for (int64_t a = 0; a < A2; ++a) (*first)[key[a] + 1]++;
+    for (int h = 0; h < H; ++h) (*first)[h + 1] += (*first)[h];
+    order->resize(A2);
+    std::vector<int64_t> fill(first->begin(), first->end() - 1);
+    for (int64_t a = 0; a < A2; ++a) (*order)[fill[key[a]]++] = a;
+  };
+  std::vector<int64_t> in_first, in_order, out_first, out_order;
+  sort_by(dst, &in_first, &in_order);
+  sort_by(src, &out_first, &out_order);
+  auto deg = [](const std::vector<int64_t> &first, int h) { return (int)(first[h + 1] - first[h]); };
+
+  // ---- the permutation: sort by primary in-length into a few super-buckets, inside by primary out-length
+  std::vector<int32_t> st(H);
+  std::iota(st.begin(), st.end(), 0);
+  auto lin = [&](int h) { return std::min(deg(in_first, h), kMaxRowLen); };
+  auto lout = [&](int h) { return std::min(deg(out_first, h), kMaxRowLen); };
+  std::stable_sort(st.begin(), st.end(), [&](int x, int y) { return lin(x) > lin(y); });
+  const int ngroups = Npos / 64;
+  const int nbucket = std::max(1, (int)std::lround(std::sqrt((double)std::max(1, (H + 63) / 64))));
+  for (int b = 0; b < nbucket; ++b) {
+    const size_t lo = (size_t)H * b / nbucket, hi = (size_t)H * (b + 1) / nbucket;
+    std::stable_sort(st.begin() + lo, st.begin() + hi, [&](int x, int y) { return lout(x) > lout(y); });
+  }
+  st.resize(Npos, -1);  // phantom states: no arcs, pi = 0
+  struct Group { int idx, cin, cout; };
+  std::vector<Group> groups(ngroups);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    int mi = 2, mo = 2;
+    for (int l = 0; l < 64; ++l) {
+      const int h = st[(size_t)gi * 64 + l];
+      if (h < 0) continue;
+      mi = std::max(mi, (lin(h) + 1) & ~1);
+      mo = std::max(mo, (lout(h) + 1) & ~1);
+    }
+    groups[gi] = Group{gi, mi, mo};
+  }
+  // longest-processing-time deal of the groups to the waves, K per wave, balancing both directions
+  std::vector<Group> by_cost(groups);
+  std::stable_sort(by_cost.begin(), by_cost.end(), [](const Group &x, const Group &y) { return x.cin + x.cout > y.cin + y.cout; });
+  std::vector<std::vector<int>> wave_groups(kWaves);
+  std::vector<int64_t> load_in(kWaves, 0), load_out(kWaves, 0);
+  for (const Group &gr : by_cost) {
+    int best = -1;
+    for (int w = 0; w < kWaves; ++w) {
+      if ((int)wave_groups[w].size() >= K) continue;
+      if (best < 0 || std::max(load_in[w] + gr.cin, load_out[w] + gr.cout) < std::max(load_in[best] + gr.cin, load_out[best] + gr.cout)) best = w;
+    }
+    wave_groups[best].push_back(gr.idx);
+    load_in[best] += gr.cin;
+    load_out[best] += gr.cout;
+  }
+  g->pos.assign(H, 0);
+  std::vector<int32_t> state_at(Npos, -1);
+  for (int w = 0; w < kWaves; ++w)
+    for (int k = 0; k < K; ++k)
+      for (int l = 0; l < 64; ++l) {
+        const int h = st[(size_t)wave_groups[w][k] * 64 + l];
+        const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
+        state_at[p] = h;
+        if (h >= 0) g->pos[h] = p;
+      }
+
+  // ---- per direction: primary rows at home, secondary rows dealt to the least-loaded waves
+  int extra_total[2] = {0, 0};
+  for (int dir = 0; dir < 2; ++dir) {
+    const std::vector<int64_t> &first = dir == 0 ? in_first : out_first, &order = dir == 0 ? in_order : out_order;
+    const std::vector<int32_t> &other = dir == 0 ? src : dst;
+    ScheduleHost *out = dir == 0 ? &g->fwd : &g->bwd;
+    std::vector<int32_t> opos(A2);
+    for (int64_t a = 0; a < A2; ++a) opos[a] = g->pos[other[a]];
+    std::vector<std::vector<std::vector<OwnerTask>>> slots(kWaves, std::vector<std::vector<OwnerTask>>(K, std::vector<OwnerTask>(64)));
+    std::vector<OwnerTask> secondary;
+    std::vector<int64_t> load(kWaves, 0);
+    for (int w = 0; w < kWaves; ++w)
+      for (int k = 0; k < K; ++k) {
+        int steps = 2;
+        for (int l = 0; l < 64; ++l) {
+          const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
+          const int h = state_at[p];
+          OwnerTask t{h, 0, 0};
+          if (h >= 0) {
+            const int d = deg(first, h);
+            t.begin = first[h];
+            t.len = std::min(d, kMaxRowLen);
+            for (int done = t.len; done < d; done += kMaxRowLen)
+              secondary.push_back(OwnerTask{h, first[h] + done, std::min(kMaxRowLen, d - done)});
+          }
+          slots[w][k][l] = t;
+          steps = std::max(steps, (t.len + 1) & ~1);
+        }
+        load[w] += steps;
+      }
+    std::stable_sort(secondary.begin(), secondary.end(), [](const OwnerTask &x, const OwnerTask &y) { return x.len > y.len; });
+    std::vector<std::vector<int2>> fix_of_thread(kThreads);
+    std::vector<int> extra_first(kWaves + 1, 0);
+    std::vector<std::vector<std::vector<OwnerTask>>> sec_slots(kWaves);
+    for (size_t b = 0; b < secondary.size(); b += 64) {
+      const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+      std::vector<OwnerTask> tasks(64, OwnerTask{-1, 0, 0});
+      for (size_t i = b; i < std::min(secondary.size(), b + 64); ++i) tasks[i - b] = secondary[i];
+      load[w] += (secondary[b].len + 1) & ~1;
+      sec_slots[w].push_back(tasks);
+    }
+    // private slots: wave w's j-th secondary row, lane l -> accumulator index Npos + 4 + 64 * (extra_first[w] + j) + l
+    for (int w = 0; w < kWaves; ++w) extra_first[w + 1] = extra_first[w] + (int)sec_slots[w].size();
+    for (int w = 0; w < kWaves; ++w)
+      for (size_t j = 0; j < sec_slots[w].size(); ++j) {
+        for (int l = 0; l < 64; ++l) {
+          const OwnerTask &t = sec_slots[w][j][l];
+          if (t.state < 0) continue;
+          const int p = g->pos[t.state];
+          fix_of_thread[(p >> 2) % kThreads].push_back(make_int2(p, Npos + 4 + 64 * (extra_first[w] + (int)j) + l));
+        }
+        slots[w].push_back(sec_slots[w][j]);
+      }
+    out->extra_first.assign(extra_first.begin(), extra_first.end() - 1);
+    out->extra_slots = 64 * extra_first[kWaves];
+    extra_total[dir] = out->extra_slots;
+    out->fix.clear();
+    out->fix_begin.assign(kThreads + 1, 0);
+    for (int t = 0; t < kThreads; ++t) {
+      out->fix_begin[t] = (int)out->fix.size();
+      for (auto &f : fix_of_thread[t]) out->fix.push_back(f);
+    }
+    out->fix_begin[kThreads] = (int)out->fix.size();
+    out->nfix = (int32_t)out->fix.size();
+    if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
+    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out);
+  }
+  if (!compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), true, &g->layout)) return false;
+  // per-state tables in position order
+  std::vector<uint32_t> fs(Npos + 4, 0u);
+  std::vector<float> ws(Npos + 4, 0.f);
+  g->pi_pos.assign(Npos + 4, 0.f);
+  for (int h = 0; h < H; ++h) {
+    fs[g->pos[h]] = g->tied_fs[h];
+    ws[g->pos[h]] = g->tied_w[h];
+    g->pi_pos[g->pos[h]] = g->initial_probs[h];
+  }
+  g->tied_fs.swap(fs);
+  g->tied_w.swap(ws);
+  return true;
+}
+
 int build_schedules(tc_den_graph *g) {
   const int Hs = round4(g->H);
   // ---- is the graph tied?  (see tc_den_graph::tied)
@@ -417,57 +685,13 @@ int build_schedules(tc_den_graph *g) {
       }
   }
   if (g->tied) {
-    // schedules over everything but the special self-loops
-    std::vector<int32_t> src, dst, pdf;
-    std::vector<float> prob;
-    for (int64_t a = 0; a < g->A; ++a)
-      if (!special[a]) {
-        src.push_back(g->arc_src[a]);
-        dst.push_back(g->arc_dst[a]);
-        pdf.push_back(g->arc_pdf[a]);
-        prob.push_back(g->arc_prob[a]);
-      }
-    const int64_t A2 = (int64_t)src.size();
-    build_one(g->H, Hs, g->P, A2, dst.data(), src.data(), pdf.data(), prob.data(), kStreamUnrollTied, true, &g->fwd);
-    build_one(g->H, Hs, g->P, A2, src.data(), dst.data(), pdf.data(), prob.data(), kStreamUnrollTied, true, &g->bwd);
-    g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), true, &g->layout);
-    // Tied walks use neither the pdf offset nor (in the ROW cell) the state, so a cell shrinks to a
-    // 32-bit weight plus a 16-bit LDS byte offset (gather offset for an arc, accumulator offset for a
-    // ROW cell): 12 bytes per pair of cells, exact fp32 weights, 25 % less to stream.
-    if (g->layout_ok && g->layout.acc_floats * 4 <= 65536) {
-      for (ScheduleHost *sc : {&g->fwd, &g->bwd}) {
-        const size_t npair = sc->cells.size() / 128;
-        sc->cells6.assign(npair * 64 * 3, 0u);
-        for (size_t pr = 0; pr < npair; ++pr)
-          for (int l = 0; l < 64; ++l) {
-            uint32_t w[2], off[2];
-            for (int k = 0; k < 2; ++k) {
-              const ArcRec &c = sc->cells[(pr * 64 + l) * 2 + k];
-              uint32_t x;
-              memcpy(&x, &c.w, 4);
-              if (c.idx & kRowFlag) {
-                w[k] = 0u;                     // 0.0f: the unconditional FMA adds nothing
-                off[k] = (x & 0xffffu) * 4u;   // accumulator slot -> byte offset
-                off[k] |= kRowFlag;            // in-band ROW flag (ROW cells sit at even positions: k == 0)
-              } else {
-                w[k] = x;
-                off[k] = c.idx >> 16;          // state * 4
-              }
-            }
-            // memory layout: a chunk of 8 cells (4 pairs) of one lane is three 16-byte blocks
-            // {w0..w3}, {w4..w7}, {off01, off23, off45, off67}, stored [chunk][block][lane], so the walk
-            // issues three coalesced 16-byte loads (1 KB per wave instruction) per chunk
-            const size_t chunk = pr / 4, k = pr % 4;
-            uint32_t *base = &sc->cells6[chunk * 3 * 64 * 4];
-            base[((k / 2) * 64 + l) * 4 + (k % 2) * 2 + 0] = w[0];
-            base[((k / 2) * 64 + l) * 4 + (k % 2) * 2 + 1] = w[1];
-            base[(2 * 64 + l) * 4 + k] = off[0] | (off[1] << 16);
-          }
-      }
+    if (build_owner(g, special)) {
+      g->layout_ok = true;
       return TC_OK;
     }
-    if (g->layout_ok) return TC_OK;
-    g->tied = false;  // the second exp(y) buffer does not fit: use the general kernel
+    g->tied = false;  // does not fit the owner-computes layout: use the general kernel
+    g->fwd = ScheduleHost();
+    g->bwd = ScheduleHost();
   }
   // forward: alpha_{t+1}(dst) sums over in-arcs, gathers alpha'_t(src)
   build_one(g->H, Hs, g->P, g->A, g->arc_dst.data(), g->arc_src.data(), g->arc_pdf.data(), g->arc_prob.data(), kStreamUnroll, false, &g->fwd);
@@ -684,6 +908,9 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   struct Part { const void *src; size_t bytes; size_t off; };
   std::vector<float> pi_pad(Hs + 4, 0.f);
   std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
+  if (g->tied) pi_pad = g->pi_pos;  // position order (build_owner)
+  const std::vector<uint32_t> no_mask(1, 0u);
+  const std::vector<int32_t> no_extra(kWaves, 0);
   Part parts[] = {
       {g->fwd.cells6.empty() ? (const void *)g->fwd.cells.data() : (const void *)g->fwd.cells6.data(),
        g->fwd.cells6.empty() ? g->fwd.cells.size() * sizeof(ArcRec) : g->fwd.cells6.size() * 4, 0},
@@ -698,6 +925,10 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
       {g->bwd.fix.data(), g->bwd.fix.size() * sizeof(int2), 0},
       {g->tied_fs.data(), g->tied_fs.size() * 4, 0},
       {g->tied_w.data(), g->tied_w.size() * 4, 0},
+      {g->fwd.masks.empty() ? no_mask.data() : g->fwd.masks.data(), std::max<size_t>(1, g->fwd.masks.size()) * 4, 0},
+      {g->bwd.masks.empty() ? no_mask.data() : g->bwd.masks.data(), std::max<size_t>(1, g->bwd.masks.size()) * 4, 0},
+      {g->fwd.extra_first.empty() ? no_extra.data() : g->fwd.extra_first.data(), kWaves * 4, 0},
+      {g->bwd.extra_first.empty() ? no_extra.data() : g->bwd.extra_first.data(), kWaves * 4, 0},
   };
   size_t total = 0;
   for (auto &p : parts) {
@@ -720,11 +951,13 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   DenGraphDev d;
   d.blob = blob;
   d.fwd = ScheduleDev{(const ArcRec *)(blob + parts[0].off), (const int2 *)(blob + parts[1].off),
-                      (const int32_t *)(blob + parts[5].off),
-                      (const int2 *)(blob + parts[6].off)};
+                      (const int32_t *)(blob + parts[5].off), (const int2 *)(blob + parts[6].off),
+                      (const uint32_t *)(blob + parts[11].off), (const int32_t *)(blob + parts[13].off),
+                      g->fwd.mask_stride, g->fwd.nfix};
   d.bwd = ScheduleDev{(const ArcRec *)(blob + parts[2].off), (const int2 *)(blob + parts[3].off),
-                      (const int32_t *)(blob + parts[7].off),
-                      (const int2 *)(blob + parts[8].off)};
+                      (const int32_t *)(blob + parts[7].off), (const int2 *)(blob + parts[8].off),
+                      (const uint32_t *)(blob + parts[12].off), (const int32_t *)(blob + parts[14].off),
+                      g->bwd.mask_stride, g->bwd.nfix};
   d.pi = (const float *)(blob + parts[4].off);
   if (g->tied) {
     d.tied_fs = (const uint32_t *)(blob + parts[9].off);

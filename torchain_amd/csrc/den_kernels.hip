@@ -219,10 +219,12 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
   __builtin_amdgcn_s_setprio(0);
 }
 
-// ---- tied graphs: 6-byte cells --------------------------------------------------------------
-// A pair of cells is {w0, w1, off0 | off1 << 16}: fp32 weights and 16-bit LDS byte offsets (gather
-// offset of an arc; accumulator offset of a ROW cell, whose weight is 0).  Both tied walks are the same
-// operation -- acc(row) += w * SRC[off] -- with SRC = alpha'_t (forward) or Y_t (backward).
+// ---- tied graphs: owner-computes walk over 6-byte cells ---------------------------------------------
+// A pair of cells is {w0, w1, off0 | off1 << 16}: fp32 weights and 16-bit LDS byte offsets of the two
+// gathers.  Both tied walks are the same operation -- acc(row) += w * SRC[off] -- with SRC = alpha'_t
+// (forward) or Y_t (backward), and the row a lane is summing is always one of its OWN states (or a
+// secondary row, see den_graph.cpp build_owner): the sum is committed to the thread's own accumulator
+// slot and read back by the same thread, so no barrier separates the walk from the per-state pass.
 struct Pair6 {
   uint32_t w0, w1, off;
 };
@@ -235,62 +237,97 @@ __device__ __forceinline__ void lds_abs_store(uint32_t byte_addr, float v) {
   *reinterpret_cast<lds_float *>(byte_addr) = v;
 }
 
-// SRC_BASE / acc_base are absolute LDS byte addresses of the gather source and of the accumulators.
-// Cells are consumed a PAIR at a time: (w0, w1) are adjacent in the stream and the two gathered values
-// land in adjacent registers, so one packed FMA (v_pk_fma_f32) serves both cells, and because the
-// schedule puts ROW cells at even positions only, one scalar test serves both as well.  A ROW cell's
-// own weight is 0, so the packed FMA needs no special case for it.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Where the row a wave is currently summing commits: all 64 lanes are at the same row index k.
+struct RowCursor {
+  uint32_t base;   // per lane: own accumulator slot 0 (k < K), then the wave's first secondary slot
+  uint32_t koff;   // uniform: byte offset of row k from `base`
+  int k;           // uniform
+  uint32_t fix_base;
+  int K;
+  __device__ __forceinline__ void advance() {
+    ++k;
+    if (k < K) {  // own rows: k -> 4 * (tid + 1024 * (k >> 2)) + (k & 3)
+      koff += 4u;
+      if ((koff & 12u) == 0u) koff += 4u * 4u * kThreads - 16u;
+    } else if (k == K) {
+      base = fix_base;
+      koff = 0u;
+    } else {
+      koff += 256u;  // secondary rows: 64 consecutive private slots per row
+    }
+  }
+};
+
+// One chunk = 4 pairs.  `m` bit u <=> the row ends after pair u (wave-uniform, from the schedule's mask
+// words through the scalar cache), so the commit sits behind a scalar branch and the common path is two
+// gathers and one packed FMA (v_pk_fma_f32) per pair.
 template <uint32_t SRC_BASE>
-__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t &row_off, v2f &acc,
-                                               uint32_t acc_base) {
+__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t m, RowCursor &rc, v2f &acc) {
   v2f a[kChunk / 2];
 #pragma unroll
   for (int u = 0; u < kChunk / 2; ++u) {
-    a[u].x = lds_abs(SRC_BASE + (q[u].off & 0xfffcu));
+#ifdef TC_ABL_NOGATHER
+    a[u].x = __uint_as_float(q[u].off & 0xffffu);
+    a[u].y = __uint_as_float(q[u].off >> 16);
+#else
+    a[u].x = lds_abs(SRC_BASE + (q[u].off & 0xffffu));
     a[u].y = lds_abs(SRC_BASE + (q[u].off >> 16));
+#endif
   }
 #pragma unroll
   for (int u = 0; u < kChunk / 2; ++u) {
-    // the ROW flag travels in-band (bit 0 of the even cell's offset) and is the same in all 64 lanes,
-    // so no separate mask stream -- and no extra dependent L2 load per loop iteration -- is needed
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane(q[u].off) & 1u, 0)) {
-      lds_abs_store(acc_base + row_off, acc.x + acc.y);  // commit the finished row
-      const uint32_t off = q[u].off & 0xfffcu;
-      // in-place updates (no phi copies on the common path)
-      asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "+v"(acc.x), "+v"(acc.y));
-      asm volatile("v_mov_b32 %0, %1" : "+v"(row_off) : "v"(off));
-    }
     v2f w;
     w.x = __uint_as_float(q[u].w0);
     w.y = __uint_as_float(q[u].w1);
     acc = __builtin_elementwise_fma(a[u], w, acc);
+    if (__builtin_expect((m >> u) & 1u, 0)) {
+      lds_abs_store(rc.base + rc.koff, acc.x + acc.y);  // commit the finished row
+      acc.x = 0.f;
+      acc.y = 0.f;
+      rc.advance();
+    }
   }
 }
 
-// Two register buffers in ping-pong, as in walk_rows.
-template <uint32_t SRC_BASE>
-__device__ __forceinline__ void walk_rows6(const ScheduleDev &sc, int wave, int lane, int dummy_row,
-                                           uint32_t acc_base) {
+// A wave's share of a frame is only a handful of chunks, so the L2 round trip of the first one is a
+// visible fraction of the walk: the kernel issues it BEFORE the frame's barrier (the stream is the same
+// every frame) and the wait overlaps the latency.
+__device__ __forceinline__ const uint4 *walk6_base(const ScheduleDev &sc, int wave, int lane, int &ncells) {
   const int2 range = sc.wave_range[wave];
-  const int first = __builtin_amdgcn_readfirstlane(range.x);   // multiple of kStreamUnrollTied
-  const int ncells = __builtin_amdgcn_readfirstlane(range.y);  // multiple of kStreamUnrollTied
+  const int first = __builtin_amdgcn_readfirstlane(range.x);  // multiple of kChunk
+  ncells = __builtin_amdgcn_readfirstlane(range.y);           // multiple of kChunk
   // the stream is stored [chunk of 8 cells][3 blocks][lane]{16 bytes}: see den_graph.cpp
-  const uint4 *__restrict__ r = reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / kChunk) * 3 * 64 + lane;
-  Pair6 qa[kChunk / 2], qb[kChunk / 2];
-  auto load_chunk = [&](Pair6 (&q)[kChunk / 2], int cell0) {
-    const uint4 *rc = r + (int64_t)(cell0 / kChunk) * 3 * 64;
-    const uint4 wa = rc[0], wb = rc[64], oc = rc[128];
-    q[0] = Pair6{wa.x, wa.y, oc.x};
-    q[1] = Pair6{wa.z, wa.w, oc.y};
-    q[2] = Pair6{wb.x, wb.y, oc.z};
-    q[3] = Pair6{wb.z, wb.w, oc.w};
-  };
-  load_chunk(qa, 0);
-  uint32_t row_off = (uint32_t)dummy_row * 4u;
+  return reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / kChunk) * 3 * 64 + lane;
+}
+
+__device__ __forceinline__ void load_chunk6(Pair6 (&q)[kChunk / 2], const uint4 *__restrict__ r, int cell0) {
+#ifdef TC_ABL_SAME
+  cell0 = 0;
+#endif
+  const uint4 *rc = r + (int64_t)(cell0 / kChunk) * 3 * 64;
+  const uint4 wa = rc[0], wb = rc[64], oc = rc[128];
+  q[0] = Pair6{wa.x, wa.y, oc.x};
+  q[1] = Pair6{wa.z, wa.w, oc.y};
+  q[2] = Pair6{wb.x, wb.y, oc.z};
+  q[3] = Pair6{wb.z, wb.w, oc.w};
+}
+
+// Two register buffers in ping-pong; qa arrives preloaded with chunk 0.  The stream and the mask words
+// are followed by readable padding, so the loads past the wave's range need no guard.
+template <uint32_t SRC_BASE>
+__device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncells,
+                                           const uint32_t *__restrict__ masks, Pair6 (&qa)[kChunk / 2],
+                                           RowCursor rc) {
+  Pair6 qb[kChunk / 2];
   v2f acc = {0.f, 0.f};
-  for (int c = 0; c < ncells; c += kStreamUnrollTied) {
+  // constant address space + uniform address = s_load_dword: the mask words never touch the vector
+  // memory pipe (a vector load here would also serialise behind every older load: vmcnt is in-order)
+  typedef __attribute__((address_space(4))) const uint32_t const_u32;
+  const_u32 *mk = (const_u32 *)masks;
+  uint32_t m = mk[0];
+  for (int c = 0; c < ncells; c += 2 * kChunk) {
     if (4 * c < ncells)  // progress-based priority: see walk_rows
       __builtin_amdgcn_s_setprio(3);
     else if (2 * c < ncells)
@@ -299,11 +336,13 @@ __device__ __forceinline__ void walk_rows6(const ScheduleDev &sc, int wave, int 
       __builtin_amdgcn_s_setprio(1);
     else
       __builtin_amdgcn_s_setprio(0);
-    // the stream is followed by kStreamUnrollTied readable padding cells, so these loads need no guard
-    load_chunk(qb, c + kChunk);
-    process_chunk6<SRC_BASE>(qa, row_off, acc, acc_base);
-    load_chunk(qa, c + 2 * kChunk);
-    process_chunk6<SRC_BASE>(qb, row_off, acc, acc_base);
+    load_chunk6(qb, r, c + kChunk);
+    const uint32_t mnext = mk[(c >> 4) + 1];
+    process_chunk6<SRC_BASE>(qa, m, rc, acc);
+    if (c + kChunk >= ncells) break;
+    load_chunk6(qa, r, c + 2 * kChunk);
+    process_chunk6<SRC_BASE>(qb, m >> 4, rc, acc);
+    m = mnext;
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -376,11 +415,38 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   if (tid == 0) asum_h[0] = asum;
   float inv_prev = 1.0f / asum;
   float asum_prev = asum;
+  // tied graphs: the owned states' (f, s) offsets and self-loop weights stay in registers through the
+  // forward frames (the backward phase sets the register allocation; forward has room for them)
+  uint4 tfs[JV];
+  float4 tws[JV];
+  int fwd_n = 0, bwd_n = 0;
+  const uint4 *fwd_r = nullptr, *bwd_r = nullptr;
+  const uint32_t *fwd_m = nullptr, *bwd_m = nullptr;
+  RowCursor fwd_rc, bwd_rc;
+  if (TIED) {
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      const int h0 = 4 * (tid + kThreads * j);
+      tfs[j] = h0 < Hs ? *reinterpret_cast<const uint4 *>(p.tied_fs + h0) : make_uint4(0u, 0u, 0u, 0u);
+      tws[j] = h0 < Hs ? *reinterpret_cast<const float4 *>(p.tied_w + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    fwd_r = walk6_base(p.fwd, wave, lane, fwd_n);
+    bwd_r = walk6_base(p.bwd, wave, lane, bwd_n);
+    fwd_m = p.fwd.masks + wave * p.fwd.mask_stride;
+    bwd_m = p.bwd.masks + wave * p.bwd.mask_stride;
+    const uint32_t acc0 = (uint32_t)p.L.off_acc * 4u;
+    const uint32_t own = acc0 + 16u * (uint32_t)tid;
+    const int K = Hs / kThreads;
+    fwd_rc = RowCursor{own, 0u, 0, acc0 + 4u * (uint32_t)(Hs + 4 + 64 * p.fwd.extra_first[wave] + lane), K};
+    bwd_rc = RowCursor{own, 0u, 0, acc0 + 4u * (uint32_t)(Hs + 4 + 64 * p.bwd.extra_first[wave] + lane), K};
+  }
 
   // ---- forward frames t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
   TC_STAMP_DECL
   for (int t = 1; t <= T; ++t) {
     TC_STAMP(0)
+    Pair6 q0[kChunk / 2];
+    if (TIED) load_chunk6(q0, fwd_r, 0);
     __syncthreads();  // A0, PB, ACC ready
     TC_STAMP(1)
     float4 yreg[PV];
@@ -391,13 +457,15 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
     if (TIED)
-      walk_rows6<PV * 16 * kThreads>(p.fwd, wave, lane, Hs, (uint32_t)p.L.off_acc * 4u);
+      walk_rows6<PV * 16 * kThreads>(fwd_r, fwd_n, fwd_m, q0, fwd_rc);
     else
       walk_rows<false, true, false>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
-    __syncthreads();  // all row sums committed
+    if (!TIED || p.fwd.nfix) {
+      __syncthreads();  // all row sums committed (tied graphs: only when rows were split)
+      fold_split_rows(p.fwd, ffx0, ffx1, ACC);
+    }
     TC_STAMP(3)
-    fold_split_rows(p.fwd, ffx0, ffx1, ACC);
     float4 v4[JV];
     part = 0.f;
 #pragma unroll
@@ -407,8 +475,8 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       if (h0 < Hs) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
         if (TIED) {
-          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
-          const float4 ws = *reinterpret_cast<const float4 *>(p.tied_w + h0);
+          const uint4 fs = tfs[j];
+          const float4 ws = tws[j];
           const float4 al = *reinterpret_cast<float4 *>(A0 + h0);  // alpha'_t of the owned states
           a = make_float4(tied_alpha(PB, fs.x, ws.x, a.x, al.x), tied_alpha(PB, fs.y, ws.y, a.y, al.y),
                           tied_alpha(PB, fs.z, ws.z, a.z, al.z), tied_alpha(PB, fs.w, ws.w, a.w, al.w));
@@ -535,6 +603,8 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #endif
   for (int t = T - 1; t >= 0; --t) {
     TC_STAMP(0)
+    Pair6 q0[kChunk / 2];
+    if (TIED) load_chunk6(q0, bwd_r, 0);
     __syncthreads();  // B (or Y), PB, AL ready; BACC and GAMMA zero
     TC_STAMP(1)
     const float asum_t = asum_h[t];
@@ -556,7 +626,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     if (TIED)  // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
-      walk_rows6<PV * 16 * kThreads>(p.bwd, wave, lane, Hs, (uint32_t)p.L.off_acc * 4u);
+      walk_rows6<PV * 16 * kThreads>(bwd_r, bwd_n, bwd_m, q0, bwd_rc);
     else
       walk_rows<true, ALPHA_LDS, false>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
     if (TIED) {
@@ -570,9 +640,11 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     TC_STAMP(2)
-    __syncthreads();  // beta' sums and gamma committed
+    if (!TIED || p.bwd.nfix) {
+      __syncthreads();  // beta' sums and gamma committed (tied graphs: only when rows were split)
+      fold_split_rows(p.bwd, bfx0, bfx1, ACC);
+    }
     TC_STAMP(3)
-    fold_split_rows(p.bwd, bfx0, bfx1, ACC);
     float4 b4[JV];
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
