@@ -58,7 +58,7 @@ constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are f
 // cells per loop iteration = cells per row-mask word: two 8-cell chunks in ping-pong (a third buffer was
 // measured: no gain, and it pushes the fused kernel past 128 VGPRs)
 constexpr int kStreamUnroll = 16;
-constexpr int kStreamUnrollTied = 16;
+constexpr int kStreamUnrollTied = 8;  // tied streams: a wave's range is padded to whole chunks
 constexpr int kMaxIndex = 1 << 14;
 
 struct ScheduleHost {

@@ -442,9 +442,11 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       row_end.resize(pairs_before, 0);
       row_end[pairs_before - 1] = 1;
     }
-    while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0)
+    // whole chunks, and at least two of them (the forward walk keeps its first two chunks in registers)
+    while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 || out->cells.size() / 64 - first < 2 * kStreamUnrollTied)
       for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
+    if (getenv("TC_SCHED_DEBUG")) fprintf(stderr, "[sched] wave %d: %d cells, %zu rows\n", w, out->wave_range[w].y, slots[w].size());
     auto &mw = wave_masks[w];
     mw.assign((row_end.size() + 7) / 8, 0u);
     for (size_t i = 0; i < row_end.size(); ++i)
@@ -540,10 +542,17 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   std::vector<std::vector<int>> wave_groups(kWaves);
   std::vector<int64_t> load_in(kWaves, 0), load_out(kWaves, 0);
   for (const Group &gr : by_cost) {
+    // (shares skewed towards the older waves of each SIMD, which the CU serves first, were measured: no
+    // gain -- the walk is bound by the shared stream path, not by any one wave)
     int best = -1;
+    int64_t best_t = 0;
     for (int w = 0; w < kWaves; ++w) {
       if ((int)wave_groups[w].size() >= K) continue;
-      if (best < 0 || std::max(load_in[w] + gr.cin, load_out[w] + gr.cout) < std::max(load_in[best] + gr.cin, load_out[best] + gr.cout)) best = w;
+      const int64_t tw = std::max(load_in[w] + gr.cin, load_out[w] + gr.cout);
+      if (best < 0 || tw < best_t) {
+        best = w;
+        best_t = tw;
+      }
     }
     wave_groups[best].push_back(gr.idx);
     load_in[best] += gr.cin;

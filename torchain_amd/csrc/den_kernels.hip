@@ -27,7 +27,7 @@ namespace tc {
 // wave of workgroup 0 accumulates shader cycles per phase; the totals go to a scratch area of the
 // workspace that nothing else reads.  Never quote the run time of such a build.
 #ifdef TC_PHASE_STAMPS
-#define TC_STAMP_DECL long long st_prev = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TC_STAMP_DECL long long st_prev = clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long *wst = st_acc + 5;
 #define TC_STAMP(i)                      \
   {                                      \
     const long long st_now = clock64();  \
@@ -43,10 +43,24 @@ namespace tc {
 #define TC_STAMP_FLUSH(ptr)
 #endif
 
+// Sum over the 64 lanes, returned in every lane.  DPP adds inside each row of 16 lanes, then the four row
+// totals through v_readlane: ~12 instructions and no LDS round trips (__shfl_xor is ds_bpermute_b32, six
+// dependent LDS latencies per reduction, and these reductions sit on the per-frame critical path).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+  return v + __int_as_float(moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dpp_add<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x128>(v);  // row_ror:8   -> every lane holds its row's total
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // sum over the workgroup; `red` must not be written again before the next barrier
@@ -314,12 +328,41 @@ __device__ __forceinline__ void load_chunk6(Pair6 (&q)[kChunk / 2], const uint4 
   q[3] = Pair6{wb.z, wb.w, oc.w};
 }
 
-// Two register buffers in ping-pong; qa arrives preloaded with chunk 0.  The stream and the mask words
-// are followed by readable padding, so the loads past the wave's range need no guard.
-template <uint32_t SRC_BASE>
+// Two register buffers in ping-pong; qa arrives preloaded with the first STREAMED chunk.  The stream and
+// the mask words are followed by readable padding, so the loads past the wave's range need no guard.
+// RES = 2: the wave's first two chunks (one mask word) are held in registers by the caller for the whole
+// phase (ra, rb) and never re-read: the walk is bound by the L2 -> CU stream path, so every resident
+// chunk is time saved.  Every wave's range is at least two chunks long (den_graph.cpp).
+#ifdef TC_PHASE_STAMPS
+// diagnostic: cycles spent waiting for the current chunk's loads (three younger loads may stay in
+// flight) and cycles spent processing it, accumulated into stamp slots 5 and 6
+#define TC_WALK_WAIT                                  \
+  {                                                   \
+    const long long w0 = clock64();                   \
+    __builtin_amdgcn_s_waitcnt(0x0F73); /* vmcnt(3) */ \
+    wst[0] += clock64() - w0;                         \
+    wst[2] = clock64();                               \
+  }
+#define TC_WALK_PROC                                  \
+  {                                                   \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ \
+    wst[1] += clock64() - wst[2];                     \
+  }
+#define TC_WALK_ARG , long long *wst
+#define TC_WALK_PASS , wst
+#else
+#define TC_WALK_WAIT
+#define TC_WALK_PROC
+#define TC_WALK_ARG
+#define TC_WALK_PASS
+#endif
+
+template <uint32_t SRC_BASE, int RES>
 __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncells,
                                            const uint32_t *__restrict__ masks, Pair6 (&qa)[kChunk / 2],
-                                           RowCursor rc) {
+                                           RowCursor rc, const Pair6 (&ra)[kChunk / 2],
+                                           const Pair6 (&rb)[kChunk / 2] TC_WALK_ARG) {
+  static_assert(RES == 0 || RES == 2, "resident prefix is zero or two chunks");
   Pair6 qb[kChunk / 2];
   v2f acc = {0.f, 0.f};
   // constant address space + uniform address = s_load_dword: the mask words never touch the vector
@@ -327,7 +370,14 @@ __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncel
   typedef __attribute__((address_space(4))) const uint32_t const_u32;
   const_u32 *mk = (const_u32 *)masks;
   uint32_t m = mk[0];
-  for (int c = 0; c < ncells; c += 2 * kChunk) {
+  if (RES == 2) {
+    const uint32_t m1 = mk[1];
+    __builtin_amdgcn_s_setprio(3);
+    process_chunk6<SRC_BASE>(ra, m, rc, acc);
+    process_chunk6<SRC_BASE>(rb, m >> 4, rc, acc);
+    m = m1;
+  }
+  for (int c = RES * kChunk; c < ncells; c += 2 * kChunk) {
     if (4 * c < ncells)  // progress-based priority: see walk_rows
       __builtin_amdgcn_s_setprio(3);
     else if (2 * c < ncells)
@@ -338,10 +388,14 @@ __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncel
       __builtin_amdgcn_s_setprio(0);
     load_chunk6(qb, r, c + kChunk);
     const uint32_t mnext = mk[(c >> 4) + 1];
+    TC_WALK_WAIT
     process_chunk6<SRC_BASE>(qa, m, rc, acc);
+    TC_WALK_PROC
     if (c + kChunk >= ncells) break;
     load_chunk6(qa, r, c + 2 * kChunk);
+    TC_WALK_WAIT
     process_chunk6<SRC_BASE>(qb, m >> 4, rc, acc);
+    TC_WALK_PROC
     m = mnext;
   }
   __builtin_amdgcn_s_setprio(0);
@@ -362,6 +416,11 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const int s = blockIdx.x;
   const int H = p.H, P = p.P, S = p.S, T = p.T;
   const int Hs = p.L.Hs, Ps = p.L.Ps;
+  // Which of its JV float4s of states a thread really has: tied graphs are laid out in whole planes of
+  // 4096 positions (den_graph.cpp build_owner), so the test is wave-uniform there (a scalar branch, no
+  // per-lane compare and exec masking in the per-state passes).
+  const int planes = Hs / (4 * kThreads);
+  auto owns = [&](int j, int h0) { return TIED ? j < planes : h0 < Hs; };
   float *const PB = lds;                          // exp(y_t), at LDS offset 0
   float *const A0 = lds + PV * 4 * kThreads;      // alpha'_t (forward) / beta_{t+1} (backward): gather source
   float *const ACC = lds + p.L.off_acc; // row accumulators: one per state, dummy at Hs, then split-row slots
@@ -376,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
   for (int j = 0; j < JV; ++j) {
     const int h0 = 4 * (tid + kThreads * j);
-    pi4[j] = h0 < Hs ? *reinterpret_cast<const float4 *>(p.pi + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    pi4[j] = owns(j, h0) ? *reinterpret_cast<const float4 *>(p.pi + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
     cpi[j] = make_float4(p.leaky * pi4[j].x, p.leaky * pi4[j].y, p.leaky * pi4[j].z, p.leaky * pi4[j].w);
     part += (pi4[j].x + pi4[j].y) + (pi4[j].z + pi4[j].w);
   }
@@ -387,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
   for (int j = 0; j < JV; ++j) {
     const int h0 = 4 * (tid + kThreads * j);
-    if (h0 < Hs) {
+    if (owns(j, h0)) {
       float4 a = make_float4(pi4[j].x + cpi[j].x * asum, pi4[j].y + cpi[j].y * asum, pi4[j].z + cpi[j].z * asum,
                              pi4[j].w + cpi[j].w * asum);
       *reinterpret_cast<float4 *>(A0 + h0) = a;
@@ -423,14 +482,17 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const uint4 *fwd_r = nullptr, *bwd_r = nullptr;
   const uint32_t *fwd_m = nullptr, *bwd_m = nullptr;
   RowCursor fwd_rc, bwd_rc;
+  Pair6 fres0[kChunk / 2], fres1[kChunk / 2];  // forward stream, chunks 0 and 1: resident for the forward phase
   if (TIED) {
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
-      tfs[j] = h0 < Hs ? *reinterpret_cast<const uint4 *>(p.tied_fs + h0) : make_uint4(0u, 0u, 0u, 0u);
-      tws[j] = h0 < Hs ? *reinterpret_cast<const float4 *>(p.tied_w + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      tfs[j] = owns(j, h0) ? *reinterpret_cast<const uint4 *>(p.tied_fs + h0) : make_uint4(0u, 0u, 0u, 0u);
+      tws[j] = owns(j, h0) ? *reinterpret_cast<const float4 *>(p.tied_w + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     fwd_r = walk6_base(p.fwd, wave, lane, fwd_n);
+    load_chunk6(fres0, fwd_r, 0);
+    load_chunk6(fres1, fwd_r, kChunk);
     bwd_r = walk6_base(p.bwd, wave, lane, bwd_n);
     fwd_m = p.fwd.masks + wave * p.fwd.mask_stride;
     bwd_m = p.bwd.masks + wave * p.bwd.mask_stride;
@@ -446,7 +508,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   for (int t = 1; t <= T; ++t) {
     TC_STAMP(0)
     Pair6 q0[kChunk / 2];
-    if (TIED) load_chunk6(q0, fwd_r, 0);
+    if (TIED) load_chunk6(q0, fwd_r, 2 * kChunk);
     __syncthreads();  // A0, PB, ACC ready
     TC_STAMP(1)
     float4 yreg[PV];
@@ -457,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
     if (TIED)
-      walk_rows6<PV * 16 * kThreads>(fwd_r, fwd_n, fwd_m, q0, fwd_rc);
+      walk_rows6<PV * 16 * kThreads, 2>(fwd_r, fwd_n, fwd_m, q0, fwd_rc, fres0, fres1 TC_WALK_PASS);
     else
       walk_rows<false, true, false>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
@@ -472,11 +534,16 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
       v4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h0 < Hs) {
+      if (owns(j, h0)) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
         if (TIED) {
+#ifdef TC_TFS_RESIDENT
           const uint4 fs = tfs[j];
           const float4 ws = tws[j];
+#else
+          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          const float4 ws = *reinterpret_cast<const float4 *>(p.tied_w + h0);
+#endif
           const float4 al = *reinterpret_cast<float4 *>(A0 + h0);  // alpha'_t of the owned states
           a = make_float4(tied_alpha(PB, fs.x, ws.x, a.x, al.x), tied_alpha(PB, fs.y, ws.y, a.y, al.y),
                           tied_alpha(PB, fs.z, ws.z, a.z, al.z), tied_alpha(PB, fs.w, ws.w, a.w, al.w));
@@ -492,7 +559,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
-      if (h0 < Hs) {
+      if (owns(j, h0)) {
         float4 a = make_float4(v4[j].x + cpi[j].x * asum, v4[j].y + cpi[j].y * asum, v4[j].z + cpi[j].z * asum,
                                v4[j].w + cpi[j].w * asum);
         *reinterpret_cast<float4 *>(A0 + h0) = a;
@@ -556,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
       bown[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h0 < Hs) {
+      if (owns(j, h0)) {
         float4 b = make_float4(h0 < H ? inv_tot + bsum : 0.f, h0 + 1 < H ? inv_tot + bsum : 0.f,
                                h0 + 2 < H ? inv_tot + bsum : 0.f, h0 + 3 < H ? inv_tot + bsum : 0.f);
         bown[j] = b;
@@ -588,7 +655,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
       for (int j = 0; j < JV; ++j) {
         const int h0 = 4 * (tid + kThreads * j);
-        if (h0 < Hs) {
+        if (owns(j, h0)) {
           const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
           *reinterpret_cast<float4 *>(A0 + h0) =
               make_float4(bown[j].x * lds_at(PBcur, fs.x & 0xffffu), bown[j].y * lds_at(PBcur, fs.y & 0xffffu),
@@ -621,12 +688,12 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
         for (int j = 0; j < JV; ++j) {
           const int h0 = 4 * (tid + kThreads * j);
-          areg[j] = h0 < Hs ? *reinterpret_cast<const float4 *>(hist_n + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
+          areg[j] = owns(j, h0) ? *reinterpret_cast<const float4 *>(hist_n + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
     if (TIED)  // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
-      walk_rows6<PV * 16 * kThreads>(bwd_r, bwd_n, bwd_m, q0, bwd_rc);
+      walk_rows6<PV * 16 * kThreads, 0>(bwd_r, bwd_n, bwd_m, q0, bwd_rc, q0, q0 TC_WALK_PASS);
     else
       walk_rows<true, ALPHA_LDS, false>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
     if (TIED) {
@@ -652,7 +719,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
       b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h0 < Hs) {
+      if (owns(j, h0)) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
         float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
         if (TIED)
@@ -683,7 +750,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
           one(fs.z, ws.z, bown[j].z, al.z, aup.z, cpi[j].z, a.z);
           one(fs.w, ws.w, bown[j].w, al.w, aup.w, cpi[j].w, a.w);
         }
-        b4[j] = make_float4(a.x / asum_t, a.y / asum_t, a.z / asum_t, a.w / asum_t);
+        b4[j] = make_float4(a.x * inv_as, a.y * inv_as, a.z * inv_as, a.w * inv_as);  // [K] * inv_arbitrary_scale
         part += (cpi[j].x * b4[j].x + cpi[j].y * b4[j].y) + (cpi[j].z * b4[j].z + cpi[j].w * b4[j].w);
         if (t == 0) part_ab += (al.x * b4[j].x + al.y * b4[j].y) + (al.z * b4[j].z + al.w * b4[j].w);
       }
@@ -731,7 +798,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
-      if (h0 < Hs) {
+      if (owns(j, h0)) {
         const float4 b = make_float4(b4[j].x + bsum, b4[j].y + bsum, b4[j].z + bsum, b4[j].w + bsum);
         if (TIED) {
           bown[j] = b;
