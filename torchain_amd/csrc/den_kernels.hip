@@ -139,8 +139,12 @@ __device__ __forceinline__ float lds_at(const float *base, uint32_t byte_off) {
 }
 
 __device__ __forceinline__ void gamma_add(float *GM, uint32_t byte_off, float v) {
-  // integer LDS atomics run at store rate; float ones are lane-serialised on gfx950
-  atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + byte_off), __float2uint_rn(v));
+  // integer LDS atomics run at store rate; float ones are lane-serialised on gfx950.
+  // v_cvt_rpi_i32_f32 = floor(v + 0.5) in one instruction (v >= 0 here; a contribution of exactly 1.0,
+  // i.e. 2^31, saturates to 2^31 - 1: one quantum)
+  int32_t q;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(v));
+  atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + byte_off), (uint32_t)q);
 }
 
 template <bool BWD, bool ALPHA_LDS, bool TIED>
@@ -611,7 +615,6 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   float4 areg[JV];
   float4 ycur[PV], ynext[PV];
   float4 bown[JV];  // tied graphs: beta_{t+1} of the owned states (the LDS gather source holds Y instead)
-  float4 acur[JV];  // tied graphs: alpha'_t of the owned states (alpha'_{t+1} is parked in the thread's own AL slots)
   const int bfx0 = p.bwd.fix_begin[tid], bfx1 = p.bwd.fix_begin[tid + 1];
   // tied graphs keep two exp(y) buffers in the backward pass: frame t (self-loop terms of the owner
   // pass) and frame t-1 (written under the arc walk, needed to form Y for the next frame)
@@ -629,14 +632,11 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         bown[j] = b;
         if (!TIED) *reinterpret_cast<float4 *>(A0 + h0) = b;
         *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);  // states with no out-arcs
-        if (TIED) {
-          acur[j] = *reinterpret_cast<const float4 *>(hist_t + h0);
+        if (TIED) {  // alpha'_{t+1} of the owned states is parked in the thread's own AL slots
           *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + hist_step + h0);
         } else if (ALPHA_LDS) {
           *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + h0);
         }
-      } else if (TIED) {
-        acur[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     if (!TIED && ALPHA_LDS && tid < 4) AL[Hs + tid] = 0.f;
@@ -684,7 +684,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #pragma unroll
       for (int v = 0; v < PV; ++v) ynext[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
       if (ALPHA_LDS || TIED) {
-        const float *hist_n = hist + (int64_t)tn * hist_step;
+        // general graphs: alpha'_{t-1} for the next frame's LDS copy; tied graphs: alpha'_t of the owned
+        // states for THIS frame's per-state pass (the walk hides the latency; no second register set)
+        const float *hist_n = hist + (int64_t)(TIED ? t : tn) * hist_step;
 #pragma unroll
         for (int j = 0; j < JV; ++j) {
           const int h0 = 4 * (tid + kThreads * j);
@@ -715,6 +717,19 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     float4 b4[JV];
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
+    // all of the thread's table loads first: one L2 round trip per frame, not one per float4 of states
+    uint4 bfs[JV];
+    float4 bws[JV];
+    if (TIED) {
+#pragma unroll
+      for (int j = 0; j < JV; ++j) {
+        const int h0 = 4 * (tid + kThreads * j);
+        if (owns(j, h0)) {
+          bfs[j] = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          bws[j] = *reinterpret_cast<const float4 *>(p.tied_w + h0);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       const int h0 = 4 * (tid + kThreads * j);
@@ -723,7 +738,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
         float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
         if (TIED)
-          al = acur[j];
+          al = areg[j];
         else if (t == 0)
           al = ALPHA_LDS ? *reinterpret_cast<float4 *>(AL + h0) : *reinterpret_cast<const float4 *>(hist_t + h0);
         if (TIED) {
@@ -733,8 +748,8 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
           //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
           // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history.  The self-loop arc also
           // adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
-          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
-          const float4 ws = *reinterpret_cast<const float4 *>(p.tied_w + h0);
+          const uint4 fs = bfs[j];
+          const float4 ws = bws[j];
           const float asum_up = asum_h[t + 1];
           const float4 aup = *reinterpret_cast<float4 *>(AL + h0);  // alpha'_{t+1}, written by this thread
           auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float &ax) {
@@ -742,8 +757,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
             const float selfpart = ps_ws * alx * inv_as;           // self-loop part of alpha_{t+1}(g)
             const float alpha_up = aupx - cpx * asum_up;            // alpha_{t+1}(g)
             ax += ps_ws * bo;                                       // vf_s into beta'_t(g) * asum_t
-            gamma_add(GM, fsx >> 16, kGammaScale * (bo * selfpart));
-            gamma_add(GM, fsx & 0xffffu, kGammaScale * (bo * fmaxf(alpha_up - selfpart, 0.f)));
+            const float bos = kGammaScale * bo;  // power-of-two scale: exact
+            gamma_add(GM, fsx >> 16, bos * selfpart);
+            gamma_add(GM, fsx & 0xffffu, bos * fmaxf(alpha_up - selfpart, 0.f));
           };
           one(fs.x, ws.x, bown[j].x, al.x, aup.x, cpi[j].x, a.x);
           one(fs.y, ws.y, bown[j].y, al.y, aup.y, cpi[j].y, a.y);
@@ -810,8 +826,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
           *reinterpret_cast<float4 *>(A0 + h0) = b;
         }
         if (TIED) {
-          *reinterpret_cast<float4 *>(AL + h0) = acur[j];
-          acur[j] = areg[j];
+          *reinterpret_cast<float4 *>(AL + h0) = areg[j];
         } else if (ALPHA_LDS) {
           *reinterpret_cast<float4 *>(AL + h0) = areg[j];
         }
