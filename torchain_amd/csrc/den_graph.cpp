@@ -523,6 +523,38 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
     const size_t lo = (size_t)H * b / nbucket, hi = (size_t)H * (b + 1) / nbucket;
     std::stable_sort(st.begin() + lo, st.begin() + hi, [&](int x, int y) { return lout(x) > lout(y); });
   }
+  // Inside runs of equal (in, out) length the order is free: use it so that every 32 consecutive states --
+  // one half-slot, i.e. the 32 lanes that gather exp(y) at f(g) / s(g) and add gamma there in ONE
+  // instruction of the per-state passes -- have distinct pdf banks (greedy, first fit).
+  if (!getenv("TC_NO_PDF_BANKS")) {
+    auto key = [&](int h) { return lin(h) * 64 + lout(h); };
+    int used_f[32], used_s[32];
+    size_t run_end = 0;
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (i % 32 == 0) {
+        std::fill(used_f, used_f + 32, 0);
+        std::fill(used_s, used_s + 32, 0);
+      }
+      if (i >= run_end) {
+        run_end = i + 1;
+        while (run_end < st.size() && key(st[run_end]) == key(st[i])) ++run_end;
+      }
+      size_t best = i;
+      int best_cost = 1 << 30;
+      for (size_t c = i; c < run_end && best_cost > 0; ++c) {
+        const uint32_t fs = g->tied_fs[st[c]];
+        const int cost = used_f[((fs & 0xffffu) >> 2) & 31] + used_s[(fs >> 18) & 31];
+        if (cost < best_cost) {
+          best_cost = cost;
+          best = c;
+        }
+      }
+      std::swap(st[i], st[best]);
+      const uint32_t fs = g->tied_fs[st[i]];
+      used_f[((fs & 0xffffu) >> 2) & 31]++;
+      used_s[(fs >> 18) & 31]++;
+    }
+  }
   st.resize(Npos, -1);  // phantom states: no arcs, pi = 0
   struct Group { int idx, cin, cout; };
   std::vector<Group> groups(ngroups);
@@ -568,6 +600,98 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
         state_at[p] = h;
         if (h >= 0) g->pos[h] = p;
       }
+
+  // ---- lane permutation inside every half-slot: flatten the gathers' bank histograms
+  // The 32 lanes of a half-slot gather, step by step, one source state each; ds_read_b32 serves the 32
+  // lanes in (max number of distinct addresses on one bank) cycles, bank = position mod 32, and a state's
+  // bank is fixed by where it lives: 4 * (lane mod 8) + (k mod 4).  Whatever arrange_half does later,
+  // a half-slot of S steps cannot take fewer than max(S, most loaded bank) cycles, and with positions
+  // assigned by degree alone the most loaded bank is ~1.8 S.  So before the streams are emitted, states
+  // swap lanes WITHIN their half-slot (their own rows stay where they are; only the banks they present
+  // to the rows that gather them change) under a greedy local search on sum_b hist[b]^2 over all
+  // half-slots of both directions.
+  if (!getenv("TC_NO_BANK_SEARCH")) {
+    const int nhalf = kWaves * K * 2;
+    auto half_of = [&](int p) {
+      const int tid = (p >> 2) % kThreads, k = 4 * (p / (4 * kThreads)) + (p & 3);
+      return ((tid / 64) * K + k) * 2 + ((tid % 64) >= 32 ? 1 : 0);
+    };
+    auto bank_of = [](int p) { return p & 31; };
+    // hist[dir][half][bank]; dir 0: rows of destinations gather sources, dir 1: rows of sources gather destinations
+    std::vector<int32_t> hist((size_t)2 * nhalf * 32, 0);
+    auto H_ = [&](int dir, int half, int bank) -> int32_t & { return hist[((size_t)dir * nhalf + half) * 32 + bank]; };
+    for (int64_t a = 0; a < A2; ++a) {
+      H_(0, half_of(g->pos[dst[a]]), bank_of(g->pos[src[a]]))++;
+      H_(1, half_of(g->pos[src[a]]), bank_of(g->pos[dst[a]]))++;
+    }
+    // moving state u from bank b1 to bank b2 changes sum h^2 by the sum over the rows gathering u
+    auto move_delta = [&](int u, int b1, int b2) {
+      int64_t d = 0;
+      for (int64_t i = out_first[u]; i < out_first[u + 1]; ++i) {  // arcs u -> x: row of x gathers u (forward)
+        const int hf = half_of(g->pos[dst[out_order[i]]]);
+        int32_t &x1 = H_(0, hf, b1), &x2 = H_(0, hf, b2);
+        d += (int64_t)(2 * x2 + 1) - (2 * x1 - 1);
+        --x1;
+        ++x2;
+      }
+      for (int64_t i = in_first[u]; i < in_first[u + 1]; ++i) {  // arcs x -> u: row of x gathers u (backward)
+        const int hf = half_of(g->pos[src[in_order[i]]]);
+        int32_t &x1 = H_(1, hf, b1), &x2 = H_(1, hf, b2);
+        d += (int64_t)(2 * x2 + 1) - (2 * x1 - 1);
+        --x1;
+        ++x2;
+      }
+      return d;
+    };
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+      rng ^= rng << 13;
+      rng ^= rng >> 7;
+      rng ^= rng << 17;
+      return rng;
+    };
+    const int64_t proposals = (int64_t)Npos * 200;
+    int64_t accepted = 0;
+    for (int64_t it = 0; it < proposals; ++it) {
+      const uint64_t r = next();
+      const int w = (int)(r % kWaves), k = (int)((r >> 8) % K), hb = (int)((r >> 16) & 1);
+      const int la = hb * 32 + (int)((r >> 20) % 32), lb = hb * 32 + (int)((r >> 28) % 32);
+      if ((la & 7) == (lb & 7)) continue;  // same bank: nothing changes
+      const int pa = 4 * ((64 * w + la) + kThreads * (k >> 2)) + (k & 3), pb = 4 * ((64 * w + lb) + kThreads * (k >> 2)) + (k & 3);
+      const int u = state_at[pa], v = state_at[pb];
+      const int ba = bank_of(pa), bb = bank_of(pb);
+      // apply both moves, keep them if the total improved
+      int64_t d = 0;
+      if (u >= 0) d += move_delta(u, ba, bb);
+      if (v >= 0) d += move_delta(v, bb, ba);
+      if (d < 0) {
+        state_at[pa] = v;
+        state_at[pb] = u;
+        if (u >= 0) g->pos[u] = pb;
+        if (v >= 0) g->pos[v] = pa;
+        ++accepted;
+      } else {
+        if (v >= 0) move_delta(v, ba, bb);
+        if (u >= 0) move_delta(u, bb, ba);
+      }
+    }
+    if (getenv("TC_SCHED_DEBUG")) {
+      fprintf(stderr, "[sched] bank search: %lld of %lld swaps accepted\n", (long long)accepted, (long long)proposals);
+      for (int dir = 0; dir < 2; ++dir) {
+        int64_t sum_max = 0, sum_avg = 0;
+        for (int hf = 0; hf < nhalf; ++hf) {
+          int mx = 0, tot = 0;
+          for (int b = 0; b < 32; ++b) {
+            mx = std::max(mx, (int)H_(dir, hf, b));
+            tot += H_(dir, hf, b);
+          }
+          sum_max += mx;
+          sum_avg += (tot + 31) / 32;
+        }
+        fprintf(stderr, "[sched] dir %d: sum over half-slots of max bank load %lld, of mean bank load %lld\n", dir, (long long)sum_max, (long long)sum_avg);
+      }
+    }
+  }
 
   // ---- per direction: primary rows at home, secondary rows dealt to the least-loaded waves
   int extra_total[2] = {0, 0};
