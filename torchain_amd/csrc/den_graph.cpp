@@ -406,12 +406,12 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   int nrows = 0;
   for (int w = 0; w < kWaves; ++w) {
     const size_t first = out->cells.size() / 64;
-    size_t pairs_before = 0;
-    std::vector<char> row_end;  // per pair of this wave
+    size_t cells_before = 0;
+    std::vector<char> row_end;  // per pair of this wave: flags A | B
     for (size_t k = 0; k < slots[w].size(); ++k) {
       const auto &tasks = slots[w][k];
-      int steps = 2;
-      for (const OwnerTask &t : tasks) steps = std::max(steps, (t.len + 1) & ~1);
+      int steps = 1;  // rows need not be whole pairs: a pair may straddle two rows (flag A below)
+      for (const OwnerTask &t : tasks) steps = std::max(steps, t.len);
       const size_t off = out->cells.size();
       out->cells.resize(off + (size_t)steps * 64, ArcRec{0.f, 0u});
       arc_cells += (int64_t)steps * 64;
@@ -438,9 +438,10 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
           }
         }
       }
-      pairs_before += steps / 2;
-      row_end.resize(pairs_before, 0);
-      row_end[pairs_before - 1] = 1;
+      cells_before += steps;
+      row_end.resize((cells_before + 1) / 2, 0);
+      // bit 0 (B): the row ends with the pair's second cell; bit 1 (A): with its first cell
+      row_end[(cells_before - 1) / 2] |= ((cells_before - 1) & 1) ? 1 : 2;
     }
     // whole chunks, and at least two of them (the forward walk keeps its first two chunks in registers)
     while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 || out->cells.size() / 64 - first < 2 * kStreamUnrollTied)
@@ -449,8 +450,10 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
     if (getenv("TC_SCHED_DEBUG")) fprintf(stderr, "[sched] wave %d: %d cells, %zu rows\n", w, out->wave_range[w].y, slots[w].size());
     auto &mw = wave_masks[w];
     mw.assign((row_end.size() + 7) / 8, 0u);
-    for (size_t i = 0; i < row_end.size(); ++i)
-      if (row_end[i]) mw[i / 8] |= 1u << (i % 8);
+    for (size_t i = 0; i < row_end.size(); ++i) {
+      if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
+      if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
+    }
   }
   // readable padding: the kernels request up to four chunks past a wave's range
   for (int i = 0; i < 64 * 32; ++i) out->cells.push_back(ArcRec{0.f, 0u});
@@ -559,12 +562,12 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   struct Group { int idx, cin, cout; };
   std::vector<Group> groups(ngroups);
   for (int gi = 0; gi < ngroups; ++gi) {
-    int mi = 2, mo = 2;
+    int mi = 1, mo = 1;
     for (int l = 0; l < 64; ++l) {
       const int h = st[(size_t)gi * 64 + l];
       if (h < 0) continue;
-      mi = std::max(mi, (lin(h) + 1) & ~1);
-      mo = std::max(mo, (lout(h) + 1) & ~1);
+      mi = std::max(mi, lin(h));
+      mo = std::max(mo, lout(h));
     }
     groups[gi] = Group{gi, mi, mo};
   }
@@ -706,7 +709,7 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
     std::vector<int64_t> load(kWaves, 0);
     for (int w = 0; w < kWaves; ++w)
       for (int k = 0; k < K; ++k) {
-        int steps = 2;
+        int steps = 1;
         for (int l = 0; l < 64; ++l) {
           const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
           const int h = state_at[p];
@@ -719,7 +722,7 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
               secondary.push_back(OwnerTask{h, first[h] + done, std::min(kMaxRowLen, d - done)});
           }
           slots[w][k][l] = t;
-          steps = std::max(steps, (t.len + 1) & ~1);
+          steps = std::max(steps, t.len);
         }
         load[w] += steps;
       }
@@ -731,7 +734,7 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
       const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
       std::vector<OwnerTask> tasks(64, OwnerTask{-1, 0, 0});
       for (size_t i = b; i < std::min(secondary.size(), b + 64); ++i) tasks[i - b] = secondary[i];
-      load[w] += (secondary[b].len + 1) & ~1;
+      load[w] += secondary[b].len;
       sec_slots[w].push_back(tasks);
     }
     // private slots: wave w's j-th secondary row, lane l -> accumulator index Npos + 4 + 64 * (extra_first[w] + j) + l

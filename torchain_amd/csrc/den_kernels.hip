@@ -278,11 +278,13 @@ struct RowCursor {
   }
 };
 
-// One chunk = 4 pairs.  `m` bit u <=> the row ends after pair u (wave-uniform, from the schedule's mask
-// words through the scalar cache), so the commit sits behind a scalar branch and the common path is two
-// gathers and one packed FMA (v_pk_fma_f32) per pair.
+// One chunk = 4 pairs.  Row ends are wave-uniform and come from the schedule's mask words through the
+// scalar cache: bit u of `mb` <=> a row ends with the SECOND cell of pair u, bit u of `ma` <=> with its
+// FIRST cell (the pair straddles two rows: rows are not padded to whole pairs).  Commits sit behind
+// scalar branches; the common path is two gathers and one packed FMA (v_pk_fma_f32) per pair.
 template <uint32_t SRC_BASE>
-__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t m, RowCursor &rc, v2f &acc) {
+__device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uint32_t mb, uint32_t ma, RowCursor &rc,
+                                               v2f &acc) {
   v2f a[kChunk / 2];
 #pragma unroll
   for (int u = 0; u < kChunk / 2; ++u) {
@@ -299,8 +301,16 @@ __device__ __forceinline__ void process_chunk6(const Pair6 (&q)[kChunk / 2], uin
     v2f w;
     w.x = __uint_as_float(q[u].w0);
     w.y = __uint_as_float(q[u].w1);
-    acc = __builtin_elementwise_fma(a[u], w, acc);
-    if (__builtin_expect((m >> u) & 1u, 0)) {
+    if (__builtin_expect((ma >> u) & 1u, 0)) {
+      // the first cell closes the current row, the second opens the next one
+      lds_abs_store(rc.base + rc.koff, fmaf(a[u].x, w.x, acc.x) + acc.y);
+      rc.advance();
+      acc.x = 0.f;
+      acc.y = a[u].y * w.y;
+    } else {
+      acc = __builtin_elementwise_fma(a[u], w, acc);
+    }
+    if (__builtin_expect((mb >> u) & 1u, 0)) {
       lds_abs_store(rc.base + rc.koff, acc.x + acc.y);  // commit the finished row
       acc.x = 0.f;
       acc.y = 0.f;
@@ -377,8 +387,8 @@ __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncel
   if (RES == 2) {
     const uint32_t m1 = mk[1];
     __builtin_amdgcn_s_setprio(3);
-    process_chunk6<SRC_BASE>(ra, m, rc, acc);
-    process_chunk6<SRC_BASE>(rb, m >> 4, rc, acc);
+    process_chunk6<SRC_BASE>(ra, m, m >> 8, rc, acc);
+    process_chunk6<SRC_BASE>(rb, m >> 4, m >> 12, rc, acc);
     m = m1;
   }
   for (int c = RES * kChunk; c < ncells; c += 2 * kChunk) {
@@ -393,12 +403,12 @@ __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncel
     load_chunk6(qb, r, c + kChunk);
     const uint32_t mnext = mk[(c >> 4) + 1];
     TC_WALK_WAIT
-    process_chunk6<SRC_BASE>(qa, m, rc, acc);
+    process_chunk6<SRC_BASE>(qa, m, m >> 8, rc, acc);
     TC_WALK_PROC
     if (c + kChunk >= ncells) break;
     load_chunk6(qa, r, c + 2 * kChunk);
     TC_WALK_WAIT
-    process_chunk6<SRC_BASE>(qb, m >> 4, rc, acc);
+    process_chunk6<SRC_BASE>(qb, m >> 4, m >> 12, rc, acc);
     TC_WALK_PROC
     m = mnext;
   }
