@@ -68,6 +68,26 @@ def test_skewed_graph_row_splitting(oracle):
     _check_full(oracle, fst, 4, 15, l2=0.0, leaky=0.1)
 
 
+def test_tied_graph_with_hub_states(oracle):
+    """Chain-structured graph whose hub states have arc lists far longer than one schedule row: the
+    owner-computes schedules split them into secondary rows that other lanes walk and the owner folds
+    in after a barrier; states without a self-loop and non-final states as well."""
+    fst = synth.skewed_tied_den_fst(400, 7000, 150, seed=8)
+    from torchain_amd import io
+    g = io.DenominatorGraph(fst, fst.num_pdfs)
+    assert g.stats()["tied"] == 1
+    indeg = np.bincount(fst.dst[fst.src != fst.dst], minlength=400)
+    assert indeg.max() > 64  # really needs secondary rows
+    _check_full(oracle, fst, 4, 15, l2=1e-4, leaky=0.05)
+
+
+def test_tied_graph_partial_planes(oracle):
+    """State counts that do not fill the 4096-position planes of the tied layout (phantom positions):
+    one partly filled plane, and one full plane plus a partly filled one."""
+    _check_full(oracle, synth.random_den_fst(1500, 3, 257, seed=21), 2, 7, l2=0.0, leaky=0.1)
+    _check_full(oracle, synth.random_den_fst(5000, 3, 300, seed=22), 2, 5, l2=0.0, leaky=0.1)
+
+
 def test_denominator_alone_and_accumulate(oracle):
     """[K] DenominatorComputation used directly (chain-supervision-test.hpp:403-423): log-prob,
     Backward(1.0, &deriv) semantics (adds into deriv), sum(deriv) = S*T."""

@@ -80,6 +80,41 @@ def skewed_den_fst(num_states, num_arcs, num_pdfs, seed=3, hub_fraction=0.02):
     return DenFst(H, src, dst, (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), final, 0, P)
 
 
+def skewed_tied_den_fst(num_states, num_arcs, num_pdfs, seed=5, hub_fraction=0.02):
+    """Chain-structured ("tied") graph with heavily skewed degrees: every non-self-loop arc carries the
+    forward pdf of its destination, most states have one self-loop with their own self-loop pdf, a few
+    hub states have hundreds of in- and out-arcs (longer than one schedule row), some states are
+    non-final.  Exercises the secondary rows and the fold barrier of the owner-computes schedules."""
+    rng = np.random.default_rng(seed)
+    H, A, P = int(num_states), int(num_arcs), int(num_pdfs)
+    hubs = max(1, int(H * hub_fraction))
+    w_state = np.ones(H)
+    w_state[rng.choice(H, hubs, replace=False)] = H / hubs / 2.0
+    w_state /= w_state.sum()
+    has_loop = rng.uniform(size=H) < 0.8
+    n_loop = int(has_loop.sum())
+    n_other = A - n_loop
+    o_src = np.concatenate([np.arange(H), rng.choice(H, n_other - H, p=w_state)]).astype(np.int32)
+    o_dst = rng.choice(H, n_other, p=rng.permutation(w_state)).astype(np.int32)
+    same = o_src == o_dst  # keep the non-self-loop class free of accidental self-loops
+    o_dst[same] = (o_dst[same] + 1) % H
+    fwd_pdf = rng.integers(0, P, size=H).astype(np.int32)
+    self_pdf = rng.integers(0, P, size=H).astype(np.int32)
+    l_src = np.nonzero(has_loop)[0].astype(np.int32)
+    src = np.concatenate([o_src, l_src])
+    dst = np.concatenate([o_dst, l_src])
+    pdf = np.concatenate([fwd_pdf[o_dst], self_pdf[l_src]])
+    order = np.argsort(src, kind="stable")
+    src, dst, pdf = src[order], dst[order], pdf[order]
+    prob = rng.uniform(0.05, 1.0, size=len(src))
+    tot = np.zeros(H)
+    np.add.at(tot, src, prob)
+    prob /= tot[src]
+    final = np.where(rng.uniform(size=H) < 0.7, 0.0, np.inf).astype(np.float32)
+    final[0] = 0.0
+    return DenFst(H, src, dst, (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), final, 0, P)
+
+
 def initial_probs_f64(fst, num_iters=100):
     """Plain float64 numpy version of the 100-iteration initial-prob estimate (used only to weight
     the synthetic numerator's first arcs and to cross-check the oracle)."""
