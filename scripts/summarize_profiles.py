@@ -30,6 +30,18 @@ if f:
             summary["min_ns"] = float(r[5])
 
 
+f = find("kt", "*kernel_trace.csv")
+if f:
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+               for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"])
+    dur = [x[1] for x in d]
+    if dur:
+        srt = sorted(dur)
+        summary["trace_median_ns"] = srt[len(srt) // 2]
+        summary["trace_mean_last20_ns"] = sum(dur[-20:]) / len(dur[-20:])  # the launches bench.py times with HIP events
+        summary["trace_first8_ns"] = dur[:8]
+
+
 def counter_means(sub):
     f = find(sub, "*counter_collection.csv")
     res = {}

@@ -32,31 +32,31 @@ struct ArcRec {
   uint32_t idx;  // state | (pdf << 16)
 };
 
-// A "row" is the in-arc list (forward) or out-arc list (backward) of one state, at most kMaxRowLen
-// long.  Rows are sorted by length and dealt 64 at a time into "slots"; lane l of a slot walks row l.
-// Every wave gets one flat, self-describing stream of 8-byte cells laid out [cell][lane], so a wave
-// instruction loads 64 consecutive cells (512 B, coalesced) and the whole stream can be prefetched
-// many cells ahead with no dependent address computation:
+// GENERAL graphs.  A "row" is the in-arc list (forward) or out-arc list (backward) of one state, at most
+// kMaxRowLen long.  Rows are sorted by length and dealt 64 at a time into "slots"; lane l of a slot walks
+// row l.  Every wave gets one flat, self-describing stream of 8-byte cells laid out [pair][lane][2], so a
+// wave instruction loads 64 lanes x 16 contiguous bytes and the stream is prefetched with no dependent
+// address computation:
 //   arc cell  : {w, pdf*4 | state*4 << 16}: the two LDS byte offsets the lane gathers from, ready to
 //               use (exp(y) sits at LDS offset 0, alpha'/beta at a compile-time base that the ds_read
 //               immediate supplies), so address math is one AND and one shift per cell.
 //   ROW cell  : {accumulator slot | state << 16 of the row that starts here, kRowFlag | dummy offsets}.
 //               It commits the previous row's sum with a plain LDS store.  All 64 lanes of a wave hit
 //               their ROW cells at the same stream position, so the flag test (v_readfirstlane of
-//               the cell's own offset word) feeds a scalar branch.  The flag is deliberately in-band:
-//               a separate mask array cost one dependent L2 round trip per loop iteration.
+//               the cell's own offset word) feeds a scalar branch.
 //   padding   : arc cell with w = 0, offsets 0 (adds 0)
 // A stream ends with a ROW(dummy) cell and is padded to a multiple of kStreamUnroll cells; the whole
-// array ends with kStreamUnroll / 2 extra padding cells so the prefetch never needs a bounds check.
+// array ends with readable padding so the prefetch never needs a bounds check.  Every row owns its
+// accumulator slot, so no LDS float atomics are needed (ds_add_f32 costs 192 cycles per
+// wave-instruction on gfx950, profiles/microbench): a state whose arc list fits one row uses slot =
+// state; each further chunk of a longer list gets a private slot >= Hs + 4, and the thread that owns
+// the state folds those slots in before it reads the sum ("fix-up" list, sorted by owner thread).
 //
-// Every row owns its accumulator slot, so no LDS float atomics are needed (ds_add_f32 costs 192
-// cycles per wave-instruction on gfx950, profiles/microbench): a state whose arc list fits one row
-// uses slot = state; each further chunk of a longer list gets a private slot >= Hs + 4, and the
-// thread that owns the state folds those slots in before it reads the sum ("fix-up" list, sorted by
-// owner thread).
+// TIED graphs use owner-computes schedules instead (den_graph.cpp: build_owner): states are permuted so
+// that the thread owning a state walks its row, 6-byte cells without ROW cells, row ends in mask words.
 constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are free (offsets are multiples of 4)
-// cells per loop iteration = cells per row-mask word: two 8-cell chunks in ping-pong (a third buffer was
-// measured: no gain, and it pushes the fused kernel past 128 VGPRs)
+// general streams: cells per loop iteration, two 8-cell chunks in ping-pong (a third buffer was measured:
+// no gain, and it pushes the fused kernel past 128 VGPRs)
 constexpr int kStreamUnroll = 16;
 constexpr int kStreamUnrollTied = 8;  // tied streams: a wave's range is padded to whole chunks
 constexpr int kMaxIndex = 1 << 14;

@@ -8,14 +8,15 @@
 // LDS: exp(y_t), alpha'_t / beta_{t+1} (gather source), one accumulator per row and, in the backward
 // half, gamma_t (u32 fixed point) and alpha'_t.  HBM sees each y row twice (forward, backward), each
 // alpha' frame once out and once back, and each derivative row once.  The transition tables are
-// streamed from L2 as a per-wave cell stream in a lane-major schedule (den_graph.cpp): lane l of a
-// wave walks one state's arc list, a wave instruction loads 64 lanes x 12 or 16 contiguous bytes, and
-// the lanes gather alpha' (and exp(y)) from LDS.  There are no LDS float atomics (192 cycles per
-// wave-instruction on gfx950): every row owns its accumulator slot and gamma is integer fixed point.
+// streamed from L2 as a per-wave cell stream in a lane-major schedule (den_graph.cpp): a lane walks one
+// state's arc list, a wave instruction loads 64 lanes x 16 contiguous bytes, and the lanes gather
+// alpha' (and exp(y)) from LDS.  There are no LDS float atomics (192 cycles per wave-instruction on
+// gfx950): every row sum is committed with a plain store and gamma is integer fixed point.
 // Two code paths: the general kernel (any graph; two gathers per arc, one gamma atomic per arc in the
-// backward walk) and the "tied" kernel for chain-structured graphs (all non-self-loop arcs into a
-// state share a pdf): one gather per arc in both walks, no atomics in the walks, self-loops and gamma
-// handled per state by the owning thread.
+// backward walk, in-band ROW cells, three barriers per frame) and the "tied" kernel for chain-structured
+// graphs (all non-self-loop arcs into a state share a pdf): one gather per arc in both walks, no atomics
+// in the walks, self-loops and gamma handled per state, and OWNER-COMPUTES schedules -- the thread that
+// owns a state walks its arc list, so row sums never cross threads and a frame needs two barriers.
 //
 // Numerics follow the Kaldi CPU arithmetic: linear domain, fp32, per-frame renormalisation by the
 // alpha-sum of the previous frame ("arbitrary_scale"), leaky-HMM mixing, betas carrying 1/tot_prob.
