@@ -139,7 +139,8 @@ int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_outpu
  * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows,
  * out[6], out[7] = forward / backward LDS bank-conflict factor of the placed arc gathers x 1000, where
  * 1000 means conflict-free; out[8] = 1 when the graph is "tied" -- all non-self-loop arcs entering a
- * state carry one pdf -- and runs the factorised kernel). */
+ * state carry one pdf -- and runs the factorised kernel, 2 when the graph is too large for the on-chip
+ * layout and runs the streamed kernel, 0 for the general on-chip kernel). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
 #ifdef __cplusplus

@@ -88,6 +88,31 @@ def test_tied_graph_partial_planes(oracle):
     _check_full(oracle, synth.random_den_fst(5000, 3, 300, seed=22), 2, 5, l2=0.0, leaky=0.1)
 
 
+def test_streamed_path_for_graphs_beyond_lds(oracle, monkeypatch):
+    """Graphs the on-chip layouts cannot hold (more than 16384 states here) take the streamed kernel
+    (alpha/beta in global memory); the same kernel forced onto small graphs, tied and general, must agree
+    with the oracle too, including Kaldi's accumulate form."""
+    from torchain_amd import io
+    fst = synth.random_den_fst(20000, 3, 700, seed=31)
+    g = io.DenominatorGraph(fst, fst.num_pdfs)
+    assert g.stats()["tied"] == 2
+    _check_full(oracle, fst, 2, 6, l2=1e-4, leaky=0.1)
+    monkeypatch.setenv("TC_FORCE_BIG", "1")
+    _check_full(oracle, synth.random_den_fst(300, 5, 100, seed=32), 3, 11, l2=0.0, leaky=1e-5)
+    fst2 = synth.skewed_den_fst(300, 6000, 120, seed=4)
+    _check_full(oracle, fst2, 4, 9, l2=1e-3, leaky=0.1)
+    S, T = 3, 8
+    og = oracle.DenGraph(fst2)
+    y = synth.random_nnet_output(S, T, fst2.num_pdfs, seed=9)
+    ref = oracle.den_forward_backward(og, y, S, leaky=0.05, deriv_weight=1.0)
+    out = hip_den(fst2, y, S, leaky=0.05, deriv_weight=1.0, accumulate=True, init=0.5)
+    assert io.DenominatorGraph(fst2, fst2.num_pdfs).stats()["tied"] == 2
+    assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"]) and out["status"] == 0
+    assert rel_err(out["deriv"] - 0.5, ref["deriv"]) <= REL
+    out3 = hip_den(fst2, y, S, leaky=0.05, want_deriv=False)
+    assert abs(out3["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+
+
 def test_denominator_alone_and_accumulate(oracle):
     """[K] DenominatorComputation used directly (chain-supervision-test.hpp:403-423): log-prob,
     Backward(1.0, &deriv) semantics (adds into deriv), sum(deriv) = S*T."""

@@ -18,6 +18,7 @@ namespace {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
+  float *big_expy, *big_beta;  // streamed path only
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
   float *ab, *gs;
@@ -28,8 +29,9 @@ struct Workspace {
 
 // Hs: stored states per frame of the alpha history (layout positions for tied graphs: build_owner)
 int hist_states(const tc_den_graph *g) { return g->tied ? g->layout.Hs : ((g->H + 3) & ~3); }
+int big_ps(const tc_den_graph *g) { return g->big ? ((g->P + 3) & ~3) : 0; }
 
-Workspace carve(char *base, int Hs, int S, int T) {
+Workspace carve(char *base, int Hs, int S, int T, int big_Ps = 0) {
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -45,6 +47,8 @@ Workspace carve(char *base, int Hs, int S, int T) {
   w.gs = (float *)take((size_t)S * 4);
   w.fail = (int32_t *)take(256);
   w.scalar = (double *)take(4096);  // also the stamp area of diagnostic builds
+  w.big_expy = big_Ps ? (float *)take((size_t)S * big_Ps * sizeof(float)) : nullptr;
+  w.big_beta = big_Ps ? (float *)take((size_t)2 * S * Hs * sizeof(float)) : nullptr;
   w.total = off;
   return w;
 }
@@ -82,10 +86,16 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   bool tied = g->tied;
   // tied graphs address states by layout position (a multiple of 4096 of them, phantoms included)
   const int nstates = tied ? g->layout.Hs : g->H;
-  if (!compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
-    if (tied) return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit
-    return TC_ERR_UNSUPPORTED;
+  if (g->big) {
+    p->L = DenLayout();
+    p->L.Hs = (g->H + 3) & ~3;
+    p->L.Ps = (g->P + 3) & ~3;
+  } else if (!compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
+    return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit LDS
   }
+  p->big = d.big;
+  p->big_expy = w.big_expy;
+  p->big_beta = w.big_beta;
   p->tied_fs = tied ? d.tied_fs : nullptr;
   p->tied_w = tied ? d.tied_w : nullptr;
   p->fwd = d.fwd;
@@ -148,7 +158,7 @@ extern "C" {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, hist_states(g), S, T).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T, big_ps(g)).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -157,7 +167,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, hist_states(g), S, T);
+  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_ps(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -200,7 +210,7 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T);
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_ps(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;

@@ -88,7 +88,23 @@ struct ScheduleDev {
   int32_t mask_stride = 0, nfix = 0;
 };
 
+// ---- graphs too large for the on-chip layout ("streamed" path, den_big_kernel.hip) ------------------
+// alpha'/beta vectors stay in HBM/L2 and the transitions are plain CSR lists of 16-byte records, in
+// three orders: by destination (forward), by source (backward beta'), by pdf (backward gamma: one thread
+// per pdf sums its arcs, so the derivative row needs no atomics and the result is order-deterministic).
+struct BigArc {
+  int32_t a, b;  // by destination: {src, pdf}; by source: {dst, pdf}; by pdf: {src, dst}
+  float w;
+  int32_t pad;
+};
+
+struct BigDev {
+  const int32_t *in_begin = nullptr, *out_begin = nullptr, *pdf_begin = nullptr;
+  const BigArc *in_arc = nullptr, *out_arc = nullptr, *pdf_arc = nullptr;
+};
+
 struct DenGraphDev {
+  BigDev big;
   ScheduleDev fwd, bwd;
   const float *pi;  // initial probs padded to Hs
   const uint32_t *tied_fs = nullptr;  // tied graphs: per state, forward-pdf*4 | self-loop-pdf*4 << 16
@@ -126,6 +142,9 @@ struct DenParams {
   DenLayout L;
   const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
   const float *tied_w;
+  BigDev big;           // streamed path only
+  float *big_expy;      // [S][Ps]  exp(y_t) of the current frame
+  float *big_beta;      // [2][S][Hs]
   long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
 };
 
@@ -150,6 +169,10 @@ struct tc_den_graph {
   std::vector<float> pi_pos;          // initial probs in position order
   tc::DenLayout layout;
   bool layout_ok = false;
+  // streamed path: chosen when neither on-chip layout fits (or TC_FORCE_BIG is set)
+  bool big = false;
+  std::vector<int32_t> big_in_begin, big_out_begin, big_pdf_begin;
+  std::vector<tc::BigArc> big_in, big_out, big_pdf;
   std::mutex mu;
   std::map<int, tc::DenGraphDev> dev;
 };
@@ -215,6 +238,7 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
 int64_t layout_lds_bytes(const DenLayout &L, int T);
 
 int launch_den(const DenParams &p, hipStream_t stream);
+int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
                     int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,

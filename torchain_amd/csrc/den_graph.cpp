@@ -778,8 +778,33 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   return true;
 }
 
+// CSR lists for the streamed path (chain_internal.h: BigArc)
+static void build_big(tc_den_graph *g) {
+  const int H = g->H, P = g->P;
+  const int64_t A = g->A;
+  auto csr = [&](int n, const std::vector<int32_t> &key, std::vector<int32_t> *begin, std::vector<BigArc> *out,
+                 const std::vector<int32_t> &fa, const std::vector<int32_t> &fb) {
+    begin->assign(n + 1, 0);
+    for (int64_t a = 0; a < A; ++a) (*begin)[key[a] + 1]++;
+    for (int i = 0; i < n; ++i) (*begin)[i + 1] += (*begin)[i];
+    out->assign(std::max<int64_t>(A, 1), BigArc{0, 0, 0.f, 0});
+    std::vector<int32_t> fill(begin->begin(), begin->end() - 1);
+    for (int64_t a = 0; a < A; ++a) (*out)[fill[key[a]]++] = BigArc{fa[a], fb[a], g->arc_prob[a], 0};  // FST arc order kept
+  };
+  csr(H, g->arc_dst, &g->big_in_begin, &g->big_in, g->arc_src, g->arc_pdf);
+  csr(H, g->arc_src, &g->big_out_begin, &g->big_out, g->arc_dst, g->arc_pdf);
+  csr(P, g->arc_pdf, &g->big_pdf_begin, &g->big_pdf, g->arc_src, g->arc_dst);
+}
+
 int build_schedules(tc_den_graph *g) {
   const int Hs = round4(g->H);
+  if (getenv("TC_FORCE_BIG") || g->H > kMaxIndex || g->P > kMaxIndex) {
+    g->big = true;
+    g->tied = false;
+    g->layout_ok = false;
+    build_big(g);
+    return TC_OK;
+  }
   // ---- is the graph tied?  (see tc_den_graph::tied)
   // Per state g: every non-self-loop in-arc carries one pdf f(g); self-loops that also carry f(g) are
   // ordinary members of that class; at most one further self-loop (pdf s(g)) is "special" and is applied
@@ -834,6 +859,12 @@ int build_schedules(tc_den_graph *g) {
   // backward: beta'_t(src) sums over out-arcs, gathers beta_{t+1}(dst)
   build_one(g->H, Hs, g->P, g->A, g->arc_src.data(), g->arc_dst.data(), g->arc_pdf.data(), g->arc_prob.data(), kStreamUnroll, false, &g->bwd);
   g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
+  if (!g->layout_ok) {  // the per-frame working set does not fit LDS: stream it
+    g->big = true;
+    g->fwd = ScheduleHost();
+    g->bwd = ScheduleHost();
+    build_big(g);
+  }
   return TC_OK;
 }
 
@@ -1028,7 +1059,7 @@ int tc_den_graph_stats(const tc_den_graph *g, int64_t *o) {
   o[5] = g->bwd.rows;
   o[6] = g->fwd.conflict_free_cost ? 1000 * g->fwd.conflict_cost / g->fwd.conflict_free_cost : 0;
   o[7] = g->bwd.conflict_free_cost ? 1000 * g->bwd.conflict_cost / g->bwd.conflict_free_cost : 0;
-  o[8] = g->tied ? 1 : 0;
+  o[8] = g->big ? 2 : (g->tied ? 1 : 0);
   return TC_OK;
 }
 
@@ -1042,6 +1073,44 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   const int Hs = (g->H + 3) & ~3;
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   struct Part { const void *src; size_t bytes; size_t off; };
+  if (g->big) {
+    std::vector<float> pi_pad(Hs + 4, 0.f);
+    std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
+    Part parts[] = {
+        {g->big_in_begin.data(), g->big_in_begin.size() * 4, 0}, {g->big_in.data(), g->big_in.size() * sizeof(BigArc), 0},
+        {g->big_out_begin.data(), g->big_out_begin.size() * 4, 0}, {g->big_out.data(), g->big_out.size() * sizeof(BigArc), 0},
+        {g->big_pdf_begin.data(), g->big_pdf_begin.size() * 4, 0}, {g->big_pdf.data(), g->big_pdf.size() * sizeof(BigArc), 0},
+        {pi_pad.data(), pi_pad.size() * 4, 0},
+    };
+    size_t total = 0;
+    for (auto &p : parts) {
+      p.off = total;
+      total += align(p.bytes);
+    }
+    char *blob = nullptr;
+    hipError_t e = hipMalloc((void **)&blob, total);
+    if (e == hipSuccess)
+      for (auto &p : parts) {
+        e = hipMemcpy(blob + p.off, p.src, p.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) break;
+      }
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return TC_ERR_HIP;
+    }
+    DenGraphDev d;
+    d.blob = blob;
+    d.big.in_begin = (const int32_t *)(blob + parts[0].off);
+    d.big.in_arc = (const BigArc *)(blob + parts[1].off);
+    d.big.out_begin = (const int32_t *)(blob + parts[2].off);
+    d.big.out_arc = (const BigArc *)(blob + parts[3].off);
+    d.big.pdf_begin = (const int32_t *)(blob + parts[4].off);
+    d.big.pdf_arc = (const BigArc *)(blob + parts[5].off);
+    d.pi = (const float *)(blob + parts[6].off);
+    g->dev[device] = d;
+    return TC_OK;
+  }
   std::vector<float> pi_pad(Hs + 4, 0.f);
   std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
   if (g->tied) pi_pad = g->pi_pos;  // position order (build_owner)

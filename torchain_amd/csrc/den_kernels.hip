@@ -878,6 +878,7 @@ static int launch_jpt(const DenParams &p, int accumulate, size_t lds_bytes, hipS
 
 // accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
 int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
+  if (p.big.in_begin) return launch_den_big(p, accumulate, stream);  // graph beyond the on-chip layout
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
