@@ -88,6 +88,17 @@ def test_tied_graph_partial_planes(oracle):
     _check_full(oracle, synth.random_den_fst(5000, 3, 300, seed=22), 2, 5, l2=0.0, leaky=0.1)
 
 
+def test_tied_tight_layout_mid_vocab(oracle):
+    """4097..8192 pdfs with 8192 states: the tied kernel's roomy LDS layout does not fit, the tight one
+    (alpha' re-read from the history, exp(y) rewritten in place) does; 6000 pdfs with fewer states fits
+    the roomy layout of the same <JV=2, PV=2> instantiation."""
+    from torchain_amd import io
+    fst = synth.random_den_fst(8192, 3, 6000, seed=41)
+    assert io.DenominatorGraph(fst, fst.num_pdfs).stats()["tied"] == 1
+    _check_full(oracle, fst, 2, 9, l2=1e-4, leaky=0.1)
+    _check_full(oracle, synth.random_den_fst(3000, 4, 6000, seed=42), 3, 7, l2=0.0, leaky=0.05)
+
+
 def test_streamed_path_for_graphs_beyond_lds(oracle, monkeypatch):
     """Graphs the on-chip layouts cannot hold (more than 16384 states here) take the streamed kernel
     (alpha/beta in global memory); the same kernel forced onto small graphs, tied and general, must agree
@@ -162,6 +173,8 @@ def test_config5_large_vocab_subset(oracle):
     c = synth.CONFIGS["C5"]
     fst = synth.config_den_fst("C5")
     assert len(fst.src) == 61440
+    from torchain_amd import io
+    assert io.DenominatorGraph(fst, fst.num_pdfs).stats()["tied"] == 1  # tight tied layout
     _check_full(oracle, fst, 3, 20, l2=c["l2"], leaky=c["leaky"])
 
 

@@ -20,6 +20,7 @@ constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 // the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 constexpr int kJvSmall = 2048 / kThreads, kPvSmall = 1024 / kThreads, kJvLarge = 4096 / kThreads, kPvLarge = 3072 / kThreads;
+constexpr int kPvMid = 2048 / kThreads;  // 4097..8192 pdfs
 // the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 // the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 constexpr int kMaxRowLen = 32;             // longer in/out-arc lists are split into virtual rows

@@ -27,6 +27,9 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
   if (jv <= kJvSmall && pv <= kPvSmall) {
     L->JV = kJvSmall;
     L->PV = kPvSmall;
+  } else if (jv <= kJvSmall && pv <= kPvMid) {
+    L->JV = kJvSmall;
+    L->PV = kPvMid;
   } else if (jv <= kJvSmall && pv <= kPvLarge) {
     L->JV = kJvSmall;
     L->PV = kPvLarge;
@@ -45,10 +48,13 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
     off += L->acc_floats;  // ACC / BACC (+ dummy row + private slots of split rows)
     L->off_g = off;
     off += L->Ps;
+    // tied graphs, roomy layout: owner-private parking of alpha'_{t+1} and a second exp(y) buffer; the
+    // tight layout (alpha_in_lds == false) re-reads alpha'_{t+1} from the history and rewrites exp(y) in
+    // place behind one more barrier per backward frame -- what lets 4097..12288 pdfs stay on this path
     L->off_al = off;
-    if (with_alpha || tied) off += L->Hs + 4;  // tied graphs: owner-private parking of alpha'_{t+1}
+    if (with_alpha) off += L->Hs + 4;
     L->off_p2 = off;
-    if (tied) off += L->PV * 4 * kThreads;
+    if (tied && with_alpha) off += L->PV * 4 * kThreads;
     L->off_red = off;
     off += 4 * kWaves;
     L->off_asum = off;

@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const int bfx0 = p.bwd.fix_begin[tid], bfx1 = p.bwd.fix_begin[tid + 1];
   // tied graphs keep two exp(y) buffers in the backward pass: frame t (self-loop terms of the owner
   // pass) and frame t-1 (written under the arc walk, needed to form Y for the next frame)
-  float *PBcur = PB, *PBnext = lds + p.L.off_p2;
+  float *PBcur = PB, *PBnext = (TIED && !ALPHA_LDS) ? PB : lds + p.L.off_p2;  // tight tied layout: one exp(y) buffer
   {
     const float *hist_t = hist + (int64_t)(T - 1) * hist_step;
     const float *yrow = p.y + ((int64_t)(T - 1) * S + s) * p.y_stride;
@@ -643,8 +643,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         bown[j] = b;
         if (!TIED) *reinterpret_cast<float4 *>(A0 + h0) = b;
         *reinterpret_cast<float4 *>(ACC + h0) = make_float4(0.f, 0.f, 0.f, 0.f);  // states with no out-arcs
-        if (TIED) {  // alpha'_{t+1} of the owned states is parked in the thread's own AL slots
-          *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + hist_step + h0);
+        if (TIED) {  // alpha'_{t+1} of the owned states is parked in the thread's own AL slots (roomy layout)
+          if (ALPHA_LDS)
+            *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + hist_step + h0);
         } else if (ALPHA_LDS) {
           *reinterpret_cast<float4 *>(AL + h0) = *reinterpret_cast<const float4 *>(hist_t + h0);
         }
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       walk_rows6<PV * 16 * kThreads, 0>(bwd_r, bwd_n, bwd_m, q0, bwd_rc, q0, q0 TC_WALK_PASS);
     else
       walk_rows<true, ALPHA_LDS, false>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
-    if (TIED) {
+    if (TIED && ALPHA_LDS) {
       // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
 #pragma unroll
       for (int v = 0; v < PV; ++v) {
@@ -762,7 +763,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
           const uint4 fs = bfs[j];
           const float4 ws = bws[j];
           const float asum_up = asum_h[t + 1];
-          const float4 aup = *reinterpret_cast<float4 *>(AL + h0);  // alpha'_{t+1}, written by this thread
+          // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
+          const float4 aup = ALPHA_LDS ? *reinterpret_cast<float4 *>(AL + h0)
+                                       : *reinterpret_cast<const float4 *>(hist_t + hist_step + h0);
           auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float &ax) {
             const float ps_ws = lds_at(PBcur, fsx >> 16) * wsx;
             const float selfpart = ps_ws * alx * inv_as;           // self-loop part of alpha_{t+1}(g)
@@ -821,6 +824,18 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
 #endif
       break;
     }
+    if (TIED && !ALPHA_LDS) {
+      // tight layout: exp(y_{t-1}) overwrites exp(y_t) in place -- its readers (the per-state pass) are
+      // behind the reduction's barrier -- and one more barrier publishes it to the Y update below
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * (tid + kThreads * v);
+        if (i0 < Ps)
+          *reinterpret_cast<float4 *>(PB + i0) = make_float4(exp_limited(ynext[v].x), exp_limited(ynext[v].y),
+                                                             exp_limited(ynext[v].z), exp_limited(ynext[v].w));
+      }
+      __syncthreads();
+    }
     // beta_t = beta'_t + leaky-sum; next frame's gather source (beta_t, or Y_{t-1} = beta_t * p_{t-1}(f) when tied)
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
@@ -836,11 +851,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         } else {
           *reinterpret_cast<float4 *>(A0 + h0) = b;
         }
-        if (TIED) {
-          *reinterpret_cast<float4 *>(AL + h0) = areg[j];
-        } else if (ALPHA_LDS) {
-          *reinterpret_cast<float4 *>(AL + h0) = areg[j];
-        }
+        if (ALPHA_LDS) *reinterpret_cast<float4 *>(AL + h0) = areg[j];
       }
     }
 #pragma unroll
@@ -887,6 +898,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   if (JV == J && PV == V)                                                                  \
     return tied ? launch_jpt<J, V, true>(p, accumulate, lds, stream) : launch_jpt<J, V, false>(p, accumulate, lds, stream);
   TC_DISPATCH(kJvSmall, kPvSmall)
+  TC_DISPATCH(kJvSmall, kPvMid)
   TC_DISPATCH(kJvSmall, kPvLarge)
   TC_DISPATCH(kJvLarge, kPvLarge)
 #undef TC_DISPATCH
