@@ -143,6 +143,14 @@ int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_outpu
  * layout and runs the streamed kernel, 0 for the general on-chip kernel). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
+/* Diagnostic, host only: replays one arc walk from the graph's built schedules exactly as the kernels
+ * consume them and returns, per state, direction 0: sum over in-arcs (h->g) of w*gather[h]*pdf_factor[pdf],
+ * direction 1: sum over out-arcs (h->g) of w*gather[g]*pdf_factor[pdf]  (gather: num_states floats,
+ * pdf_factor: num_pdfs floats, out: num_states floats).  Lets the schedule builder be tested without a GPU;
+ * nothing on the hot path calls it. */
+int tc_den_graph_debug_walk(const tc_den_graph *graph, int direction, const float *gather,
+                            const float *pdf_factor, float *out);
+
 #ifdef __cplusplus
 }
 #endif

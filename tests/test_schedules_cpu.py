@@ -1,0 +1,66 @@
+"""Host-logic tests of the denominator schedule builder (no GPU): the built streams -- state
+permutation, cell order, row-end masks, secondary rows and fix-up lists, per-state tables -- are
+replayed on the CPU exactly as the kernels consume them (tc_den_graph_debug_walk) and compared with
+the definition of the arc sums ([K] chain-denominator.cc AlphaGeneralFrame / BetaDashGeneralFrame:
+sum over in-arcs of w * alpha(src) * p(pdf), sum over out-arcs of w * beta(dst) * p(pdf))."""
+import numpy as np
+import pytest
+
+from torchain_amd import io, synth
+
+
+def definition(fst, direction, gather, pdf_factor):
+    w = np.exp(-fst.weight.astype(np.float64))
+    pf = pdf_factor.astype(np.float64)[fst.ilabel - 1]
+    g = gather.astype(np.float64)
+    if direction == 0:
+        return np.bincount(fst.dst, weights=w * g[fst.src] * pf, minlength=fst.num_states)
+    return np.bincount(fst.src, weights=w * g[fst.dst] * pf, minlength=fst.num_states)
+
+
+def check_graph(fst, expect_kind):
+    graph = io.DenominatorGraph(fst, fst.num_pdfs)
+    assert graph.stats()["tied"] == expect_kind
+    rng = np.random.default_rng(1)
+    gather = rng.uniform(0.1, 1.0, fst.num_states).astype(np.float32)
+    pdf_factor = rng.uniform(0.5, 2.0, fst.num_pdfs).astype(np.float32)
+    for direction in (0, 1):
+        got = graph.debug_walk(direction, gather, pdf_factor)
+        ref = definition(fst, direction, gather, pdf_factor)
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= 2e-6 * scale, (direction, np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("H,deg,P", [(3, 2, 5), (64, 4, 32), (1000, 5, 400), (4096, 3, 300), (5000, 3, 300)])
+def test_tied_owner_schedules_replay(H, deg, P):
+    check_graph(synth.random_den_fst(H, deg, P, seed=H + deg), 1)
+
+
+def test_tied_schedules_with_hub_states_replay():
+    """Arc lists of several hundred arcs: primary rows at home, secondary rows elsewhere, folded by the owner."""
+    check_graph(synth.skewed_tied_den_fst(400, 7000, 150, seed=8), 1)
+    check_graph(synth.skewed_tied_den_fst(3000, 30000, 500, seed=9, hub_fraction=0.005), 1)
+
+
+def test_left_to_right_graph_replay():
+    check_graph(synth.left_to_right_den_fst(200, seed=42), io.DenominatorGraph(synth.left_to_right_den_fst(200, seed=42), 200).stats()["tied"])
+
+
+def test_general_schedules_replay():
+    check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 0)
+
+
+def test_config3_and_config5_graphs_replay():
+    check_graph(synth.config_den_fst("C3"), 1)
+    check_graph(synth.config_den_fst("C5"), 1)
+
+
+def test_streamed_tables_replay(monkeypatch):
+    check_graph(synth.random_den_fst(20000, 3, 700, seed=31), 2)
+    monkeypatch.setenv("TC_FORCE_BIG", "1")
+    check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 2)
+
+
+def test_forced_general_matches_tied(monkeypatch):
+    monkeypatch.setenv("TC_FORCE_GENERAL", "1")
+    check_graph(synth.random_den_fst(1000, 5, 400, seed=3), 0)

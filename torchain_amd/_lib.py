@@ -58,6 +58,8 @@ def _load():
     L.tc_den_graph_prepare.argtypes = [vp, C.c_int]
     L.tc_den_graph_stats.restype = C.c_int
     L.tc_den_graph_stats.argtypes = [vp, vp]
+    L.tc_den_graph_debug_walk.restype = C.c_int
+    L.tc_den_graph_debug_walk.argtypes = [vp, C.c_int, vp, vp, vp]
     L.tc_supervision_create.restype = C.c_int
     L.tc_supervision_create.argtypes = [C.POINTER(vp), f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.tc_supervision_free.restype = None

@@ -1069,6 +1069,115 @@ int tc_den_graph_stats(const tc_den_graph *g, int64_t *o) {
   return TC_OK;
 }
 
+// Host-side replay of the schedules (diagnostic; never on the product path): performs one arc walk the
+// way the kernels consume the streams -- cell order, row-end masks, commit cursor, secondary rows and
+// fix-up lists, position permutation, per-state tables -- and returns per state
+//   direction 0: sum over in-arcs  (h -> g) of w * gather[h] * pdf_factor[pdf]
+//   direction 1: sum over out-arcs (h -> g) of w * gather[g] * pdf_factor[pdf]
+// so that tests without a GPU can compare the built schedules with the definition.
+int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *gather, const float *pdf_factor,
+                            float *out) {
+  if (!g || !gather || !pdf_factor || !out || direction < 0 || direction > 1) return TC_ERR_INVALID_ARGUMENT;
+  const int H = g->H;
+  if (g->big) {
+    const std::vector<int32_t> &begin = direction == 0 ? g->big_in_begin : g->big_out_begin;
+    const std::vector<BigArc> &arc = direction == 0 ? g->big_in : g->big_out;
+    for (int h = 0; h < H; ++h) {
+      float sum = 0.f;
+      for (int a = begin[h]; a < begin[h + 1]; ++a) sum += arc[a].w * gather[arc[a].a] * pdf_factor[arc[a].b];
+      out[h] = sum;
+    }
+    return TC_OK;
+  }
+  if (!g->layout_ok) return TC_ERR_UNSUPPORTED;
+  const ScheduleHost &sc = direction == 0 ? g->fwd : g->bwd;
+  const int Hs = g->layout.Hs;
+  std::vector<float> acc((size_t)g->layout.acc_floats + 64, 0.f);
+  if (g->tied) {
+    const int K = Hs / kThreads;
+    std::vector<float> src_pos((size_t)Hs + 4, 0.f);
+    for (int h = 0; h < H; ++h) {
+      const uint32_t fs = g->tied_fs[g->pos[h]];
+      src_pos[g->pos[h]] = direction == 0 ? gather[h] : gather[h] * pdf_factor[(fs & 0xffffu) >> 2];
+    }
+    for (int w = 0; w < kWaves; ++w) {
+      const int first = sc.wave_range[w].x, n = sc.wave_range[w].y;
+      for (int l = 0; l < 64; ++l) {
+        const int tid = 64 * w + l;
+        int k = 0;
+        float ax = 0.f, ay = 0.f;
+        auto slot = [&]() {
+          return k < K ? 4 * (tid + kThreads * (k >> 2)) + (k & 3) : Hs + 4 + 64 * (sc.extra_first[w] + (k - K)) + l;
+        };
+        auto cell = [&](int i, float *wgt, int *position) {
+          const size_t c = (size_t)first + i, chunk = c / 8, q = c % 8;
+          const uint32_t *base = &sc.cells6[chunk * 3 * 64 * 4];
+          uint32_t x = base[((q / 4) * 64 + l) * 4 + (q % 4)];
+          memcpy(wgt, &x, 4);
+          const uint32_t o = base[(2 * 64 + l) * 4 + q / 2];
+          *position = (int)(((q & 1) ? o >> 16 : o & 0xffffu) >> 2);
+        };
+        for (int i = 0; i < n; i += 2) {
+          float w0, w1;
+          int p0, p1;
+          cell(i, &w0, &p0);
+          cell(i + 1, &w1, &p1);
+          const uint32_t m = sc.masks[(size_t)w * sc.mask_stride + (i / 2) / 8];
+          const int bit = (i / 2) % 8;
+          if ((m >> (8 + bit)) & 1u) {  // the row ends with the pair's first cell
+            acc[slot()] = (ax + w0 * src_pos[p0]) + ay;
+            ++k;
+            ax = 0.f;
+            ay = w1 * src_pos[p1];
+          } else {
+            ax += w0 * src_pos[p0];
+            ay += w1 * src_pos[p1];
+          }
+          if ((m >> bit) & 1u) {
+            acc[slot()] = ax + ay;
+            ++k;
+            ax = ay = 0.f;
+          }
+        }
+      }
+    }
+    for (int t = 0; t < kThreads; ++t)
+      for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) acc[sc.fix[e].x] += acc[sc.fix[e].y];
+    for (int h = 0; h < H; ++h) {
+      const int p = g->pos[h];
+      const uint32_t fs = g->tied_fs[p];
+      const float self = pdf_factor[fs >> 18] * g->tied_w[p] * gather[h];
+      out[h] = direction == 0 ? pdf_factor[(fs & 0xffffu) >> 2] * acc[p] + self : acc[p] + self;
+    }
+    return TC_OK;
+  }
+  // general schedules: 8-byte cells [pair][lane][2] with in-band ROW cells
+  for (int w = 0; w < kWaves; ++w) {
+    const int first = sc.wave_range[w].x, n = sc.wave_range[w].y;
+    for (int l = 0; l < 64; ++l) {
+      int cur = Hs;  // dummy row
+      float a = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const size_t c = (size_t)first + i;
+        const ArcRec &r = sc.cells[((c >> 1) * 64 + l) * 2 + (c & 1)];
+        if (r.idx & kRowFlag) {
+          acc[cur] = a;
+          uint32_t x;
+          memcpy(&x, &r.w, 4);
+          cur = (int)(x & 0xffffu);
+          a = 0.f;
+        } else {
+          a += r.w * gather[std::min<uint32_t>(r.idx >> 18, (uint32_t)H - 1)] * pdf_factor[(r.idx >> 2) & 0x3fffu];
+        }
+      }
+    }
+  }
+  for (int t = 0; t < kThreads; ++t)
+    for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) acc[sc.fix[e].x] += acc[sc.fix[e].y];
+  for (int h = 0; h < H; ++h) out[h] = acc[h];
+  return TC_OK;
+}
+
 int tc_den_graph_prepare(tc_den_graph *g, int device) {
   if (!g) return TC_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lock(g->mu);

@@ -88,6 +88,17 @@ class DenominatorGraph:
         return dict(zip(keys, (int(x) for x in out)))
 
 
+    def debug_walk(self, direction, gather, pdf_factor):
+        """Diagnostic (host only): replays one arc walk from the built schedules, see
+        ``tc_den_graph_debug_walk``.  Used by the CPU tests of the schedule builder."""
+        gather = np.ascontiguousarray(gather, np.float32)
+        pdf_factor = np.ascontiguousarray(pdf_factor, np.float32)
+        out = np.zeros(lib.tc_den_graph_num_states(self.ptr), np.float32)
+        check(lib.tc_den_graph_debug_walk(self.ptr, int(direction), _p(gather), _p(pdf_factor), _p(out)),
+              "tc_den_graph_debug_walk")
+        return out
+
+
 class Supervision:
     """Reference ``io.py:20-31``: wraps a supervision handle and exposes ``n_pdf``, ``n_batch``,
     ``n_frame``, ``shape``.  A null handle raises ``ValueError`` exactly like the reference (its
