@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         const float4 b = make_float4(b4[j].x + bsum, b4[j].y + bsum, b4[j].z + bsum, b4[j].w + bsum);
         if (TIED) {
           bown[j] = b;
-          const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          const uint4 fs = bfs[j];
           *reinterpret_cast<float4 *>(A0 + h0) =
               make_float4(b.x * lds_at(PBnext, fs.x & 0xffffu), b.y * lds_at(PBnext, fs.y & 0xffffu),
                           b.z * lds_at(PBnext, fs.z & 0xffffu), b.w * lds_at(PBnext, fs.w & 0xffffu));
