@@ -387,20 +387,12 @@ __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncel
   uint32_t m = mk[0];
   if (RES == 2) {
     const uint32_t m1 = mk[1];
-    __builtin_amdgcn_s_setprio(3);
     process_chunk6<SRC_BASE>(ra, m, m >> 8, rc, acc);
     process_chunk6<SRC_BASE>(rb, m >> 4, m >> 12, rc, acc);
     m = m1;
   }
   for (int c = RES * kChunk; c < ncells; c += 2 * kChunk) {
-    if (4 * c < ncells)  // progress-based priority: see walk_rows
-      __builtin_amdgcn_s_setprio(3);
-    else if (2 * c < ncells)
-      __builtin_amdgcn_s_setprio(2);
-    else if (4 * c < 3 * ncells)
-      __builtin_amdgcn_s_setprio(1);
-    else
-      __builtin_amdgcn_s_setprio(0);
+    // (no s_setprio here: the progress-based priorities of the general walk cost 1 % on this one)
     load_chunk6(qb, r, c + kChunk);
     const uint32_t mnext = mk[(c >> 4) + 1];
     TC_WALK_WAIT
@@ -413,7 +405,6 @@ __device__ __forceinline__ void walk_rows6(const uint4 *__restrict__ r, int ncel
     TC_WALK_PROC
     m = mnext;
   }
-  __builtin_amdgcn_s_setprio(0);
 }
 
 // Tied graphs: per-state self-loop and forward-pdf terms, applied by the thread that owns the state.
