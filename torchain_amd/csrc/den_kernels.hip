@@ -69,9 +69,14 @@ __device__ __forceinline__ float block_sum(float v, float *red, int wave, int la
   v = wave_sum(v);
   if (lane == 0) red[wave] = v;
   __syncthreads();
-  float t = 0.f;
-#pragma unroll
-  for (int i = 0; i < kWaves; ++i) t += red[i];
+  // the 16 wave totals: one per lane of every row of 16 lanes, summed with four DPP adds (5 instructions
+  // instead of 8 LDS reads + 16 dependent adds; these reductions are on the per-frame critical path)
+  static_assert(kWaves == 16, "one DPP row holds the wave totals");
+  float t = red[lane & 15];
+  t = dpp_add<0xB1>(t);
+  t = dpp_add<0x4E>(t);
+  t = dpp_add<0x124>(t);
+  t = dpp_add<0x128>(t);
   return t;
 }
 
