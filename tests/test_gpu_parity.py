@@ -86,6 +86,12 @@ def test_tied_graph_partial_planes(oracle):
     one partly filled plane, and one full plane plus a partly filled one."""
     _check_full(oracle, synth.random_den_fst(1500, 3, 257, seed=21), 2, 7, l2=0.0, leaky=0.1)
     _check_full(oracle, synth.random_den_fst(5000, 3, 300, seed=22), 2, 5, l2=0.0, leaky=0.1)
+    # three and four planes: the <JV=4> instantiations (8193..16384 states), small and mid vocabularies
+    from torchain_amd import io
+    for H, P, seed in ((9000, 5000, 23), (14000, 2000, 24)):
+        fst = synth.random_den_fst(H, 3, P, seed=seed)
+        assert io.DenominatorGraph(fst, P).stats()["tied"] == 1
+        _check_full(oracle, fst, 2, 4, l2=1e-4, leaky=0.1)
 
 
 def test_tied_tight_layout_mid_vocab(oracle):

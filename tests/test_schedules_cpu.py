@@ -31,7 +31,8 @@ def check_graph(fst, expect_kind):
         assert np.abs(got - ref).max() <= 2e-6 * scale, (direction, np.abs(got - ref).max(), scale)
 
 
-@pytest.mark.parametrize("H,deg,P", [(3, 2, 5), (64, 4, 32), (1000, 5, 400), (4096, 3, 300), (5000, 3, 300)])
+@pytest.mark.parametrize("H,deg,P", [(3, 2, 5), (64, 4, 32), (1000, 5, 400), (4096, 3, 300), (5000, 3, 300), (9000, 3, 5000),
+                                     (14000, 3, 2000)])
 def test_tied_owner_schedules_replay(H, deg, P):
     check_graph(synth.random_den_fst(H, deg, P, seed=H + deg), 1)
 

@@ -23,7 +23,7 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
   L->Ps = round4(P);
   const int jv = (L->Hs / 4 + kThreads - 1) / kThreads, pv = (L->Ps / 4 + kThreads - 1) / kThreads;
   if (H > kMaxIndex || P > kMaxIndex) return false;  // 16-bit byte offsets in ArcRec
-  // the two kernel instantiations (den_kernels.hip): <JV=2, PV=1> and <JV=4, PV=3>
+  // the kernel instantiations (den_kernels.hip): JV in {2, 4} x PV in {1, 2, 3}
   if (jv <= kJvSmall && pv <= kPvSmall) {
     L->JV = kJvSmall;
     L->PV = kPvSmall;
@@ -33,6 +33,12 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
   } else if (jv <= kJvSmall && pv <= kPvLarge) {
     L->JV = kJvSmall;
     L->PV = kPvLarge;
+  } else if (jv <= kJvLarge && pv <= kPvSmall) {
+    L->JV = kJvLarge;
+    L->PV = kPvSmall;
+  } else if (jv <= kJvLarge && pv <= kPvMid) {
+    L->JV = kJvLarge;
+    L->PV = kPvMid;
   } else if (jv <= kJvLarge && pv <= kPvLarge) {
     L->JV = kJvLarge;
     L->PV = kPvLarge;

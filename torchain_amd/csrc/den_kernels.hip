@@ -896,6 +896,8 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   TC_DISPATCH(kJvSmall, kPvSmall)
   TC_DISPATCH(kJvSmall, kPvMid)
   TC_DISPATCH(kJvSmall, kPvLarge)
+  TC_DISPATCH(kJvLarge, kPvSmall)
+  TC_DISPATCH(kJvLarge, kPvMid)
   TC_DISPATCH(kJvLarge, kPvLarge)
 #undef TC_DISPATCH
   return TC_ERR_UNSUPPORTED;

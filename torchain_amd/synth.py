@@ -235,6 +235,9 @@ CONFIGS = {
     "C3": dict(S=256, T=150, P=4096, H=8192, degree=8, leaky=0.1, l2=5e-5),
     "C4": dict(S=2048, T=150, P=4096, H=8192, degree=8, leaky=0.1, l2=5e-5),
     "C5": dict(S=128, T=150, P=10240, H=8192, degree=7.5, leaky=0.1, l2=5e-5),
+    # not in BASELINE.json: a den graph of the size Kaldi recipes produce for a few-thousand-leaf tree
+    # (robustness / timing of the <JV=4> instantiation only)
+    "X1": dict(S=256, T=150, P=2928, H=14000, degree=15, leaky=0.1, l2=5e-5),
 }
 
 
