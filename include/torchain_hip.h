@@ -143,6 +143,19 @@ int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_outpu
  * layout and runs the streamed kernel, 0 for the general on-chip kernel). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
+/* ---- layout conversion either side of the path -------------------------- */
+
+/* Replaces `to2d` (torchain/functions.py:118-125: x.permute(2,0,1).contiguous().view(-1, C)):
+ * in_bct is a contiguous (B, C, T) device tensor, out2d[(t*B + b) * out_stride + c] = in_bct[b][c][t]. */
+int tc_to2d(const float *in_bct, int32_t B, int32_t C, int32_t T, float *out2d, int64_t out_stride, int device,
+            void *stream);
+
+/* The way back, fused with the sign / scale the reference applies in separate passes
+ * (torchain/functions.py:108-112: -mmi_grad, -xent_regularize * xent_grad, then autograd's inverse permute):
+ * out_bct[b][c][t] = scale * in2d[(t*B + b) * in_stride + c],  out_bct contiguous (B, C, T). */
+int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_t T, float scale, float *out_bct,
+              int device, void *stream);
+
 /* Diagnostic, host only: replays one arc walk from the graph's built schedules exactly as the kernels
  * consume them and returns, per state, direction 0: sum over in-arcs (h->g) of w*gather[h]*pdf_factor[pdf],
  * direction 1: sum over out-arcs (h->g) of w*gather[g]*pdf_factor[pdf]  (gather: num_states floats,

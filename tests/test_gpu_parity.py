@@ -286,3 +286,42 @@ def test_results_are_bitwise_reproducible():
     b = hip_den(fst, y, S, leaky=0.1, deriv_weight=-1.0, l2_scale=1e-4, graph=a["graph"])
     assert a["logprob"] == b["logprob"]
     assert np.array_equal(a["deriv"], b["deriv"])
+
+
+def test_fused_layout_kernels_match_torch_permute():
+    """tc_to2d / tc_from2d against the reference's own layout code (functions.py:118-125: permute(2,0,1)
+    .contiguous()); copies, so bit-exact; ragged channel counts and more frames than one tile."""
+    from torchain_amd.functions import from2d_hip, to2d, to2d_hip
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for B, C, T in ((3, 100, 17), (2, 64, 240), (5, 130, 241), (1, 1, 1), (4, 257, 500)):
+        x = torch.randn(B, C, T, device="cuda", generator=gen)
+        ref = to2d(x)
+        assert torch.equal(to2d_hip(x), ref)
+        back = from2d_hip(ref, (B, C, T), -0.5)
+        assert torch.equal(back, -0.5 * x)
+
+
+def test_chain_loss_3d_input_fused_path_matches_2d_path(oracle):
+    """chain_loss on a (B, C, T) tensor (fused layout passes) gives the loss and the input / xent-input
+    gradients of the reference composition to2d -> 2-D loss -> autograd's inverse permute, bit for bit."""
+    from torchain_amd import io
+    from torchain_amd.functions import _ChainLoss, ChainResults, chain_loss, to2d
+    fst = synth.random_den_fst(200, 5, 90, seed=13)
+    B, T, P = 4, 23, 90
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, B, T, 3, seed=4, initial_probs=g.initial_probs())
+    den, hsup = io.DenominatorGraph(fst, P), io.Supervision.from_synth(sup)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for kaldi_way in (True, False):
+        x = torch.randn(B, P, T, device="cuda", generator=gen).requires_grad_(True)
+        xe = torch.randn(B, P, T, device="cuda", generator=gen).requires_grad_(True)
+        loss, res = chain_loss(x, den, hsup, l2_regularize=1e-4, leaky_hmm_coefficient=0.05, xent_regularize=0.1,
+                               xent_input=xe, kaldi_way=kaldi_way)
+        loss.backward()
+        x2 = x.detach().clone().requires_grad_(True)
+        xe2 = xe.detach().clone().requires_grad_(True)
+        res2 = ChainResults()
+        loss2 = _ChainLoss.apply(to2d(x2), to2d(xe2), res2, den, hsup, 1e-4, 0.05, 0.1, kaldi_way)
+        loss2.backward()
+        assert torch.equal(res.data, res2.data) and torch.equal(loss, loss2)
+        assert torch.equal(x.grad, x2.grad) and torch.equal(xe.grad, xe2.grad)

@@ -60,6 +60,10 @@ def _load():
     L.tc_den_graph_stats.argtypes = [vp, vp]
     L.tc_den_graph_debug_walk.restype = C.c_int
     L.tc_den_graph_debug_walk.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.tc_to2d.restype = C.c_int
+    L.tc_to2d.argtypes = [vp, i32, i32, i32, vp, i64, C.c_int, vp]
+    L.tc_from2d.restype = C.c_int
+    L.tc_from2d.argtypes = [vp, i64, i32, i32, i32, f32, vp, C.c_int, vp]
     L.tc_supervision_create.restype = C.c_int
     L.tc_supervision_create.argtypes = [C.POINTER(vp), f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.tc_supervision_free.restype = None

@@ -245,4 +245,22 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
                              cols, stream);
 }
 
+int tc_to2d(const float *in_bct, int32_t B, int32_t Cn, int32_t T, float *out2d, int64_t out_stride, int device,
+            void *stream_v) {
+  if (!in_bct || !out2d || B <= 0 || Cn <= 0 || T <= 0 || out_stride < Cn) return TC_ERR_INVALID_ARGUMENT;
+  if (B > 65535 || (T + 239) / 240 > 65535) return TC_ERR_UNSUPPORTED;  // grid y / z limits
+  DeviceGuard guard(device);
+  if (!guard.ok) return TC_ERR_HIP;
+  return launch_layout(true, in_bct, out2d, B, Cn, T, out_stride, 1.0f, (hipStream_t)stream_v);
+}
+
+int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t Cn, int32_t T, float scale, float *out_bct,
+              int device, void *stream_v) {
+  if (!in2d || !out_bct || B <= 0 || Cn <= 0 || T <= 0 || in_stride < Cn) return TC_ERR_INVALID_ARGUMENT;
+  if (B > 65535 || (T + 239) / 240 > 65535) return TC_ERR_UNSUPPORTED;
+  DeviceGuard guard(device);
+  if (!guard.ok) return TC_ERR_HIP;
+  return launch_layout(false, in2d, out_bct, B, Cn, T, in_stride, scale, (hipStream_t)stream_v);
+}
+
 }  // extern "C"

@@ -249,6 +249,8 @@ int launch_zero_on_fail(const int32_t *fail_flag, float *a, int64_t a_stride, fl
 int launch_den_reduce(const double *den_lp, const float *ab, const float *gs, int S, double *logprob_out,
                       int32_t *status_out, hipStream_t stream);
 int launch_sum_double(const double *in, int n, double scale, double *out, hipStream_t stream);
+int launch_layout(bool to2d, const float *in, float *out, int B, int Cn, int T, int64_t stride2d, float scale,
+                  hipStream_t stream);
 
 extern thread_local int g_last_hip_error;
 #define TC_HIP_CHECK(expr)                        \

@@ -1,0 +1,63 @@
+// Layout conversion either side of the hot path: the reference's recipe hands
+// chain_loss a (B, C, T) tensor and torchain/functions.py:118-125 (`to2d`) turns it into frame-major rows
+// with x.permute(2,0,1).contiguous(); on the way back autograd undoes the permutation and
+// functions.py:112 negates the gradient -- three more passes over a 629 MB tensor at C3.  These two
+// kernels do the forward permutation in one pass and the backward permutation, the negation and the
+// xent scale in one pass.  Both are plain HBM-bound transposes through LDS: a workgroup moves a
+// [64 channels] x [<= 240 frames] tile of one sequence, reading and writing 256-byte (or longer) runs.
+#include "chain_internal.h"
+
+namespace tc {
+
+namespace {
+
+constexpr int kTileC = 64, kTileTMax = 240, kLayoutThreads = 512;
+
+// TO2D: in (B, C, T) contiguous -> out[(t*B + b) * out_stride + c];  !TO2D: the inverse, times `scale`
+template <bool TO2D>
+__global__ __launch_bounds__(kLayoutThreads) void layout_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                                int B, int Cn, int T, int64_t stride2d, float scale) {
+  extern __shared__ float tile[];  // kTileC x (frames of the tile | 1): sized by the launch, several blocks per CU
+  const int c0 = blockIdx.x * kTileC, b = blockIdx.y, t0 = blockIdx.z * kTileTMax;
+  const int tc = min(kTileTMax, T - t0), nc = min(kTileC, Cn - c0);
+  const int pitch = tc | 1;  // odd pitch: the transposed accesses are bank-conflict-free
+  const int tid = threadIdx.x;
+  const float *bct = TO2D ? in : out;  // the (B, C, T) side
+  (void)bct;
+  if (TO2D) {
+    // read runs of tc floats along t (for tc == T the whole tile is one contiguous block)
+    for (int idx = tid; idx < nc * tc; idx += kLayoutThreads) {
+      const int c = idx / tc, t = idx - c * tc;
+      tile[c * pitch + t] = in[((int64_t)b * Cn + c0 + c) * T + t0 + t];
+    }
+    __syncthreads();
+    const int cx = tid & (kTileC - 1);
+    for (int t = tid / kTileC; t < tc; t += kLayoutThreads / kTileC)
+      if (cx < nc) out[((int64_t)(t0 + t) * B + b) * stride2d + c0 + cx] = tile[cx * pitch + t];
+  } else {
+    const int cx = tid & (kTileC - 1);
+    for (int t = tid / kTileC; t < tc; t += kLayoutThreads / kTileC)
+      if (cx < nc) tile[cx * pitch + t] = in[((int64_t)(t0 + t) * B + b) * stride2d + c0 + cx];
+    __syncthreads();
+    for (int idx = tid; idx < nc * tc; idx += kLayoutThreads) {
+      const int c = idx / tc, t = idx - c * tc;
+      out[((int64_t)b * Cn + c0 + c) * T + t0 + t] = scale * tile[c * pitch + t];
+    }
+  }
+}
+
+}  // namespace
+
+int launch_layout(bool to2d, const float *in, float *out, int B, int Cn, int T, int64_t stride2d, float scale,
+                  hipStream_t stream) {
+  const dim3 grid((Cn + kTileC - 1) / kTileC, B, (T + kTileTMax - 1) / kTileTMax);
+  const size_t lds = sizeof(float) * kTileC * ((size_t)(T < kTileTMax ? T : kTileTMax) | 1);
+  if (to2d)
+    hipLaunchKernelGGL(layout_kernel<true>, grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
+  else
+    hipLaunchKernelGGL(layout_kernel<false>, grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+}  // namespace tc

@@ -6,7 +6,9 @@ Same names, argument meaning, defaults and quirks as the reference:
 * ``ChainResults.data`` is a CPU float tensor ``[objf, l2_term, weight]``; ``loss = -objf/weight``
   (l2 not included, ``functions.py:19``).
 * ``chain_loss`` accepts ``(B, C, T)`` or ``(T*B, C)`` input; 3-D input is permuted to frame-major
-  rows ``t*B + b`` (``functions.py:118-125``).
+  rows ``t*B + b`` (``functions.py:118-125``).  For CUDA float32 3-D inputs the permutation, its inverse
+  and the backward's negation / xent scale are single fused passes (``tc_to2d`` / ``tc_from2d``) with
+  identical values.
 * backward returns ``-mmi_grad`` for the input and ``-xent_regularize * xent_grad`` for
   ``xent_input``; ``grad_output`` is ignored and nothing is divided by ``weight``
   (``functions.py:106-115``).
@@ -114,6 +116,65 @@ class _ChainLoss(Function):
         return (-ctx.mmi_grad, xent_grad, None, None, None, None, None, None, None)
 
 
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def to2d_hip(x):
+    """(B, C, T) -> (T*B, C) in one pass (``tc_to2d``); same values as ``to2d``."""
+    B, Cn, T = x.shape
+    x = x.contiguous()
+    out = torch.empty(T * B, Cn, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.tc_to2d(_ptr(x), B, Cn, T, _ptr(out), out.stride(0), x.device.index, _stream(x.device)), "tc_to2d")
+    return out
+
+
+def from2d_hip(g2d, shape, scale):
+    """(T*B, C) -> scale * (B, C, T) in one pass (``tc_from2d``): inverse permutation fused with the
+    negation / xent scale of the reference's backward (``functions.py:108-112``)."""
+    B, Cn, T = shape
+    out = torch.empty(B, Cn, T, dtype=torch.float32, device=g2d.device)
+    with torch.cuda.device(g2d.device):
+        check(lib.tc_from2d(_ptr(g2d), g2d.stride(0), B, Cn, T, float(scale), _ptr(out), g2d.device.index,
+                            _stream(g2d.device)), "tc_from2d")
+    return out
+
+
+class _ChainLoss3d(Function):
+    """``_ChainLoss`` for ``(B, C, T)`` inputs with the layout conversions fused in: the
+    value and the gradients are those of ``_ChainLoss.apply(to2d(input), ...)`` followed by autograd's
+    inverse permute, without the three extra passes over the activation tensor."""
+
+    @staticmethod
+    def forward(ctx, input, xent_input, results, den_graph, supervision,
+                l2_regularize, leaky_hmm_coefficient, xent_regularize=0.0, kaldi_way=False):
+        assert input.is_cuda, "Only CUDA implementation is available"
+        x2d = to2d_hip(input.detach())
+        mmi_grad = torch.empty_like(x2d)
+        use_xent = xent_input is not None and xent_regularize != 0.0
+        xe2d = to2d_hip(xent_input.detach()) if use_xent else None
+        xent_grad = torch.empty_like(xe2d) if use_xent else None
+        compute_chain_objf_and_deriv(den_graph, supervision, x2d, results.data, mmi_grad, xent_grad,
+                                     l2_regularize, leaky_hmm_coefficient, xent_regularize)
+        if use_xent and not kaldi_way:  # the reference's second call (functions.py:96-103)
+            compute_chain_objf_and_deriv(den_graph, supervision, xe2d, results.data, mmi_grad, xent_grad,
+                                         l2_regularize, leaky_hmm_coefficient, xent_regularize)
+        ctx.mmi_grad = mmi_grad
+        ctx.in_shape = tuple(input.shape)
+        if use_xent:
+            ctx.xent_grad = xent_grad
+            ctx.xent_shape = tuple(xent_input.shape)
+            ctx.xent_scale = float(xent_regularize)
+        return input.new_tensor([float(results.loss)])
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        g = from2d_hip(ctx.mmi_grad, ctx.in_shape, -1.0)
+        xg = from2d_hip(ctx.xent_grad, ctx.xent_shape, -ctx.xent_scale) if hasattr(ctx, "xent_grad") else None
+        return (g, xg, None, None, None, None, None, None, None)
+
+
 def to2d(x):
     if x.dim() == 3:  # (B, C, T)
         n_pdf = x.shape[1]
@@ -122,14 +183,22 @@ def to2d(x):
     return x
 
 
+def _fusable(x):
+    return x.dim() == 3 and x.is_cuda and x.dtype == torch.float32
+
+
 def chain_loss(input, den_graph, supervision,
                l2_regularize=0.0, leaky_hmm_coefficient=1e-5,
                xent_regularize=0.0, xent_input=None, kaldi_way=False):
+    results = ChainResults()
+    if _fusable(input) and (xent_input is None or _fusable(xent_input)):
+        loss = _ChainLoss3d.apply(input, xent_input, results, den_graph, supervision,
+                                  l2_regularize, leaky_hmm_coefficient, xent_regularize, kaldi_way)
+        return loss, results
     input = to2d(input)
     if xent_input is not None:
         xent_input = to2d(xent_input)
 
-    results = ChainResults()
     loss = _ChainLoss.apply(input, xent_input, results, den_graph, supervision,
                             l2_regularize, leaky_hmm_coefficient, xent_regularize, kaldi_way)
     return loss, results
