@@ -63,3 +63,22 @@ def hip_den(fst, y, S, leaky=1e-5, deriv_weight=1.0, l2_scale=0.0, accumulate=Fa
     torch.cuda.synchronize()
     return dict(logprob=float(lp.item()), deriv=None if deriv is None else deriv.cpu().numpy(), status=int(st.item()),
                 graph=graph)
+
+
+def hip_num(sup, y, want_deriv=True, device="cuda:0"):
+    """Runs tc_num_forward_backward; returns dict(logprob_weighted, deriv)."""
+    hsup = io.Supervision.from_synth(sup)
+    rows, cols = y.shape
+    yt = torch.from_numpy(np.ascontiguousarray(y)).to(device)
+    deriv = torch.zeros(rows, cols, device=device) if want_deriv else None
+    nbytes = 256 * ((hsup.n_batch * 8 + 255) // 256) + 256
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    lp = torch.zeros(1, dtype=torch.float64, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = lib.tc_num_forward_backward(
+        hsup.ptr, C.c_void_p(yt.data_ptr()), rows, cols, yt.stride(0),
+        C.c_void_p(deriv.data_ptr()) if want_deriv else None, cols, C.c_void_p(lp.data_ptr()),
+        C.c_void_p(ws.data_ptr()), nbytes, torch.cuda.current_device(), C.c_void_p(stream))
+    check(rc, "tc_num_forward_backward")
+    torch.cuda.synchronize()
+    return dict(logprob_weighted=float(lp.item()), deriv=None if deriv is None else deriv.cpu().numpy())
