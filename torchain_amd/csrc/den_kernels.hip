@@ -485,22 +485,12 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   if (tid == 0) asum_h[0] = asum;
   float inv_prev = 1.0f / asum;
   float asum_prev = asum;
-  // tied graphs: the owned states' (f, s) offsets and self-loop weights stay in registers through the
-  // forward frames (the backward phase sets the register allocation; forward has room for them)
-  uint4 tfs[JV];
-  float4 tws[JV];
   int fwd_n = 0, bwd_n = 0;
   const uint4 *fwd_r = nullptr, *bwd_r = nullptr;
   const uint32_t *fwd_m = nullptr, *bwd_m = nullptr;
   RowCursor fwd_rc, bwd_rc;
   Pair6 fres0[kChunk / 2], fres1[kChunk / 2];  // forward stream, chunks 0 and 1: resident for the forward phase
   if (TIED) {
-#pragma unroll
-    for (int j = 0; j < JV; ++j) {
-      const int h0 = 4 * (tid + kThreads * j);
-      tfs[j] = owns(j, h0) ? *reinterpret_cast<const uint4 *>(p.tied_fs + h0) : make_uint4(0u, 0u, 0u, 0u);
-      tws[j] = owns(j, h0) ? *reinterpret_cast<const float4 *>(p.tied_w + h0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     fwd_r = walk6_base(p.fwd, wave, lane, fwd_n);
     load_chunk6(fres0, fwd_r, 0);
     load_chunk6(fres1, fwd_r, kChunk);
@@ -548,13 +538,8 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       if (owns(j, h0)) {
         float4 a = *reinterpret_cast<float4 *>(ACC + h0);
         if (TIED) {
-#ifdef TC_TFS_RESIDENT
-          const uint4 fs = tfs[j];
-          const float4 ws = tws[j];
-#else
           const uint4 fs = *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
           const float4 ws = *reinterpret_cast<const float4 *>(p.tied_w + h0);
-#endif
           const float4 al = *reinterpret_cast<float4 *>(A0 + h0);  // alpha'_t of the owned states
           a = make_float4(tied_alpha(PB, fs.x, ws.x, a.x, al.x), tied_alpha(PB, fs.y, ws.y, a.y, al.y),
                           tied_alpha(PB, fs.z, ws.z, a.z, al.z), tied_alpha(PB, fs.w, ws.w, a.w, al.w));
