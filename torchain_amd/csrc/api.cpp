@@ -18,7 +18,7 @@ namespace {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
-  float *big_expy, *big_beta;  // streamed path only
+  float *big_expy, *big_beta, *big_small;  // streamed path only
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
   float *ab, *gs;
@@ -29,17 +29,20 @@ struct Workspace {
 
 // Hs: stored states per frame of the alpha history (layout positions for tied graphs: build_owner)
 int hist_states(const tc_den_graph *g) { return g->tied ? g->layout.Hs : ((g->H + 3) & ~3); }
-int big_ps(const tc_den_graph *g) { return g->big ? ((g->P + 3) & ~3) : 0; }
+int big_p(const tc_den_graph *g) { return g->big ? g->P : 0; }
+int big_h(const tc_den_graph *g) { return g->big ? g->H : 0; }
 
-Workspace carve(char *base, int Hs, int S, int T, int big_Ps = 0) {
+// big_P != 0 selects the streamed path's layout: sequences padded to 64 lanes, [state][sequence] matrices
+Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0) {
   Workspace w;
+  const int Sp = (S + 63) & ~63;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char *p = base ? base + off : nullptr;
     off += align256(bytes);
     return p;
   };
-  w.alpha_hist = (float *)take((size_t)(T + 1) * S * Hs * sizeof(float));
+  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + 1) * S * Hs * sizeof(float));
   w.den_lp = (double *)take((size_t)S * 8);
   w.num_lp = (double *)take((size_t)S * 8);
   w.y2 = (double *)take((size_t)S * 8);
@@ -47,8 +50,9 @@ Workspace carve(char *base, int Hs, int S, int T, int big_Ps = 0) {
   w.gs = (float *)take((size_t)S * 4);
   w.fail = (int32_t *)take(256);
   w.scalar = (double *)take(4096);  // also the stamp area of diagnostic builds
-  w.big_expy = big_Ps ? (float *)take((size_t)S * big_Ps * sizeof(float)) : nullptr;
-  w.big_beta = big_Ps ? (float *)take((size_t)2 * S * Hs * sizeof(float)) : nullptr;
+  w.big_expy = big_P ? (float *)take((size_t)Sp * big_P * sizeof(float)) : nullptr;
+  w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
+  w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
   w.total = off;
   return w;
 }
@@ -96,6 +100,9 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->big = d.big;
   p->big_expy = w.big_expy;
   p->big_beta = w.big_beta;
+  p->big_small = w.big_small;
+  p->big_Sp = (S + 63) & ~63;
+  p->big_sum_pi = g->big_sum_pi;
   p->tied_fs = tied ? d.tied_fs : nullptr;
   p->tied_w = tied ? d.tied_w : nullptr;
   p->fwd = d.fwd;
@@ -158,7 +165,7 @@ extern "C" {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, hist_states(g), S, T, big_ps(g)).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g)).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -167,7 +174,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_ps(g));
+  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -210,7 +217,7 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_ps(g));
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;

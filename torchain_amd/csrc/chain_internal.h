@@ -90,13 +90,14 @@ struct ScheduleDev {
 };
 
 // ---- graphs too large for the on-chip layout ("streamed" path, den_big_kernel.hip) ------------------
-// alpha'/beta vectors stay in HBM/L2 and the transitions are plain CSR lists of 16-byte records, in
-// three orders: by destination (forward), by source (backward beta'), by pdf (backward gamma: one thread
-// per pdf sums its arcs, so the derivative row needs no atomics and the result is order-deterministic).
+// alpha / beta live in HBM/L2 as [state][sequence] matrices (lanes run over sequences) and the
+// transitions are plain CSR lists of 16-byte records, wave-uniform, in three orders: by destination
+// (forward), by source (backward beta'), by pdf (backward gamma: one wave per pdf sums its arcs, so the
+// derivative needs no atomics and the result is order-deterministic).
 struct BigArc {
   int32_t a, b;  // by destination: {src, pdf}; by source: {dst, pdf}; by pdf: {src, dst}
   float w;
-  int32_t pad;
+  float pi;      // initial probability of the arc's SOURCE state (alpha' = alpha + leaky*pi*asum on the fly)
 };
 
 struct BigDev {
@@ -144,8 +145,11 @@ struct DenParams {
   const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
   const float *tied_w;
   BigDev big;           // streamed path only
-  float *big_expy;      // [S][Ps]  exp(y_t) of the current frame
-  float *big_beta;      // [2][S][Hs]
+  float *big_expy;      // [P][Sp]  exp(y_t) of the current frame, transposed
+  float *big_beta;      // [2][H][Sp]
+  float *big_small;     // per-sequence sums and per-block partials (den_big_kernel.hip: BigSmall)
+  int big_Sp;           // sequences rounded up to a multiple of 64
+  float big_sum_pi;     // sum of the initial probabilities
   long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
 };
 
@@ -174,6 +178,7 @@ struct tc_den_graph {
   bool big = false;
   std::vector<int32_t> big_in_begin, big_out_begin, big_pdf_begin;
   std::vector<tc::BigArc> big_in, big_out, big_pdf;
+  float big_sum_pi = 0.f;
   std::mutex mu;
   std::map<int, tc::DenGraphDev> dev;
 };
@@ -240,6 +245,7 @@ int64_t layout_lds_bytes(const DenLayout &L, int T);
 
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
+int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
                     int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,

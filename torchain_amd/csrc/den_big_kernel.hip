@@ -1,43 +1,31 @@
-// Streamed denominator forward-backward: the fallback for graphs whose per-frame working set does not
-// fit one CU's LDS (more than 16384 states or pdfs, or a layout beyond 160 KB).
+// Streamed denominator forward-backward: the path for graphs whose per-frame working set does not fit
+// one CU's LDS (more than 16384 states or pdfs, or a layout beyond 160 KB) -- which includes many real
+// Kaldi den.fst files (tens of thousands of states, hundreds of thousands of arcs).
 //
 // Same computation as den_kernels.hip ([K] DenominatorComputation::Forward() + Backward(),
-// chain-denominator.cc; reference call site src/my_lib_chain.cpp:129-131), same mapping -- one
-// workgroup per sequence for all 2T frames -- but alpha' / beta / exp(y_t) live in global memory (they
-// are L2-sized: a few hundred KB per sequence) and the transitions are walked as plain CSR lists
-// (chain_internal.h: BigArc).  Per frame:
-//   forward : one thread per state sums its in-arcs in FST order (Kaldi's CPU order);
-//   backward: one thread per state sums its out-arcs (beta'), and one thread per PDF sums the arcs that
-//             carry it (gamma), so the derivative row is written once, without atomics, and the result
-//             does not depend on scheduling.
-// This path is about correctness on any graph, not about the roofline: arc records are fetched per
-// thread (uncoalesced, served by L2) and hub states serialise in one lane.
+// chain-denominator.cc; reference call site src/my_lib_chain.cpp:129-131), different mapping: with the
+// state vectors in HBM/L2 anyway, LANES RUN OVER SEQUENCES.  alpha / beta are stored [state][sequence]
+// and exp(y_t) is transposed to [pdf][sequence] once per frame, so
+//   * an arc record is the same for all 64 lanes of a wave: it arrives through the scalar cache, 16 bytes
+//     per 64 sequences (the on-chip kernels pay 6 bytes per arc per SEQUENCE);
+//   * every gather is a coalesced 256-byte row segment (64 sequences x 4 bytes) served by L2 / Infinity
+//     Cache -- the per-frame alpha matrix (H x S x 4 bytes) is a few tens of MB.
+// One launch per frame and pass (the frame recursion is a grid-wide dependency).  Sums over states use
+// per-block partials reduced by a second small kernel in a fixed order: no float atomics, results do not
+// depend on scheduling.  gamma is computed by one wave per pdf from a by-pdf arc list and transposed back
+// to the derivative's row-major layout through LDS.
+//
+// The history holds UN-dashed alpha_t and the per-frame sums; alpha'_t = alpha_t + leaky*pi*asum_t and
+// beta_t = beta'_t + bsum_t are formed on the fly by their consumers.
 #include "chain_internal.h"
 
 namespace tc {
 
 namespace {
 
-constexpr int kBigThreads = 1024;
-constexpr int kBigWaves = kBigThreads / 64;
-
-__device__ __forceinline__ float big_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// sum over the workgroup; ends with every thread past a barrier (global writes before it are visible)
-__device__ __forceinline__ float big_block_sum(float v, float *red, int slot) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  v = big_wave_sum(v);
-  if (lane == 0) red[slot * kBigWaves + wave] = v;
-  __syncthreads();
-  float t = 0.f;
-#pragma unroll
-  for (int i = 0; i < kBigWaves; ++i) t += red[slot * kBigWaves + i];
-  return t;
-}
+constexpr int kBT = 256;             // threads per block: 4 waves
+constexpr int kStatesPerBlock = 16;  // forward / backward kernels: 4 states per wave
+constexpr int kPdfsPerBlock = 64;    // gamma kernel: 16 pdfs per wave
 
 __device__ __forceinline__ float big_exp(float x) {
   x = x < -30.0f ? -30.0f : x;  // compare-and-clamp keeps NaN
@@ -45,166 +33,345 @@ __device__ __forceinline__ float big_exp(float x) {
   return __expf(x);
 }
 
-template <bool WANT_DERIV, bool ACCUM>
-__global__ __launch_bounds__(kBigThreads) void den_big_kernel(const DenParams p) {
-  extern __shared__ float lds[];
-  float *red = lds;                     // 8 reduction slots x 16 waves
-  float *asum_h = lds + 8 * kBigWaves;  // T + 1
-  const int tid = threadIdx.x, s = blockIdx.x;
-  const int S = p.S, T = p.T, H = p.H, P = p.P, Hs = p.L.Hs, Ps = p.L.Ps;
-  const BigDev g = p.big;
-  float *E = p.big_expy + (int64_t)s * Ps;
-  float *hist = p.alpha_hist + (int64_t)s * Hs;
-  const int64_t hist_step = (int64_t)S * Hs;
-  const float leaky = p.leaky;
-  int slot = 0;  // rotating reduction slot: a slot is rewritten only after a later barrier
+// small per-sequence arrays inside p.big_small, all with row length Sp
+struct BigSmall {
+  float *asum;       // [T + 1][Sp]
+  float *bsum;       // [2][Sp]      leaky * sum_h pi(h) beta'(h), frames t+1 / t alternate
+  float *inv_tot;    // [Sp]
+  float *ab, *gs;    // [Sp]  alpha'_0 . beta'_0 and sum_pdf gamma_0
+  float *part_a;     // [ceil(H / 16)][Sp]   also the backward's bsum partials
+  float *part_ab;    // [ceil(H / 16)][Sp]
+  float *part_g;     // [ceil(P / 64)][Sp]
+  float *part_y2;    // [ceil(P / 64)][Sp]  running sum of y^2 per pdf tile
+};
 
-  // ---- t = 0  ([K] AlphaFirstFrame + AlphaDash(0)), exp(y_0)
-  float part = 0.f;
-  for (int h = tid; h < H; h += kBigThreads) part += p.pi[h];
-  float asum = big_block_sum(part, red, slot++ & 7);
-  for (int h = tid; h < H; h += kBigThreads) {
-    const float pi = p.pi[h];
-    hist[h] = pi + leaky * pi * asum;
-  }
-  float y2 = 0.f;
-  {
-    const float *yrow = p.y + (int64_t)s * p.y_stride;
-    for (int i = tid; i < P; i += kBigThreads) {
-      const float yv = yrow[i];
-      y2 += yv * yv;
-      E[i] = big_exp(yv);
+__host__ __device__ inline BigSmall big_small(const DenParams &p) {
+  const int64_t Sp = p.big_Sp;
+  const int64_t hb = (p.H + kStatesPerBlock - 1) / kStatesPerBlock, pb = (p.P + kPdfsPerBlock - 1) / kPdfsPerBlock;
+  BigSmall s;
+  float *q = p.big_small;
+  s.asum = q;
+  q += (int64_t)(p.T + 1) * Sp;
+  s.bsum = q;
+  q += 2 * Sp;
+  s.inv_tot = q;
+  q += Sp;
+  s.ab = q;
+  q += Sp;
+  s.gs = q;
+  q += Sp;
+  s.part_a = q;
+  q += hb * Sp;
+  s.part_ab = q;
+  q += hb * Sp;
+  s.part_g = q;
+  q += pb * Sp;
+  s.part_y2 = q;
+  q += pb * Sp;
+  return s;
+}
+
+// expT[pdf][s] = exp(y[t*S + s][pdf]); padding lanes (s >= S) get exp(0)
+// SUM_SQ (forward pass): also accumulates sum(y^2) per sequence into this block's own slot of part_y2
+// (one block per (pdf tile, sequence group), launches are ordered: a plain read-modify-write)
+template <bool SUM_SQ>
+__global__ __launch_bounds__(kBT) void big_exp_kernel(const DenParams p, int t) {
+  __shared__ float tile[64][65];
+  __shared__ float sq[64][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
+  const int p0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
+  for (int sl = wave; sl < 64; sl += 4) {
+    const int s = s0 + sl, pdf = p0 + lane;
+    float v = 1.0f, y2 = 0.f;
+    if (s < p.S && pdf < p.P) {
+      const float yv = p.y[((int64_t)t * p.S + s) * p.y_stride + pdf];
+      v = big_exp(yv);
+      y2 = yv * yv;
     }
+    tile[sl][lane] = v;
+    if (SUM_SQ) sq[sl][lane] = y2;
   }
-  if (tid == 0) asum_h[0] = asum;
-  double logsum = 0.0;  // thread 0
-  float asum_prev = asum;
   __syncthreads();
-
-  // ---- forward frames  ([K] AlphaGeneralFrame(t) + AlphaDash(t))
-  for (int t = 1; t <= T; ++t) {
-    const float *prev = hist + (int64_t)(t - 1) * hist_step;
-    float *cur = hist + (int64_t)t * hist_step;
-    const float inv_prev = 1.0f / asum_prev;
-    part = 0.f;
-    for (int h = tid; h < H; h += kBigThreads) {
-      float sum = 0.f;
-      const int e = g.in_begin[h + 1];
-      for (int a = g.in_begin[h]; a < e; ++a) {
-        const BigArc r = g.in_arc[a];
-        sum += prev[r.a] * r.w * E[r.b];
-      }
-      const float v = sum * inv_prev;
-      cur[h] = v;
-      part += v;
-    }
-    asum = big_block_sum(part, red, slot++ & 7);  // every thread is past its reads of E and prev
-    float part_tot = 0.f;
-    for (int h = tid; h < H; h += kBigThreads) {
-      const float a = cur[h] + leaky * p.pi[h] * asum;
-      cur[h] = a;
-      part_tot += a;
-    }
-    if (t < T) {
-      const float *yrow = p.y + ((int64_t)t * S + s) * p.y_stride;
-      for (int i = tid; i < P; i += kBigThreads) {
-        const float yv = yrow[i];
-        y2 += yv * yv;
-        E[i] = big_exp(yv);
-      }
-    }
-    if (tid == 0) {
-      asum_h[t] = asum;
-      logsum += (double)__logf(asum_prev);
-    }
-    asum_prev = asum;
-    if (t == T) part = part_tot;
-    __syncthreads();
+  if (SUM_SQ && wave == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < 64; ++i) acc += sq[lane][i];  // sequence s0 + lane, this tile's 64 pdfs
+    float *slot = big_small(p).part_y2 + (int64_t)blockIdx.x * p.big_Sp + s0 + lane;
+    *slot = (t == 0 ? 0.f : *slot) + acc;
   }
-  // ---- total probability  ([K] ComputeTotLogLike)
-  const float tot = big_block_sum(part, red, slot++ & 7);
-  {
-    const double y2d = (double)big_block_sum(y2, red, slot++ & 7);
-    if (tid == 0) {
-      p.seq_logprob[s] = logsum + (double)__logf(tot);
-      p.seq_y2[s] = y2d;
+  for (int pl = wave; pl < 64; pl += 4) {
+    const int pdf = p0 + pl;
+    if (pdf < p.P) p.big_expy[(int64_t)pdf * p.big_Sp + s0 + lane] = tile[lane][pl];
+  }
+}
+
+// alpha_0 = pi for every sequence; asum_0 = sum(pi)   ([K] AlphaFirstFrame)
+__global__ __launch_bounds__(kBT) void big_alpha0_kernel(const DenParams p) {
+  const int64_t n = (int64_t)p.H * p.big_Sp;
+  const BigSmall sm = big_small(p);
+  for (int64_t i = (int64_t)blockIdx.x * kBT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBT)
+    p.alpha_hist[i] = p.pi[i / p.big_Sp];
+  if (blockIdx.x == 0)
+    for (int s = threadIdx.x; s < p.big_Sp; s += kBT) sm.asum[s] = p.big_sum_pi;
+}
+
+// sums a [rows][Sp] array of per-block partials over the rows, in a fixed order; 16 waves, each with
+// eight independent row loads in flight (a serial loop here cost more than the frame kernel it follows)
+constexpr int kRT = 1024, kRW = kRT / 64;
+__device__ __forceinline__ float big_colsum(const float *part, int rows, int Sp, int s, int wave, float (*red)[64],
+                                            int lane) {
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = wave; r < rows; r += 8 * kRW) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = r + u * kRW;
+      acc[u] += rr < rows ? part[(int64_t)rr * Sp + s] : 0.f;
     }
   }
-  if (!WANT_DERIV) return;
+  red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < kRW; ++w) t += red[w][lane];
+  __syncthreads();
+  return t;
+}
 
-  // ---- backward  ([K] BetaDashLastFrame, Beta(T), BetaDashGeneralFrame(t), Beta(t))
-  float *Bcur = p.big_beta + (int64_t)s * Hs;                        // beta_{t+1}
-  float *Bnext = p.big_beta + ((int64_t)S + s) * Hs;                 // beta'_t, then beta_t
-  const float inv_tot = 1.0f / tot;
-  part = 0.f;
-  for (int h = tid; h < H; h += kBigThreads) part += leaky * p.pi[h] * inv_tot;
-  float bsum = big_block_sum(part, red, slot++ & 7);
-  for (int h = tid; h < H; h += kBigThreads) Bcur[h] = inv_tot + bsum;
-  for (int t = T - 1; t >= 0; --t) {
-    const float *alpha = hist + (int64_t)t * hist_step;
-    const float *yrow = p.y + ((int64_t)t * S + s) * p.y_stride;
-    for (int i = tid; i < P; i += kBigThreads) E[i] = big_exp(yrow[i]);
-    __syncthreads();  // E, Bcur complete
-    const float inv_as = 1.0f / asum_h[t];
-    part = 0.f;
-    float part_ab = 0.f, part_g = 0.f;
-    for (int h = tid; h < H; h += kBigThreads) {
-      float sum = 0.f;
-      const int e = g.out_begin[h + 1];
-      for (int a = g.out_begin[h]; a < e; ++a) {
-        const BigArc r = g.out_arc[a];
-        sum += r.w * Bcur[r.a] * E[r.b];
-      }
-      const float bp = sum * inv_as;
-      Bnext[h] = bp;
-      part += leaky * p.pi[h] * bp;
-      if (t == 0) part_ab += alpha[h] * bp;
+// Sum over one CSR segment, kArcUnroll arcs at a time: the records (wave-uniform, scalar loads) and then
+// all the row segments of a group are requested before the first multiply, so a wave keeps 2 * kArcUnroll
+// 256-byte loads in flight instead of one dependent pair (the frame kernels are latency-bound otherwise).
+// Arcs are still accumulated in list order.  term(r) returns the arc's product for this lane.
+constexpr int kArcUnroll = 8;
+template <class Term>
+__device__ __forceinline__ float big_arc_sum(const BigArc *__restrict__ arcs, int e0, int e1, Term term) {
+  float sum = 0.f;
+  for (int a = e0; a < e1; a += kArcUnroll) {
+    BigArc r[kArcUnroll];
+#pragma unroll
+    for (int u = 0; u < kArcUnroll; ++u) {
+      r[u] = arcs[min(a + u, e1 - 1)];
+      if (a + u >= e1) r[u].w = 0.f;  // past the end: a repeat of the last arc with weight 0
     }
-    {
-      float *drow = p.deriv + ((int64_t)t * S + s) * p.deriv_stride;
-      for (int i = tid; i < P; i += kBigThreads) {
-        float sum = 0.f;
-        const int e = g.pdf_begin[i + 1];
-        for (int a = g.pdf_begin[i]; a < e; ++a) {
-          const BigArc r = g.pdf_arc[a];
-          sum += r.w * alpha[r.a] * Bcur[r.b];
-        }
-        const float gam = sum * E[i] * inv_as;
-        if (t == 0) part_g += gam;
-        float o = p.deriv_weight * gam - p.l2_scale * yrow[i];
-        if (ACCUM) o += drow[i];
-        drow[i] = o;
-      }
+    float v[kArcUnroll];
+#pragma unroll
+    for (int u = 0; u < kArcUnroll; ++u) v[u] = term(r[u]);
+#pragma unroll
+    for (int u = 0; u < kArcUnroll; ++u) sum += v[u];
+  }
+  return sum;
+}
+
+// forward frame t: alpha_t(h) = sum_in w * alpha'_{t-1}(src) * p_{t-1}(pdf) / asum_{t-1}   ([K] AlphaGeneralFrame)
+__global__ __launch_bounds__(kBT) void big_fwd_kernel(const DenParams p, int t) {
+  __shared__ float red[4][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
+  const int Sp = p.big_Sp, s = blockIdx.y * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const float *prev = p.alpha_hist + (int64_t)(t - 1) * p.H * Sp + s;
+  float *cur = p.alpha_hist + (int64_t)t * p.H * Sp + s;
+  const float *E = p.big_expy + s;
+  const float asum_prev = sm.asum[(int64_t)(t - 1) * Sp + s];
+  const float inv = 1.0f / asum_prev, cl_as = p.leaky * asum_prev;
+  float part = 0.f;
+  const int h0 = blockIdx.x * kStatesPerBlock + wave * (kStatesPerBlock / 4);
+  for (int k = 0; k < kStatesPerBlock / 4; ++k) {
+    const int h = h0 + k;
+    if (h >= p.H) break;
+    const int e0 = p.big.in_begin[h], e1 = p.big.in_begin[h + 1];
+    const float sum = big_arc_sum(p.big.in_arc, e0, e1, [&](const BigArc &r) {
+      return r.w * (prev[(int64_t)r.a * Sp] + cl_as * r.pi) * E[(int64_t)r.b * Sp];
+    });
+    const float v = sum * inv;
+    cur[(int64_t)h * Sp] = v;
+    part += v;
+  }
+  red[wave][lane] = part;
+  __syncthreads();
+  if (wave == 0) sm.part_a[(int64_t)blockIdx.x * Sp + s] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// asum_t = sum over states of alpha_t
+__global__ __launch_bounds__(kRT) void big_asum_kernel(const DenParams p, int t) {
+  __shared__ float red[kRW][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
+  const int Sp = p.big_Sp, s = blockIdx.x * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const int rows = (p.H + kStatesPerBlock - 1) / kStatesPerBlock;
+  const float tot = big_colsum(sm.part_a, rows, Sp, s, wave, red, lane);
+  if (wave == 0) sm.asum[(int64_t)t * Sp + s] = tot;
+}
+
+// log-prob, 1/tot and beta_T after the last forward frame; sum of y^2 per sequence from the tile partials
+__global__ __launch_bounds__(kBT) void big_total_kernel(const DenParams p) {
+  const int s = blockIdx.x * kBT + threadIdx.x;
+  if (s >= p.S) return;
+  const int Sp = p.big_Sp;
+  const BigSmall sm = big_small(p);
+  double y2 = 0.0;
+  const int pb = (p.P + kPdfsPerBlock - 1) / kPdfsPerBlock;
+  for (int b = 0; b < pb; ++b) y2 += (double)sm.part_y2[(int64_t)b * Sp + s];
+  p.seq_y2[s] = y2;
+  // tot = sum_h alpha'_T(h) = asum_T * (1 + leaky * sum(pi))   ([K] ComputeTotLogLike)
+  const float tot = sm.asum[(int64_t)p.T * Sp + s] * (1.0f + p.leaky * p.big_sum_pi);
+  double lp = (double)__logf(tot);
+  for (int t = 0; t < p.T; ++t) lp += (double)__logf(sm.asum[(int64_t)t * Sp + s]);
+  p.seq_logprob[s] = lp;
+  sm.inv_tot[s] = 1.0f / tot;
+  // beta'_T = 1/tot for every state; beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h)
+  sm.bsum[(p.T & 1) * Sp + s] = p.leaky * p.big_sum_pi * (1.0f / tot);
+}
+
+__global__ __launch_bounds__(kBT) void big_beta_init_kernel(const DenParams p) {
+  const int Sp = p.big_Sp;
+  const BigSmall sm = big_small(p);
+  float *B = p.big_beta + (int64_t)(p.T & 1) * p.H * Sp;
+  const int64_t n = (int64_t)p.H * Sp;
+  for (int64_t i = (int64_t)blockIdx.x * kBT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBT) {
+    const int s = (int)(i % Sp);
+    B[i] = s < p.S ? sm.inv_tot[s] : 0.f;
+  }
+  if (blockIdx.x == 0)  // padding lanes: defined values
+    for (int s = p.S + threadIdx.x; s < Sp; s += kBT) sm.bsum[(p.T & 1) * Sp + s] = 0.f;
+}
+
+// backward frame t: beta'_t(h) = sum_out w * beta_{t+1}(dst) * p_t(pdf) / asum_t   ([K] BetaDashGeneralFrame)
+__global__ __launch_bounds__(kBT) void big_bwd_kernel(const DenParams p, int t) {
+  __shared__ float red[2][4][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
+  const int Sp = p.big_Sp, s = blockIdx.y * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
+  float *Bcur = p.big_beta + (int64_t)(t & 1) * p.H * Sp + s;
+  const float *E = p.big_expy + s;
+  const float asum_t = sm.asum[(int64_t)t * Sp + s];
+  const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s];
+  const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
+  float part = 0.f, part_ab = 0.f;
+  const int h0 = blockIdx.x * kStatesPerBlock + wave * (kStatesPerBlock / 4);
+  for (int k = 0; k < kStatesPerBlock / 4; ++k) {
+    const int h = h0 + k;
+    if (h >= p.H) break;
+    const int e0 = p.big.out_begin[h], e1 = p.big.out_begin[h + 1];
+    const float sum = big_arc_sum(p.big.out_arc, e0, e1, [&](const BigArc &r) {
+      return r.w * (Bprev[(int64_t)r.a * Sp] + bs) * E[(int64_t)r.b * Sp];
+    });
+    const float bp = sum * inv_as;
+    Bcur[(int64_t)h * Sp] = bp;
+    const float cpi = p.leaky * p.pi[h];
+    part += cpi * bp;
+    if (t == 0) part_ab += (alpha[(int64_t)h * Sp] + cpi * asum_t) * bp;
+  }
+  red[0][wave][lane] = part;
+  red[1][wave][lane] = part_ab;
+  __syncthreads();
+  if (wave == 0) {
+    sm.part_a[(int64_t)blockIdx.x * Sp + s] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    if (t == 0)
+      sm.part_ab[(int64_t)blockIdx.x * Sp + s] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  }
+}
+
+// gamma_t(pdf) = p_t(pdf) / asum_t * sum over the arcs carrying pdf of w * alpha'_t(src) * beta_{t+1}(dst);
+// derivative row written through an LDS transpose   ([K] BetaDashGeneralFrame's log_nnet_output_deriv part)
+template <bool ACCUM>
+__global__ __launch_bounds__(kRT) void big_gamma_kernel(const DenParams p, int t) {
+  __shared__ float tile[64][65];
+  __shared__ float red[kRW][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
+  const int Sp = p.big_Sp, s0 = blockIdx.y * 64, s = s0 + lane;
+  const BigSmall sm = big_small(p);
+  const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
+  const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
+  const float *E = p.big_expy + s;
+  const float asum_t = sm.asum[(int64_t)t * Sp + s];
+  const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s], cl_as = p.leaky * asum_t;
+  const int p0 = blockIdx.x * kPdfsPerBlock;
+  float part_g = 0.f;
+  for (int k = 0; k < kPdfsPerBlock / kRW; ++k) {
+    const int pl = wave * (kPdfsPerBlock / kRW) + k, pdf = p0 + pl;
+    float gam = 0.f;
+    if (pdf < p.P) {
+      const int e0 = p.big.pdf_begin[pdf], e1 = p.big.pdf_begin[pdf + 1];
+      const float sum = big_arc_sum(p.big.pdf_arc, e0, e1, [&](const BigArc &r) {
+        return r.w * (alpha[(int64_t)r.a * Sp] + cl_as * r.pi) * (Bprev[(int64_t)r.b * Sp] + bs);
+      });
+      gam = sum * E[(int64_t)pdf * Sp] * inv_as;
     }
-    bsum = big_block_sum(part, red, slot++ & 7);  // all reads of Bcur done, all beta' written
-    if (t == 0) {
-      const float ab = big_block_sum(part_ab, red, slot++ & 7);
-      const float gs = big_block_sum(part_g, red, slot++ & 7);
-      if (tid == 0) {
-        p.seq_ab[s] = ab;
-        p.seq_gsum[s] = gs;
-      }
-      break;
+    tile[pl][lane] = gam;
+    part_g += gam;
+  }
+  red[wave][lane] = part_g;
+  __syncthreads();
+  if (t == 0 && wave == 0) {
+    float g = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRW; ++w) g += red[w][lane];
+    sm.part_g[(int64_t)blockIdx.x * Sp + s] = g;
+  }
+  const int pdf = p0 + lane;
+  for (int sl = wave; sl < 64; sl += kRW) {
+    const int sq = s0 + sl;
+    if (sq < p.S && pdf < p.P) {
+      const int64_t row = (int64_t)t * p.S + sq;
+      float o = p.deriv_weight * tile[lane][sl] - p.l2_scale * p.y[row * p.y_stride + pdf];
+      float *d = p.deriv + row * p.deriv_stride + pdf;
+      if (ACCUM) o += *d;
+      *d = o;
     }
-    for (int h = tid; h < H; h += kBigThreads) Bnext[h] += bsum;
-    float *tmp = Bcur;
-    Bcur = Bnext;
-    Bnext = tmp;
+  }
+}
+
+// bsum_t = leaky * sum_h pi(h) beta'_t(h); at t == 0 also the two checks of [K] BetaGeneralFrameDebug(0)
+__global__ __launch_bounds__(kRT) void big_bsum_kernel(const DenParams p, int t) {
+  __shared__ float red[kRW][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
+  const int Sp = p.big_Sp, s = blockIdx.x * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const int rows = (p.H + kStatesPerBlock - 1) / kStatesPerBlock;
+  const float b = big_colsum(sm.part_a, rows, Sp, s, wave, red, lane);
+  if (wave == 0) sm.bsum[(t & 1) * Sp + s] = b;
+  if (t == 0) {
+    const float ab = big_colsum(sm.part_ab, rows, Sp, s, wave, red, lane);
+    const float gs = big_colsum(sm.part_g, (p.P + kPdfsPerBlock - 1) / kPdfsPerBlock, Sp, s, wave, red, lane);
+    if (wave == 0 && s < p.S) {
+      p.seq_ab[s] = ab;
+      p.seq_gsum[s] = gs;
+    }
   }
 }
 
 }  // namespace
 
+// floats of p.big_small for this problem size (api.cpp sizes the workspace with it)
+int64_t big_small_floats(int H, int P, int T, int Sp) {
+  const int64_t hb = (H + kStatesPerBlock - 1) / kStatesPerBlock, pb = (P + kPdfsPerBlock - 1) / kPdfsPerBlock;
+  return ((int64_t)(T + 1) + 2 + 3 + 2 * hb + 2 * pb) * Sp;
+}
+
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream) {
-  const size_t lds = (size_t)(8 * kBigWaves + ((p.T + 1 + 3) & ~3)) * sizeof(float);
-  if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
-  void (*k)(const DenParams) = nullptr;
-  if (!p.deriv)
-    k = den_big_kernel<false, false>;
-  else
-    k = accumulate ? den_big_kernel<true, true> : den_big_kernel<true, false>;
-  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(p.S), dim3(kBigThreads), lds, stream, p);
+  const int Sp = p.big_Sp, sg = Sp / 64;
+  const dim3 blk(kBT);
+  const dim3 g_exp((p.P + 63) / 64, sg), g_states((p.H + kStatesPerBlock - 1) / kStatesPerBlock, sg);
+  const dim3 g_pdfs((p.P + kPdfsPerBlock - 1) / kPdfsPerBlock, sg);
+  const int fill_blocks = (int)std::min<int64_t>(4096, ((int64_t)p.H * Sp + kBT - 1) / kBT);
+  hipLaunchKernelGGL(big_alpha0_kernel, dim3(fill_blocks), blk, 0, stream, p);
+  for (int t = 1; t <= p.T; ++t) {
+    hipLaunchKernelGGL(big_exp_kernel<true>, g_exp, blk, 0, stream, p, t - 1);
+    hipLaunchKernelGGL(big_fwd_kernel, g_states, blk, 0, stream, p, t);
+    hipLaunchKernelGGL(big_asum_kernel, dim3(sg), dim3(kRT), 0, stream, p, t);
+  }
+  hipLaunchKernelGGL(big_total_kernel, dim3((p.S + kBT - 1) / kBT), blk, 0, stream, p);
+  if (p.deriv) {
+    hipLaunchKernelGGL(big_beta_init_kernel, dim3(fill_blocks), blk, 0, stream, p);
+    for (int t = p.T - 1; t >= 0; --t) {
+      hipLaunchKernelGGL(big_exp_kernel<false>, g_exp, blk, 0, stream, p, t);
+      hipLaunchKernelGGL(big_bwd_kernel, g_states, blk, 0, stream, p, t);
+      if (accumulate)
+        hipLaunchKernelGGL(big_gamma_kernel<true>, g_pdfs, dim3(kRT), 0, stream, p, t);
+      else
+        hipLaunchKernelGGL(big_gamma_kernel<false>, g_pdfs, dim3(kRT), 0, stream, p, t);
+      hipLaunchKernelGGL(big_bsum_kernel, dim3(sg), dim3(kRT), 0, stream, p, t);
+    }
+  }
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
 }

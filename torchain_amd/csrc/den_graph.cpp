@@ -799,13 +799,17 @@ static void build_big(tc_den_graph *g) {
     begin->assign(n + 1, 0);
     for (int64_t a = 0; a < A; ++a) (*begin)[key[a] + 1]++;
     for (int i = 0; i < n; ++i) (*begin)[i + 1] += (*begin)[i];
-    out->assign(std::max<int64_t>(A, 1), BigArc{0, 0, 0.f, 0});
+    out->assign(std::max<int64_t>(A, 1), BigArc{0, 0, 0.f, 0.f});
     std::vector<int32_t> fill(begin->begin(), begin->end() - 1);
-    for (int64_t a = 0; a < A; ++a) (*out)[fill[key[a]]++] = BigArc{fa[a], fb[a], g->arc_prob[a], 0};  // FST arc order kept
+    for (int64_t a = 0; a < A; ++a)  // FST arc order kept
+      (*out)[fill[key[a]]++] = BigArc{fa[a], fb[a], g->arc_prob[a], g->initial_probs[g->arc_src[a]]};
   };
   csr(H, g->arc_dst, &g->big_in_begin, &g->big_in, g->arc_src, g->arc_pdf);
   csr(H, g->arc_src, &g->big_out_begin, &g->big_out, g->arc_dst, g->arc_pdf);
   csr(P, g->arc_pdf, &g->big_pdf_begin, &g->big_pdf, g->arc_src, g->arc_dst);
+  float sum_pi = 0.f;
+  for (int h = 0; h < H; ++h) sum_pi += g->initial_probs[h];
+  g->big_sum_pi = sum_pi;
 }
 
 int build_schedules(tc_den_graph *g) {

@@ -238,6 +238,8 @@ CONFIGS = {
     # not in BASELINE.json: a den graph of the size Kaldi recipes produce for a few-thousand-leaf tree
     # (robustness / timing of the <JV=4> instantiation only)
     "X1": dict(S=256, T=150, P=2928, H=14000, degree=15, leaky=0.1, l2=5e-5),
+    # beyond the on-chip layouts: the streamed (sequence-minor) kernels
+    "X2": dict(S=256, T=150, P=4096, H=40000, degree=10, leaky=0.1, l2=5e-5),
 }
 
 
