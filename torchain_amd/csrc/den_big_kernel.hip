@@ -80,16 +80,21 @@ __global__ __launch_bounds__(kBT) void big_exp_kernel(const DenParams p, int t) 
   __shared__ float sq[64][65];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index: scalar
   const int p0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
-  for (int sl = wave; sl < 64; sl += 4) {
-    const int s = s0 + sl, pdf = p0 + lane;
-    float v = 1.0f, y2 = 0.f;
-    if (s < p.S && pdf < p.P) {
-      const float yv = p.y[((int64_t)t * p.S + s) * p.y_stride + pdf];
-      v = big_exp(yv);
-      y2 = yv * yv;
+  {
+    // all 16 row loads of a wave first (one round trip instead of sixteen), then exp and the LDS stores
+    float yv[16];
+    const int pdf = p0 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int s = s0 + wave + 4 * i;
+      yv[i] = (s < p.S && pdf < p.P) ? p.y[((int64_t)t * p.S + s) * p.y_stride + pdf] : 0.f;
     }
-    tile[sl][lane] = v;
-    if (SUM_SQ) sq[sl][lane] = y2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int sl = wave + 4 * i;
+      tile[sl][lane] = big_exp(yv[i]);
+      if (SUM_SQ) sq[sl][lane] = yv[i] * yv[i];
+    }
   }
   __syncthreads();
   if (SUM_SQ && wave == 0) {
