@@ -55,6 +55,15 @@ def test_ragged_small_shapes(oracle, H, deg, P, S, T):
     _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
 
 
+@pytest.mark.parametrize("force", ["TC_FORCE_BIG", "TC_FORCE_GENERAL"])
+@pytest.mark.parametrize("H,deg,P,S,T", [(1, 1, 1, 1, 2), (7, 3, 5, 1, 1), (130, 4, 77, 3, 9), (70, 3, 65, 65, 3)])
+def test_ragged_small_shapes_other_kernels(oracle, monkeypatch, force, H, deg, P, S, T):
+    """The same odd sizes through the streamed kernels (sequence counts that are not a multiple of the 64
+    lanes included) and through the general on-chip kernel."""
+    monkeypatch.setenv(force, "1")
+    _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
+
+
 def test_unaligned_row_stride(oracle):
     """Row stride > num_pdfs and not a multiple of 4: the C ABI takes (rows, cols, row_stride)
     like common::make_matrix (src/common.hpp:109-117)."""
