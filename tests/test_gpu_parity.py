@@ -114,6 +114,16 @@ def test_tied_tight_layout_mid_vocab(oracle):
     _check_full(oracle, synth.random_den_fst(3000, 4, 6000, seed=42), 3, 7, l2=0.0, leaky=0.05)
 
 
+def test_nearly_tied_graph_state_splitting(oracle):
+    """States entered through several pdfs are split into one copy per pdf (exact) so that the graph stays
+    on the tied kernel; compared with the oracle run on the ORIGINAL graph."""
+    from torchain_amd import io
+    fst = synth.nearly_tied_den_fst(700, 5, 150, seed=15, fraction=0.05)
+    assert io.DenominatorGraph(fst, fst.num_pdfs).stats()["tied"] == 1
+    _check_full(oracle, fst, 3, 12, l2=1e-4, leaky=0.1)
+    _check_full(oracle, synth.nearly_tied_den_fst(64, 4, 20, seed=6, fraction=0.3), 2, 9, l2=0.0, leaky=1e-5)
+
+
 def test_streamed_path_for_graphs_beyond_lds(oracle, monkeypatch):
     """Graphs the on-chip layouts cannot hold (more than 16384 states here) take the streamed kernel
     (alpha/beta in global memory); the same kernel forced onto small graphs, tied and general, must agree

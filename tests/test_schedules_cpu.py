@@ -65,3 +65,19 @@ def test_streamed_tables_replay(monkeypatch):
 def test_forced_general_matches_tied(monkeypatch):
     monkeypatch.setenv("TC_FORCE_GENERAL", "1")
     check_graph(synth.random_den_fst(1000, 5, 400, seed=3), 0)
+
+
+def test_nearly_tied_graphs_are_split_not_demoted(monkeypatch):
+    """A few states entered through several pdfs: the builder splits them (exactly) and keeps the graph on
+    the tied kernel; with splitting disabled the same graph takes the general path."""
+    fst = synth.nearly_tied_den_fst(2000, 6, 300, seed=5)
+    check_graph(fst, 1)
+    fst2 = synth.nearly_tied_den_fst(64, 4, 20, seed=6, fraction=0.3)
+    check_graph(fst2, 1)
+    monkeypatch.setenv("TC_NO_SPLIT", "1")
+    check_graph(fst, 0)
+
+
+def test_arbitrary_labelings_are_not_split():
+    """Random arc labels are not a chain graph: splitting would multiply the states; general path."""
+    check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 0)

@@ -170,7 +170,14 @@ struct tc_den_graph {
   bool tied = false;
   std::vector<uint32_t> tied_fs;      // position order once build_owner has run
   std::vector<float> tied_w;
-  std::vector<int32_t> pos;           // tied graphs: state -> LDS position (see build_owner)
+  // The graph the tied schedules are built from: the FST itself, or -- when a few states are entered
+  // through arcs of more than one pdf -- its "tied-ified" version in which such a state is split into one
+  // copy per entering pdf (den_graph.cpp: make_work_graph).  copy_first[h] .. copy_first[h+1] are the work
+  // states of FST state h; work_H == H and copy_first[h] == h when nothing was split.
+  int32_t work_H = 0;
+  std::vector<int32_t> work_src, work_dst, work_pdf, copy_first;
+  std::vector<float> work_prob, work_pi;
+  std::vector<int32_t> pos;           // tied graphs: WORK state -> LDS position (see build_owner)
   std::vector<float> pi_pos;          // initial probs in position order
   tc::DenLayout layout;
   bool layout_ok = false;

@@ -500,17 +500,17 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
 // Returns false when the graph cannot use the owner-computes kernel (too many states for the 16-bit
 // offsets or the working set does not fit LDS); the caller then falls back to the general kernel.
 static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
-  const int H = g->H;
+  const int H = g->work_H;  // states of the work graph (tc_den_graph::work_*)
   const int Npos = 4096 * ((H + 4095) / 4096);
   if (Npos > kMaxIndex) return false;
   const int K = Npos / kThreads;
   std::vector<int32_t> src, dst;
   std::vector<float> prob;
-  for (int64_t a = 0; a < g->A; ++a)
+  for (int64_t a = 0; a < (int64_t)g->work_src.size(); ++a)
     if (!special[a]) {
-      src.push_back(g->arc_src[a]);
-      dst.push_back(g->arc_dst[a]);
-      prob.push_back(g->arc_prob[a]);
+      src.push_back(g->work_src[a]);
+      dst.push_back(g->work_dst[a]);
+      prob.push_back(g->work_prob[a]);
     }
   const int64_t A2 = (int64_t)src.size();
   auto sort_by = [&](const std::vector<int32_t> &key, std::vector<int64_t> *first, std::vector<int64_t> *order) {
@@ -783,10 +783,120 @@ static bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   for (int h = 0; h < H; ++h) {
     fs[g->pos[h]] = g->tied_fs[h];
     ws[g->pos[h]] = g->tied_w[h];
-    g->pi_pos[g->pos[h]] = g->initial_probs[h];
+    g->pi_pos[g->pos[h]] = g->work_pi[h];
   }
   g->tied_fs.swap(fs);
   g->tied_w.swap(ws);
+  return true;
+}
+
+// Is the work graph tied?  Per state g: every non-self-loop in-arc carries one pdf f(g); self-loops that
+// also carry f(g) are ordinary members of that class; at most one further self-loop (pdf s(g)) is
+// "special" and is applied by the thread that owns g instead of travelling in the schedules.  Fills
+// special[] and the per-state tables tied_fs / tied_w (work-state order).
+static bool detect_tied(tc_den_graph *g, std::vector<char> *special) {
+  const int H = g->work_H;
+  const int64_t A = (int64_t)g->work_src.size();
+  special->assign(A, 0);
+  std::vector<int32_t> fpdf(H, -1), spdf(H, -1);
+  std::vector<float> wself(H, 0.f);
+  for (int64_t a = 0; a < A; ++a) {
+    const int s = g->work_src[a], d = g->work_dst[a], p = g->work_pdf[a];
+    if (s == d) continue;
+    if (fpdf[d] >= 0 && fpdf[d] != p) return false;
+    fpdf[d] = p;
+  }
+  for (int64_t a = 0; a < A; ++a) {
+    const int s = g->work_src[a], d = g->work_dst[a], p = g->work_pdf[a];
+    if (s != d) continue;
+    if (fpdf[d] >= 0 && p == fpdf[d]) continue;  // forward class
+    if (spdf[d] < 0) {
+      spdf[d] = p;
+      wself[d] = g->work_prob[a];
+      (*special)[a] = 1;
+    } else if (fpdf[d] < 0) {
+      fpdf[d] = p;
+    } else {
+      return false;
+    }
+  }
+  const int Hs = round4(H);
+  g->tied_fs.assign(Hs + 4, 0u);
+  g->tied_w.assign(Hs + 4, 0.f);
+  for (int h = 0; h < H; ++h) {
+    g->tied_fs[h] = (uint32_t)(std::max(fpdf[h], 0) * 4) | ((uint32_t)(std::max(spdf[h], 0) * 4) << 16);
+    g->tied_w[h] = wself[h];
+  }
+  return true;
+}
+
+// Tied-ification.  Real chain graphs are tied except where minimisation merged two phone instances with
+// the same self-loop pdf and future but different forward pdfs (LM back-off); one such state would send
+// the whole graph to the general kernel.  Splitting state g into one copy per pdf that enters it is
+// exact: the copies share g's out-arcs (and its special self-loop), so their futures are identical,
+// beta(copy) = beta(g), alpha(g) = sum of the copies' alphas, and pi(g) may sit on any one of them.
+// Every arc h -> g is replicated from every copy of h.  Returns false (graph left untouched) when the
+// split graph would be more than 1.5x the states or 2x the arcs: arbitrary labelings are not chain graphs.
+static bool make_work_graph(tc_den_graph *g) {
+  const int H = g->H;
+  const int64_t A = g->A;
+  // classes of a state: pdfs of its non-self-loop in-arcs, plus self-loop pdfs beyond the first new one
+  std::vector<std::vector<int32_t>> cls(H);
+  std::vector<int32_t> spdf(H, -1);
+  auto has = [](const std::vector<int32_t> &v, int32_t x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+  for (int64_t a = 0; a < A; ++a)
+    if (g->arc_src[a] != g->arc_dst[a] && !has(cls[g->arc_dst[a]], g->arc_pdf[a])) {
+      if (cls[g->arc_dst[a]].size() >= 64) return false;
+      cls[g->arc_dst[a]].push_back(g->arc_pdf[a]);
+    }
+  std::vector<char> is_special(A, 0);
+  for (int64_t a = 0; a < A; ++a) {
+    const int h = g->arc_src[a], p = g->arc_pdf[a];
+    if (h != g->arc_dst[a] || has(cls[h], p)) continue;
+    if (spdf[h] < 0 || spdf[h] == p) {
+      if (spdf[h] == p) return false;  // two self-loops with one pdf: keep it simple, general path
+      spdf[h] = p;
+      is_special[a] = 1;
+    } else {
+      cls[h].push_back(p);
+    }
+  }
+  std::vector<int32_t> first(H + 1, 0);
+  for (int h = 0; h < H; ++h) first[h + 1] = first[h] + std::max<int>(1, (int)cls[h].size());
+  const int WH = first[H];
+  if (WH == H) return false;  // nothing to split: the graph failed the tied test for another reason
+  if (WH > H + H / 2 + 64) return false;
+  std::vector<int32_t> ws, wd, wp;
+  std::vector<float> ww;
+  for (int64_t a = 0; a < A; ++a) {
+    const int h = g->arc_src[a], d = g->arc_dst[a], p = g->arc_pdf[a];
+    const int nh = first[h + 1] - first[h];
+    if (is_special[a]) {
+      for (int c = 0; c < nh; ++c) {
+        ws.push_back(first[h] + c);
+        wd.push_back(first[h] + c);
+        wp.push_back(p);
+        ww.push_back(g->arc_prob[a]);
+      }
+      continue;
+    }
+    const int target = first[d] + (int)(std::find(cls[d].begin(), cls[d].end(), p) - cls[d].begin());
+    for (int c = 0; c < nh; ++c) {
+      ws.push_back(first[h] + c);
+      wd.push_back(target);
+      wp.push_back(p);
+      ww.push_back(g->arc_prob[a]);
+    }
+    if ((int64_t)ws.size() > 2 * A + 1024) return false;
+  }
+  g->work_H = WH;
+  g->work_src.swap(ws);
+  g->work_dst.swap(wd);
+  g->work_pdf.swap(wp);
+  g->work_prob.swap(ww);
+  g->work_pi.assign(WH, 0.f);
+  for (int h = 0; h < H; ++h) g->work_pi[first[h]] = g->initial_probs[h];
+  g->copy_first = first;
   return true;
 }
 
@@ -821,45 +931,20 @@ int build_schedules(tc_den_graph *g) {
     build_big(g);
     return TC_OK;
   }
-  // ---- is the graph tied?  (see tc_den_graph::tied)
-  // Per state g: every non-self-loop in-arc carries one pdf f(g); self-loops that also carry f(g) are
-  // ordinary members of that class; at most one further self-loop (pdf s(g)) is "special" and is applied
-  // by the thread that owns g instead of travelling in the schedules.
-  std::vector<char> special(g->A, 0);
+  // ---- the tied path: on the FST as it is, or on its tied-ified work graph
+  std::vector<char> special;
   {
-    const int H = g->H;
-    std::vector<int32_t> fpdf(H, -1), spdf(H, -1);
-    std::vector<float> wself(H, 0.f);
-    bool tied = true;
-    for (int64_t a = 0; a < g->A && tied; ++a) {
-      const int s = g->arc_src[a], d = g->arc_dst[a], p = g->arc_pdf[a];
-      if (s == d) continue;
-      if (fpdf[d] >= 0 && fpdf[d] != p) tied = false;
-      fpdf[d] = p;
-    }
-    for (int64_t a = 0; a < g->A && tied; ++a) {
-      const int s = g->arc_src[a], d = g->arc_dst[a], p = g->arc_pdf[a];
-      if (s != d) continue;
-      if (fpdf[d] >= 0 && p == fpdf[d]) continue;  // forward class
-      if (spdf[d] < 0) {
-        spdf[d] = p;
-        wself[d] = g->arc_prob[a];
-        special[a] = 1;
-      } else if (fpdf[d] < 0) {
-        fpdf[d] = p;
-      } else {
-        tied = false;
-      }
-    }
-    if (getenv("TC_FORCE_GENERAL")) tied = false;
+    g->work_H = g->H;
+    g->work_src = g->arc_src;
+    g->work_dst = g->arc_dst;
+    g->work_pdf = g->arc_pdf;
+    g->work_prob = g->arc_prob;
+    g->work_pi = g->initial_probs;
+    g->copy_first.resize(g->H + 1);
+    std::iota(g->copy_first.begin(), g->copy_first.end(), 0);
+    bool tied = !getenv("TC_FORCE_GENERAL") && detect_tied(g, &special);
+    if (!tied && !getenv("TC_FORCE_GENERAL") && !getenv("TC_NO_SPLIT") && make_work_graph(g)) tied = detect_tied(g, &special);
     g->tied = tied;
-    g->tied_fs.assign(Hs + 4, 0u);
-    g->tied_w.assign(Hs + 4, 0.f);
-    if (tied)
-      for (int h = 0; h < H; ++h) {
-        g->tied_fs[h] = (uint32_t)(std::max(fpdf[h], 0) * 4) | ((uint32_t)(std::max(spdf[h], 0) * 4) << 16);
-        g->tied_w[h] = wself[h];
-      }
   }
   if (g->tied) {
     if (build_owner(g, special)) {
@@ -1106,10 +1191,14 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   if (g->tied) {
     const int K = Hs / kThreads;
     std::vector<float> src_pos((size_t)Hs + 4, 0.f);
-    for (int h = 0; h < H; ++h) {
-      const uint32_t fs = g->tied_fs[g->pos[h]];
-      src_pos[g->pos[h]] = direction == 0 ? gather[h] : gather[h] * pdf_factor[(fs & 0xffffu) >> 2];
-    }
+    // a split state's alpha is the sum of its copies' (forward: the first copy carries the value), its
+    // beta is shared by all copies (backward: every copy presents it)
+    for (int h = 0; h < H; ++h)
+      for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
+        const uint32_t fs = g->tied_fs[g->pos[c]];
+        src_pos[g->pos[c]] = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f)
+                                            : gather[h] * pdf_factor[(fs & 0xffffu) >> 2];
+      }
     for (int w = 0; w < kWaves; ++w) {
       const int first = sc.wave_range[w].x, n = sc.wave_range[w].y;
       for (int l = 0; l < 64; ++l) {
@@ -1154,10 +1243,19 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
     for (int t = 0; t < kThreads; ++t)
       for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) acc[sc.fix[e].x] += acc[sc.fix[e].y];
     for (int h = 0; h < H; ++h) {
-      const int p = g->pos[h];
-      const uint32_t fs = g->tied_fs[p];
-      const float self = pdf_factor[fs >> 18] * g->tied_w[p] * gather[h];
-      out[h] = direction == 0 ? pdf_factor[(fs & 0xffffu) >> 2] * acc[p] + self : acc[p] + self;
+      float sum = 0.f;
+      for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
+        const int p = g->pos[c];
+        const uint32_t fs = g->tied_fs[p];
+        const float self = pdf_factor[fs >> 18] * g->tied_w[p] * (direction == 0 && c != g->copy_first[h] ? 0.f : gather[h]);
+        const float v = direction == 0 ? pdf_factor[(fs & 0xffffu) >> 2] * acc[p] + self : acc[p] + self;
+        if (direction == 1) {  // every copy computes the state's out-sum: take the first
+          sum = v;
+          break;
+        }
+        sum += v;
+      }
+      out[h] = sum;
     }
     return TC_OK;
   }

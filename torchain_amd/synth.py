@@ -115,6 +115,25 @@ def skewed_tied_den_fst(num_states, num_arcs, num_pdfs, seed=5, hub_fraction=0.0
     return DenFst(H, src, dst, (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), final, 0, P)
 
 
+def nearly_tied_den_fst(num_states, out_degree, num_pdfs, seed=42, fraction=0.03):
+    """A chain-structured graph (``random_den_fst``) in which a few states are entered through arcs of two
+    or three different pdfs and a few carry a second self-loop -- what minimisation produces in a real
+    den.fst when two phone instances with equal futures but different forward pdfs are merged.  Exercises
+    the state splitting ("tied-ification") of the schedule builder."""
+    fst = random_den_fst(num_states, out_degree, num_pdfs, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    lab = fst.ilabel.copy()
+    H = fst.num_states
+    odd = rng.choice(H, max(1, int(H * fraction)), replace=False)
+    for g in odd:
+        arcs = np.nonzero((fst.dst == g) & (fst.src != g))[0]
+        if len(arcs) >= 2:
+            k = rng.integers(1, min(3, len(arcs)))
+            pick = rng.choice(arcs, k, replace=False)
+            lab[pick] = rng.integers(1, num_pdfs + 1, size=k)
+    return DenFst(H, fst.src, fst.dst, lab.astype(np.int32), fst.weight, fst.final, 0, num_pdfs)
+
+
 def initial_probs_f64(fst, num_iters=100):
     """Plain float64 numpy version of the 100-iteration initial-prob estimate (used only to weight
     the synthetic numerator's first arcs and to cross-check the oracle)."""
