@@ -6,4 +6,4 @@ cd "$(dirname "$0")/../torchain_amd/csrc"
 name=$1; shift
 mkdir -p ../../scratch_abl
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -w -I../../include --offload-arch=gfx950 -munsafe-fp-atomics "$@" -c den_kernels.hip -o /tmp/den_kernels_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_abl/lib_$name.so den_graph.o supervision.o api.o /tmp/den_kernels_$name.o den_big_kernel.o num_kernels.o layout_kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_abl/lib_$name.so den_graph.o den_layout.o schedule_general.o schedule_owner.o supervision.o api.o /tmp/den_kernels_$name.o den_big_kernel.o num_kernels.o layout_kernels.o
