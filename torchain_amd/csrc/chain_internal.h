@@ -53,7 +53,7 @@ struct ArcRec {
 // state; each further chunk of a longer list gets a private slot >= Hs + 4, and the thread that owns
 // the state folds those slots in before it reads the sum ("fix-up" list, sorted by owner thread).
 //
-// TIED graphs use owner-computes schedules instead (den_graph.cpp: build_owner): states are permuted so
+// TIED graphs use owner-computes schedules instead (schedule_owner.cpp: build_owner): states are permuted so
 // that the thread owning a state walks its row, 6-byte cells without ROW cells, row ends in mask words.
 constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are free (offsets are multiples of 4)
 // general streams: cells per loop iteration, two 8-cell chunks in ping-pong (a third buffer was measured:
@@ -72,7 +72,7 @@ struct ScheduleHost {
   int64_t conflict_cost = 0, conflict_free_cost = 0;  // LDS cycles of the arc gathers: as placed / if conflict-free
   int64_t real_arcs = 0, padded_arcs = 0;
   int32_t rows = 0;
-  // owner-computes schedules of tied graphs (den_graph.cpp: build_owner)
+  // owner-computes schedules of tied graphs (schedule_owner.cpp: build_owner)
   std::vector<uint32_t> masks;        // [wave][mask_stride]: bit i of word j <=> a row ends after pair 8 j + i
   int32_t mask_stride = 0;
   std::vector<int32_t> extra_first;   // per wave: index of its first secondary-row slot group
@@ -172,7 +172,7 @@ struct tc_den_graph {
   std::vector<float> tied_w;
   // The graph the tied schedules are built from: the FST itself, or -- when a few states are entered
   // through arcs of more than one pdf -- its "tied-ified" version in which such a state is split into one
-  // copy per entering pdf (den_graph.cpp: make_work_graph).  copy_first[h] .. copy_first[h+1] are the work
+  // copy per entering pdf (schedule_owner.cpp: make_work_graph).  copy_first[h] .. copy_first[h+1] are the work
   // states of FST state h; work_H == H and copy_first[h] == h when nothing was split.
   int32_t work_H = 0;
   std::vector<int32_t> work_src, work_dst, work_pdf, copy_first;

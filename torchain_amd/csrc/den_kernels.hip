@@ -8,7 +8,7 @@
 // LDS: exp(y_t), alpha'_t / beta_{t+1} (gather source), one accumulator per row and, in the backward
 // half, gamma_t (u32 fixed point) and alpha'_t.  HBM sees each y row twice (forward, backward), each
 // alpha' frame once out and once back, and each derivative row once.  The transition tables are
-// streamed from L2 as a per-wave cell stream in a lane-major schedule (den_graph.cpp): a lane walks one
+// streamed from L2 as a per-wave cell stream in a lane-major schedule (schedule_*.cpp): a lane walks one
 // state's arc list, a wave instruction loads 64 lanes x 16 contiguous bytes, and the lanes gather
 // alpha' (and exp(y)) from LDS.  There are no LDS float atomics (192 cycles per wave-instruction on
 // gfx950): every row sum is committed with a plain store and gamma is integer fixed point.
@@ -247,7 +247,7 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
 // A pair of cells is {w0, w1, off0 | off1 << 16}: fp32 weights and 16-bit LDS byte offsets of the two
 // gathers.  Both tied walks are the same operation -- acc(row) += w * SRC[off] -- with SRC = alpha'_t
 // (forward) or Y_t (backward), and the row a lane is summing is always one of its OWN states (or a
-// secondary row, see den_graph.cpp build_owner): the sum is committed to the thread's own accumulator
+// secondary row, see schedule_owner.cpp build_owner): the sum is committed to the thread's own accumulator
 // slot and read back by the same thread, so no barrier separates the walk from the per-state pass.
 struct Pair6 {
   uint32_t w0, w1, off;
@@ -332,7 +332,7 @@ __device__ __forceinline__ const uint4 *walk6_base(const ScheduleDev &sc, int wa
   const int2 range = sc.wave_range[wave];
   const int first = __builtin_amdgcn_readfirstlane(range.x);  // multiple of kChunk
   ncells = __builtin_amdgcn_readfirstlane(range.y);           // multiple of kChunk
-  // the stream is stored [chunk of 8 cells][3 blocks][lane]{16 bytes}: see den_graph.cpp
+  // the stream is stored [chunk of 8 cells][3 blocks][lane]{16 bytes}: see schedule_owner.cpp
   return reinterpret_cast<const uint4 *>(sc.cells) + (int64_t)(first / kChunk) * 3 * 64 + lane;
 }
 
@@ -352,7 +352,7 @@ __device__ __forceinline__ void load_chunk6(Pair6 (&q)[kChunk / 2], const uint4 
 // the mask words are followed by readable padding, so the loads past the wave's range need no guard.
 // RES = 2: the wave's first two chunks (one mask word) are held in registers by the caller for the whole
 // phase (ra, rb) and never re-read: the walk is bound by the L2 -> CU stream path, so every resident
-// chunk is time saved.  Every wave's range is at least two chunks long (den_graph.cpp).
+// chunk is time saved.  Every wave's range is at least two chunks long (schedule_owner.cpp).
 #ifdef TC_PHASE_STAMPS
 // diagnostic: cycles spent waiting for the current chunk's loads (three younger loads may stay in
 // flight) and cycles spent processing it, accumulated into stamp slots 5 and 6
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const int H = p.H, P = p.P, S = p.S, T = p.T;
   const int Hs = p.L.Hs, Ps = p.L.Ps;
   // Which of its JV float4s of states a thread really has: tied graphs are laid out in whole planes of
-  // 4096 positions (den_graph.cpp build_owner), so the test is wave-uniform there (a scalar branch, no
+  // 4096 positions (schedule_owner.cpp build_owner), so the test is wave-uniform there (a scalar branch, no
   // per-lane compare and exec masking in the per-state passes).
   const int planes = Hs / (4 * kThreads);
   auto owns = [&](int j, int h0) { return TIED ? j < planes : h0 < Hs; };
