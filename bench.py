@@ -30,6 +30,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", help="workload name in torchain_amd.synth.CONFIGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed full-objective / layout measurements")
     ap.add_argument("--cpu-seqs", type=int, default=256, help="sequences in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -62,6 +63,41 @@ def cpu_baseline(fst, cfg, nseq):
         dt2 = time.perf_counter() - t0
         out["all_cores"] = {"value": n2 * T / dt2, "cores": threads,
                             "sample": "%d sequences in blocks of 8, OpenMP over blocks; %.1f s" % (n2, dt2)}
+    return out
+
+
+def extras(graph, fst, cfg, S, T, P, dev):
+    """Not part of the metric: the rest of the path around the benchmarked unit, timed after the timed
+    region with HIP events -- the full objective (tc_chain_objf_and_deriv: denominator + numerator +
+    finalisation) on a synthetic supervision, and the layout kernels that replace the reference's
+    (B, C, T) <-> (T*B, C) permutes (functions.py:118-125, :112) next to the torch ops they replace."""
+    import torch
+    from torchain_amd import io, synth
+    from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv, from2d_hip, to2d, to2d_hip
+
+    def timeit(fn, n=10, warm=3):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    sup = synth.random_supervision(fst, S, T, 3, seed=7, initial_probs=graph.initial_probs())
+    hsup = io.Supervision.from_synth(sup)
+    y = torch.randn(S * T, P, device=dev)
+    deriv = torch.empty_like(y)
+    res = ChainResults()
+    full = timeit(lambda: compute_chain_objf_and_deriv(graph, hsup, y, res.data, deriv, None, cfg.get("l2", 0.0),
+                                                       cfg["leaky"], 0.0))
+    x = y.view(T, S, P).permute(1, 2, 0).contiguous()  # (B, C, T)
+    out = {"full_objective_ms": full, "objf_per_frame": float(res.data[0] / res.data[2]),
+           "to2d_hip_ms": timeit(lambda: to2d_hip(x)), "to2d_torch_ms": timeit(lambda: to2d(x)),
+           "from2d_neg_hip_ms": timeit(lambda: from2d_hip(y, (S, P, T), -1.0)),
+           "from2d_neg_torch_ms": timeit(lambda: (-y).view(T, S, P).permute(1, 2, 0).contiguous())}
     return out
 
 
@@ -189,6 +225,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fst, cfg, args.cpu_seqs)
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(graph, fst, cfg, S, T, P, dev)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -8,11 +8,11 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-cmd="python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cmd="python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
 cd /tmp
 # the kernel-trace pass runs the default bench (30 steps + 5 warm-up + 20 event-timed launches), so its
 # average is taken over the same mix of launches as bench.py's HIP-event figure
-rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt" -o kt -- python3 $root/bench.py --no-cpu-baseline > "$out/kt.log" 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt" -o kt -- python3 $root/bench.py --no-cpu-baseline --no-extras > "$out/kt.log" 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$out/fetch" -o pmc -- $cmd > "$out/fetch.log" 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/write" -o pmc -- $cmd > "$out/write.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM -d "$out/sq1" -o pmc -- $cmd > "$out/sq1.log" 2>&1
