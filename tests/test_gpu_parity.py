@@ -134,7 +134,9 @@ def test_streamed_path_for_graphs_beyond_lds(oracle, monkeypatch):
     assert g.stats()["tied"] == 2
     _check_full(oracle, fst, 2, 6, l2=1e-4, leaky=0.1)
     monkeypatch.setenv("TC_FORCE_BIG", "1")
-    _check_full(oracle, synth.random_den_fst(300, 5, 100, seed=32), 3, 11, l2=0.0, leaky=1e-5)
+    _check_full(oracle, synth.random_den_fst(300, 5, 100, seed=32), 3, 11, l2=0.0, leaky=1e-5)  # tied streamed kernels
+    _check_full(oracle, synth.nearly_tied_den_fst(500, 5, 90, seed=7), 3, 8, l2=1e-4, leaky=0.1)  # ... of a split graph
+    _check_full(oracle, synth.skewed_tied_den_fst(400, 7000, 150, seed=8), 2, 9, l2=0.0, leaky=0.05)  # hubs, no-self-loop states
     fst2 = synth.skewed_den_fst(300, 6000, 120, seed=4)
     _check_full(oracle, fst2, 4, 9, l2=1e-3, leaky=0.1)
     S, T = 3, 8

@@ -57,9 +57,11 @@ def test_config3_and_config5_graphs_replay():
 
 
 def test_streamed_tables_replay(monkeypatch):
-    check_graph(synth.random_den_fst(20000, 3, 700, seed=31), 2)
+    check_graph(synth.random_den_fst(20000, 3, 700, seed=31), 2)      # tied streamed tables
     monkeypatch.setenv("TC_FORCE_BIG", "1")
-    check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 2)
+    check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 2)       # general streamed tables
+    check_graph(synth.nearly_tied_den_fst(500, 5, 90, seed=7), 2)      # tied streamed tables of a split graph
+    check_graph(synth.skewed_tied_den_fst(400, 7000, 150, seed=8), 2)  # tied, hub states, states without self-loop
 
 
 def test_forced_general_matches_tied(monkeypatch):

@@ -18,7 +18,7 @@ namespace {
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
-  float *big_expy, *big_beta, *big_small;  // streamed path only
+  float *big_expy, *big_beta, *big_small, *big_y;  // streamed path only
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
   float *ab, *gs;
@@ -28,9 +28,12 @@ struct Workspace {
 };
 
 // Hs: stored states per frame of the alpha history (layout positions for tied graphs: build_owner)
-int hist_states(const tc_den_graph *g) { return g->tied ? g->layout.Hs : ((g->H + 3) & ~3); }
+int hist_states(const tc_den_graph *g) {
+  if (g->big) return ((g->tied ? g->work_H : g->H) + 3) & ~3;
+  return g->tied ? g->layout.Hs : ((g->H + 3) & ~3);
+}
 int big_p(const tc_den_graph *g) { return g->big ? g->P : 0; }
-int big_h(const tc_den_graph *g) { return g->big ? g->H : 0; }
+int big_h(const tc_den_graph *g) { return g->big ? (g->tied ? g->work_H : g->H) : 0; }  // tied: work-graph states
 
 // big_P != 0 selects the streamed path's layout: sequences padded to 64 lanes, [state][sequence] matrices
 Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0) {
@@ -53,6 +56,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0) 
   w.big_expy = big_P ? (float *)take((size_t)Sp * big_P * sizeof(float)) : nullptr;
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
+  w.big_y = big_P ? (float *)take((size_t)Sp * big_H * sizeof(float)) : nullptr;
   w.total = off;
   return w;
 }
@@ -89,11 +93,12 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   }
   bool tied = g->tied;
   // tied graphs address states by layout position (a multiple of 4096 of them, phantoms included)
-  const int nstates = tied ? g->layout.Hs : g->H;
+  const int nstates = g->big ? (tied ? g->work_H : g->H) : (tied ? g->layout.Hs : g->H);
   if (g->big) {
     p->L = DenLayout();
-    p->L.Hs = (g->H + 3) & ~3;
+    p->L.Hs = (nstates + 3) & ~3;
     p->L.Ps = (g->P + 3) & ~3;
+    tied = false;  // the on-chip tied kernel's tables are not used; p->big.tied selects the streamed variant
   } else if (!compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
     return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit LDS
   }
@@ -101,6 +106,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->big_expy = w.big_expy;
   p->big_beta = w.big_beta;
   p->big_small = w.big_small;
+  p->big_y = w.big_y;
   p->big_Sp = (S + 63) & ~63;
   p->big_sum_pi = g->big_sum_pi;
   p->tied_fs = tied ? d.tied_fs : nullptr;

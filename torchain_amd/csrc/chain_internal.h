@@ -103,6 +103,13 @@ struct BigArc {
 struct BigDev {
   const int32_t *in_begin = nullptr, *out_begin = nullptr, *pdf_begin = nullptr;
   const BigArc *in_arc = nullptr, *out_arc = nullptr, *pdf_arc = nullptr;
+  // tied graphs (work-graph states): the arc lists hold the non-special arcs only and exp(y) is applied
+  // per state, so an arc costs ONE row gather per pass; gamma comes from per-state quantities through
+  // pdf_arc, here a by-pdf list of entries {state, (self-loop pdf + 1) * 2 | role, self-loop prob, pi}
+  // (role 0: the entry stands under the state's forward pdf, 1: under its self-loop pdf)
+  int tied = 0;
+  const int32_t *tf = nullptr, *ts = nullptr;  // per state: forward / self-loop pdf (-1: none)
+  const float *tws = nullptr;                  // per state: special self-loop probability
 };
 
 struct DenGraphDev {
@@ -147,6 +154,7 @@ struct DenParams {
   BigDev big;           // streamed path only
   float *big_expy;      // [P][Sp]  exp(y_t) of the current frame, transposed
   float *big_beta;      // [2][H][Sp]
+  float *big_y;         // [H][Sp]  tied graphs: Y = beta_{t+1} * p_t(f), the backward gather source
   float *big_small;     // per-sequence sums and per-block partials (den_big_kernel.hip: BigSmall)
   int big_Sp;           // sequences rounded up to a multiple of 64
   float big_sum_pi;     // sum of the initial probabilities
@@ -185,6 +193,7 @@ struct tc_den_graph {
   bool big = false;
   std::vector<int32_t> big_in_begin, big_out_begin, big_pdf_begin;
   std::vector<tc::BigArc> big_in, big_out, big_pdf;
+  std::vector<int32_t> tied_f, tied_s;  // per work state: forward / special self-loop pdf, -1 if none
   float big_sum_pi = 0.f;
   std::mutex mu;
   std::map<int, tc::DenGraphDev> dev;

@@ -325,6 +325,186 @@ __global__ __launch_bounds__(kRT) void big_gamma_kernel(const DenParams p, int t
   }
 }
 
+// ---- tied graphs: exp(y) applied per state, one row gather per arc and pass ---------------------------
+//   forward : alpha_t(g) * asum_{t-1} = p(f(g)) * sum_in w * alpha'_{t-1}(src) + p(s(g)) * w_s(g) * alpha'_{t-1}(g)
+//   backward: Y(g) = beta_{t+1}(g) * p_t(f(g));  beta'_t(h) * asum_t = sum_out w * Y(dst) + p_t(s(h)) * w_s(h) * beta_{t+1}(h)
+//   gamma   : from per-state quantities (den_kernels.hip, tied path): self-loop occupation
+//             w_s * beta_{t+1}(g) * p_t(s) * alpha'_t(g) / asum_t -> pdf s(g); forward-class occupation
+//             beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart) -> pdf f(g), alpha_{t+1} being the stored un-dashed value.
+__device__ __forceinline__ float big_row(const float *base, int idx, int Sp) {
+  return idx >= 0 ? base[(int64_t)idx * Sp] : 0.f;
+}
+
+__global__ __launch_bounds__(kBT) void big_fwd_tied_kernel(const DenParams p, int t) {
+  __shared__ float red[4][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int Sp = p.big_Sp, s = blockIdx.y * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const float *prev = p.alpha_hist + (int64_t)(t - 1) * p.H * Sp + s;
+  float *cur = p.alpha_hist + (int64_t)t * p.H * Sp + s;
+  const float *E = p.big_expy + s;
+  const float asum_prev = sm.asum[(int64_t)(t - 1) * Sp + s];
+  const float inv = 1.0f / asum_prev, cl_as = p.leaky * asum_prev;
+  float part = 0.f;
+  const int h0 = blockIdx.x * kStatesPerBlock + wave * (kStatesPerBlock / 4);
+  // the per-state rows of the wave's four states are requested first: they do not depend on the arc sums,
+  // and these kernels are bound by load latency at the occupancy they run at
+  constexpr int KS = kStatesPerBlock / 4;
+  float own[KS], ef[KS], es[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int h = min(h0 + k, p.H - 1);
+    own[k] = prev[(int64_t)h * Sp];
+    ef[k] = big_row(E, p.big.tf[h], Sp);
+    es[k] = big_row(E, p.big.ts[h], Sp);
+  }
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int h = h0 + k;
+    if (h >= p.H) break;
+    const int e0 = p.big.in_begin[h], e1 = p.big.in_begin[h + 1];
+    const float F = big_arc_sum(p.big.in_arc, e0, e1, [&](const BigArc &r) {
+      return r.w * (prev[(int64_t)r.a * Sp] + cl_as * r.pi);
+    });
+    const float a_self = own[k] + cl_as * p.pi[h];
+    const float v = (ef[k] * F + es[k] * (p.big.tws[h] * a_self)) * inv;
+    cur[(int64_t)h * Sp] = v;
+    part += v;
+  }
+  red[wave][lane] = part;
+  __syncthreads();
+  if (wave == 0) sm.part_a[(int64_t)blockIdx.x * Sp + s] = (red[0][lane] + red[0 + 1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// Y(g) = beta_{t+1}(g) * p_t(f(g)) for every state
+__global__ __launch_bounds__(kBT) void big_y_kernel(const DenParams p, int t) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int Sp = p.big_Sp, s = blockIdx.y * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
+  const float *E = p.big_expy + s;
+  const float bs = sm.bsum[((t + 1) & 1) * Sp + s];
+  const int h0 = blockIdx.x * kStatesPerBlock + wave * (kStatesPerBlock / 4);
+  for (int k = 0; k < kStatesPerBlock / 4; ++k) {
+    const int h = h0 + k;
+    if (h >= p.H) break;
+    p.big_y[(int64_t)h * Sp + s] = (Bprev[(int64_t)h * Sp] + bs) * big_row(E, p.big.tf[h], Sp);
+  }
+}
+
+__global__ __launch_bounds__(kBT) void big_bwd_tied_kernel(const DenParams p, int t) {
+  __shared__ float red[2][4][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int Sp = p.big_Sp, s = blockIdx.y * 64 + lane;
+  const BigSmall sm = big_small(p);
+  const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
+  float *Bcur = p.big_beta + (int64_t)(t & 1) * p.H * Sp + s;
+  const float *Y = p.big_y + s;
+  const float *E = p.big_expy + s;
+  const float asum_t = sm.asum[(int64_t)t * Sp + s];
+  const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s];
+  const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
+  float part = 0.f, part_ab = 0.f;
+  const int h0 = blockIdx.x * kStatesPerBlock + wave * (kStatesPerBlock / 4);
+  constexpr int KS = kStatesPerBlock / 4;
+  float own[KS], es[KS], al[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int h = min(h0 + k, p.H - 1);
+    own[k] = Bprev[(int64_t)h * Sp];
+    es[k] = big_row(E, p.big.ts[h], Sp);
+    al[k] = t == 0 ? alpha[(int64_t)h * Sp] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int h = h0 + k;
+    if (h >= p.H) break;
+    const int e0 = p.big.out_begin[h], e1 = p.big.out_begin[h + 1];
+    const float sum = big_arc_sum(p.big.out_arc, e0, e1, [&](const BigArc &r) { return r.w * Y[(int64_t)r.a * Sp]; });
+    const float self = es[k] * p.big.tws[h] * (own[k] + bs);
+    const float bp = (sum + self) * inv_as;
+    Bcur[(int64_t)h * Sp] = bp;
+    const float cpi = p.leaky * p.pi[h];
+    part += cpi * bp;
+    if (t == 0) part_ab += (al[k] + cpi * asum_t) * bp;
+  }
+  red[0][wave][lane] = part;
+  red[1][wave][lane] = part_ab;
+  __syncthreads();
+  if (wave == 0) {
+    sm.part_a[(int64_t)blockIdx.x * Sp + s] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    if (t == 0)
+      sm.part_ab[(int64_t)blockIdx.x * Sp + s] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  }
+}
+
+template <bool ACCUM>
+__global__ __launch_bounds__(kRT) void big_gamma_tied_kernel(const DenParams p, int t) {
+  __shared__ float tile[64][65];
+  __shared__ float red[kRW][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int Sp = p.big_Sp, s0 = blockIdx.y * 64, s = s0 + lane;
+  const BigSmall sm = big_small(p);
+  const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
+  const float *alpha_up = p.alpha_hist + (int64_t)(t + 1) * p.H * Sp + s;  // un-dashed alpha_{t+1}
+  const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
+  const float *E = p.big_expy + s;
+  const float asum_t = sm.asum[(int64_t)t * Sp + s];
+  const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s], cl_as = p.leaky * asum_t;
+  const int p0 = blockIdx.x * kPdfsPerBlock;
+  float part_g = 0.f;
+  for (int k = 0; k < kPdfsPerBlock / kRW; ++k) {
+    const int pl = wave * (kPdfsPerBlock / kRW) + k, pdf = p0 + pl;
+    float gam = 0.f;
+    if (pdf < p.P) {
+      const int e0 = p.big.pdf_begin[pdf], e1 = p.big.pdf_begin[pdf + 1];
+      // entries are self-contained (state, role, the state's self-loop pdf / weight / pi), four at a time
+      // with all their row loads issued before the arithmetic
+      for (int e = e0; e < e1; e += 4) {
+        BigArc r[4];
+        float b[4], a[4], up[4], esv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = p.big.pdf_arc[min(e + u, e1 - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          b[u] = Bprev[(int64_t)r[u].a * Sp];
+          a[u] = alpha[(int64_t)r[u].a * Sp];
+          up[u] = alpha_up[(int64_t)r[u].a * Sp];
+          esv[u] = big_row(E, (r[u].b >> 1) - 1, Sp);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float beta = b[u] + bs;
+          const float selfpart = esv[u] * r[u].w * (a[u] + cl_as * r[u].pi) * inv_as;
+          const float occ = (r[u].b & 1) ? beta * selfpart : beta * fmaxf(up[u] - selfpart, 0.f);
+          gam += e + u < e1 ? occ : 0.f;
+        }
+      }
+    }
+    tile[pl][lane] = gam;
+    part_g += gam;
+  }
+  red[wave][lane] = part_g;
+  __syncthreads();
+  if (t == 0 && wave == 0) {
+    float g = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRW; ++w) g += red[w][lane];
+    sm.part_g[(int64_t)blockIdx.x * Sp + s] = g;
+  }
+  const int pdf = p0 + lane;
+  for (int sl = wave; sl < 64; sl += kRW) {
+    const int sq = s0 + sl;
+    if (sq < p.S && pdf < p.P) {
+      const int64_t row = (int64_t)t * p.S + sq;
+      float o = p.deriv_weight * tile[lane][sl] - p.l2_scale * p.y[row * p.y_stride + pdf];
+      float *d = p.deriv + row * p.deriv_stride + pdf;
+      if (ACCUM) o += *d;
+      *d = o;
+    }
+  }
+}
+
 // bsum_t = leaky * sum_h pi(h) beta'_t(h); at t == 0 also the two checks of [K] BetaGeneralFrameDebug(0)
 __global__ __launch_bounds__(kRT) void big_bsum_kernel(const DenParams p, int t) {
   __shared__ float red[kRW][64];
@@ -359,9 +539,13 @@ int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream) {
   const dim3 g_pdfs((p.P + kPdfsPerBlock - 1) / kPdfsPerBlock, sg);
   const int fill_blocks = (int)std::min<int64_t>(4096, ((int64_t)p.H * Sp + kBT - 1) / kBT);
   hipLaunchKernelGGL(big_alpha0_kernel, dim3(fill_blocks), blk, 0, stream, p);
+  const bool tied = p.big.tied != 0;
   for (int t = 1; t <= p.T; ++t) {
     hipLaunchKernelGGL(big_exp_kernel<true>, g_exp, blk, 0, stream, p, t - 1);
-    hipLaunchKernelGGL(big_fwd_kernel, g_states, blk, 0, stream, p, t);
+    if (tied)
+      hipLaunchKernelGGL(big_fwd_tied_kernel, g_states, blk, 0, stream, p, t);
+    else
+      hipLaunchKernelGGL(big_fwd_kernel, g_states, blk, 0, stream, p, t);
     hipLaunchKernelGGL(big_asum_kernel, dim3(sg), dim3(kRT), 0, stream, p, t);
   }
   hipLaunchKernelGGL(big_total_kernel, dim3((p.S + kBT - 1) / kBT), blk, 0, stream, p);
@@ -369,11 +553,20 @@ int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream) {
     hipLaunchKernelGGL(big_beta_init_kernel, dim3(fill_blocks), blk, 0, stream, p);
     for (int t = p.T - 1; t >= 0; --t) {
       hipLaunchKernelGGL(big_exp_kernel<false>, g_exp, blk, 0, stream, p, t);
-      hipLaunchKernelGGL(big_bwd_kernel, g_states, blk, 0, stream, p, t);
-      if (accumulate)
-        hipLaunchKernelGGL(big_gamma_kernel<true>, g_pdfs, dim3(kRT), 0, stream, p, t);
-      else
-        hipLaunchKernelGGL(big_gamma_kernel<false>, g_pdfs, dim3(kRT), 0, stream, p, t);
+      if (tied) {
+        hipLaunchKernelGGL(big_y_kernel, g_states, blk, 0, stream, p, t);
+        hipLaunchKernelGGL(big_bwd_tied_kernel, g_states, blk, 0, stream, p, t);
+        if (accumulate)
+          hipLaunchKernelGGL(big_gamma_tied_kernel<true>, g_pdfs, dim3(kRT), 0, stream, p, t);
+        else
+          hipLaunchKernelGGL(big_gamma_tied_kernel<false>, g_pdfs, dim3(kRT), 0, stream, p, t);
+      } else {
+        hipLaunchKernelGGL(big_bwd_kernel, g_states, blk, 0, stream, p, t);
+        if (accumulate)
+          hipLaunchKernelGGL(big_gamma_kernel<true>, g_pdfs, dim3(kRT), 0, stream, p, t);
+        else
+          hipLaunchKernelGGL(big_gamma_kernel<false>, g_pdfs, dim3(kRT), 0, stream, p, t);
+      }
       hipLaunchKernelGGL(big_bsum_kernel, dim3(sg), dim3(kRT), 0, stream, p, t);
     }
   }

@@ -38,14 +38,47 @@ static void build_big(tc_den_graph *g) {
   g->big_sum_pi = sum_pi;
 }
 
-int build_schedules(tc_den_graph *g) {
-  if (getenv("TC_FORCE_BIG") || g->H > kMaxIndex || g->P > kMaxIndex) {
-    g->big = true;
-    g->tied = false;
-    g->layout_ok = false;
-    build_big(g);
-    return TC_OK;
+// Streamed path of a tied (work) graph: arc lists without the special self-loops, per-state pdfs, and the
+// by-pdf {state, role} entries gamma is assembled from (chain_internal.h: BigDev).
+static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
+  const int H = g->work_H, P = g->P;
+  const int64_t A = (int64_t)g->work_src.size();
+  auto csr = [&](const std::vector<int32_t> &key, std::vector<int32_t> *begin, std::vector<BigArc> *out,
+                 const std::vector<int32_t> &other) {
+    begin->assign(H + 1, 0);
+    for (int64_t a = 0; a < A; ++a)
+      if (!special[a]) (*begin)[key[a] + 1]++;
+    for (int i = 0; i < H; ++i) (*begin)[i + 1] += (*begin)[i];
+    out->assign(std::max<int64_t>((*begin)[H], 1), BigArc{0, 0, 0.f, 0.f});
+    std::vector<int32_t> fill(begin->begin(), begin->end() - 1);
+    for (int64_t a = 0; a < A; ++a)
+      if (!special[a]) (*out)[fill[key[a]]++] = BigArc{other[a], g->work_pdf[a], g->work_prob[a], g->work_pi[g->work_src[a]]};
+  };
+  csr(g->work_dst, &g->big_in_begin, &g->big_in, g->work_src);
+  csr(g->work_src, &g->big_out_begin, &g->big_out, g->work_dst);
+  // entries by pdf: every state once under its forward pdf (role 0) and once under its special self-loop pdf (role 1)
+  g->big_pdf_begin.assign(P + 1, 0);
+  for (int h = 0; h < H; ++h) {
+    if (g->tied_f[h] >= 0) g->big_pdf_begin[g->tied_f[h] + 1]++;
+    if (g->tied_s[h] >= 0) g->big_pdf_begin[g->tied_s[h] + 1]++;
   }
+  for (int i = 0; i < P; ++i) g->big_pdf_begin[i + 1] += g->big_pdf_begin[i];
+  // an entry is a BigArc {state, (self-loop pdf + 1) * 2 | role, self-loop prob, pi(state)}: everything the
+  // gamma kernel needs about the state besides its rows, so no dependent table loads
+  g->big_pdf.assign(std::max(g->big_pdf_begin[P], 1), BigArc{0, 0, 0.f, 0.f});
+  std::vector<int32_t> fill(g->big_pdf_begin.begin(), g->big_pdf_begin.end() - 1);
+  for (int h = 0; h < H; ++h) {
+    const int32_t code = (g->tied_s[h] + 1) * 2;
+    if (g->tied_f[h] >= 0) g->big_pdf[fill[g->tied_f[h]]++] = BigArc{h, code | 0, g->tied_w[h], g->work_pi[h]};
+    if (g->tied_s[h] >= 0) g->big_pdf[fill[g->tied_s[h]]++] = BigArc{h, code | 1, g->tied_w[h], g->work_pi[h]};
+  }
+  float sum_pi = 0.f;
+  for (int h = 0; h < H; ++h) sum_pi += g->work_pi[h];
+  g->big_sum_pi = sum_pi;
+}
+
+int build_schedules(tc_den_graph *g) {
+  bool want_big = getenv("TC_FORCE_BIG") || g->H > kMaxIndex || g->P > kMaxIndex;
   // ---- the tied path: on the FST as it is, or on its tied-ified work graph
   std::vector<char> special;
   {
@@ -61,23 +94,27 @@ int build_schedules(tc_den_graph *g) {
     if (!tied && !getenv("TC_FORCE_GENERAL") && !getenv("TC_NO_SPLIT") && make_work_graph(g)) tied = detect_tied(g, &special);
     g->tied = tied;
   }
-  if (g->tied) {
+  if (!want_big && g->tied) {
     if (build_owner(g, special)) {
       g->layout_ok = true;
       return TC_OK;
     }
-    g->tied = false;  // does not fit the owner-computes layout: use the general kernel
-    g->fwd = ScheduleHost();
-    g->bwd = ScheduleHost();
+    want_big = true;  // tied but beyond the on-chip layouts: the streamed kernels keep the tied factorisation
   }
-  build_general(g);
-  g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
-  if (!g->layout_ok) {  // the per-frame working set does not fit LDS: stream it
-    g->big = true;
-    g->fwd = ScheduleHost();
-    g->bwd = ScheduleHost();
+  if (!want_big) {
+    build_general(g);
+    g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
+    if (g->layout_ok) return TC_OK;
+  }
+  // the per-frame working set does not fit LDS: stream it
+  g->big = true;
+  g->layout_ok = false;
+  g->fwd = ScheduleHost();
+  g->bwd = ScheduleHost();
+  if (g->tied)
+    build_big_tied(g, special);
+  else
     build_big(g);
-  }
   return TC_OK;
 }
 
@@ -286,6 +323,33 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
                             float *out) {
   if (!g || !gather || !pdf_factor || !out || direction < 0 || direction > 1) return TC_ERR_INVALID_ARGUMENT;
   const int H = g->H;
+  if (g->big && g->tied) {
+    // work-graph states; a split state's forward value sits on its first copy, its backward value on all
+    const std::vector<int32_t> &begin = direction == 0 ? g->big_in_begin : g->big_out_begin;
+    const std::vector<BigArc> &arc = direction == 0 ? g->big_in : g->big_out;
+    auto pf = [&](int pdf) { return pdf >= 0 ? pdf_factor[pdf] : 0.f; };
+    std::vector<float> val(g->work_H, 0.f);
+    for (int h = 0; h < H; ++h)
+      for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c)
+        val[c] = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f) : gather[h] * pf(g->tied_f[c]);
+    for (int h = 0; h < H; ++h) {
+      float total = 0.f;
+      for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
+        float sum = 0.f;
+        for (int a = begin[c]; a < begin[c + 1]; ++a) sum += arc[a].w * val[arc[a].a];
+        const float own = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f) : gather[h];
+        const float self = pf(g->tied_s[c]) * g->tied_w[c] * own;
+        const float v = direction == 0 ? pf(g->tied_f[c]) * sum + self : sum + self;
+        if (direction == 1) {
+          total = v;
+          break;
+        }
+        total += v;
+      }
+      out[h] = total;
+    }
+    return TC_OK;
+  }
   if (g->big) {
     const std::vector<int32_t> &begin = direction == 0 ? g->big_in_begin : g->big_out_begin;
     const std::vector<BigArc> &arc = direction == 0 ? g->big_in : g->big_out;
@@ -409,13 +473,21 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
   struct Part { const void *src; size_t bytes; size_t off; };
   if (g->big) {
-    std::vector<float> pi_pad(Hs + 4, 0.f);
-    std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
+    const std::vector<float> &pi_src = g->tied ? g->work_pi : g->initial_probs;
+    std::vector<float> pi_pad(pi_src.size() + 8, 0.f);
+    std::copy(pi_src.begin(), pi_src.end(), pi_pad.begin());
+    const std::vector<int32_t> none_i(1, -1);
+    const std::vector<float> none_f(1, 0.f);
+    const bool tb = g->tied;
     Part parts[] = {
         {g->big_in_begin.data(), g->big_in_begin.size() * 4, 0}, {g->big_in.data(), g->big_in.size() * sizeof(BigArc), 0},
         {g->big_out_begin.data(), g->big_out_begin.size() * 4, 0}, {g->big_out.data(), g->big_out.size() * sizeof(BigArc), 0},
-        {g->big_pdf_begin.data(), g->big_pdf_begin.size() * 4, 0}, {g->big_pdf.data(), g->big_pdf.size() * sizeof(BigArc), 0},
+        {g->big_pdf_begin.data(), g->big_pdf_begin.size() * 4, 0},
+        {g->big_pdf.data(), g->big_pdf.size() * sizeof(BigArc), 0},
         {pi_pad.data(), pi_pad.size() * 4, 0},
+        {tb ? g->tied_f.data() : none_i.data(), (tb ? g->tied_f.size() : 1) * 4, 0},
+        {tb ? g->tied_s.data() : none_i.data(), (tb ? g->tied_s.size() : 1) * 4, 0},
+        {tb ? g->tied_w.data() : none_f.data(), (tb ? g->tied_w.size() : 1) * 4, 0},
     };
     size_t total = 0;
     for (auto &p : parts) {
@@ -443,6 +515,12 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
     d.big.pdf_begin = (const int32_t *)(blob + parts[4].off);
     d.big.pdf_arc = (const BigArc *)(blob + parts[5].off);
     d.pi = (const float *)(blob + parts[6].off);
+    if (tb) {
+      d.big.tied = 1;
+      d.big.tf = (const int32_t *)(blob + parts[7].off);
+      d.big.ts = (const int32_t *)(blob + parts[8].off);
+      d.big.tws = (const float *)(blob + parts[9].off);
+    }
     g->dev[device] = d;
     return TC_OK;
   }

@@ -448,6 +448,8 @@ bool detect_tied(tc_den_graph *g, std::vector<char> *special) {
   const int Hs = round4(H);
   g->tied_fs.assign(Hs + 4, 0u);
   g->tied_w.assign(Hs + 4, 0.f);
+  g->tied_f = fpdf;
+  g->tied_s = spdf;
   for (int h = 0; h < H; ++h) {
     g->tied_fs[h] = (uint32_t)(std::max(fpdf[h], 0) * 4) | ((uint32_t)(std::max(spdf[h], 0) * 4) << 16);
     g->tied_w[h] = wself[h];
