@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBT) void big_fwd_tied_kernel(const DenParams p, in
   }
   red[wave][lane] = part;
   __syncthreads();
-  if (wave == 0) sm.part_a[(int64_t)blockIdx.x * Sp + s] = (red[0][lane] + red[0 + 1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0) sm.part_a[(int64_t)blockIdx.x * Sp + s] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // Y(g) = beta_{t+1}(g) * p_t(f(g)) for every state
