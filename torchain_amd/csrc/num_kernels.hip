@@ -2,8 +2,9 @@
 //
 // [K] NumeratorComputation (chain-numerator.cc) runs a serial CPU loop over the merged supervision
 // FST, bracketed by a device gather and a device scatter-add.  The merged FST factors per sequence
-// (supervision.cpp), so here one wavefront owns one sequence and walks its T time levels in LDS,
-// in the log semiring and in double precision like Kaldi; lanes run over the states of a level.
+// (supervision.cpp), so here one workgroup of two wavefronts owns one sequence and walks its T time
+// levels in LDS (one wave forward, one backward), in the log semiring and in double precision like Kaldi;
+// lanes run over the states of a level.
 // Occupation probabilities are summed per unique (frame, pdf) in arc order (the order Kaldi adds
 // them), then added to the derivative with one plain read-modify-write per unique index -- each
 // (row, pdf) is owned by exactly one lane, so no atomics.
@@ -26,17 +27,23 @@ __device__ __forceinline__ double log_add(double x, double y) {
   return x;
 }
 
-__global__ __launch_bounds__(64) void num_fwd_bwd_kernel(const NumParams p) {
+// Two wavefronts per sequence: the alpha and the beta recursions do not depend on each other, so wave 0
+// walks the levels forward while wave 1 walks them backward (T steps each, one shared barrier per step);
+// the occupations need both and are computed afterwards, one arc per lane.  Per state the operations and
+// their order are Kaldi's.
+__global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *log_alpha = reinterpret_cast<double *>(lds_raw);
   double *log_beta = log_alpha + p.lds_states;
   float *ylp = reinterpret_cast<float *>(log_beta + p.lds_states);  // per unique (frame, pdf): y
   float *occ = ylp + p.lds_uniq;                                    // per arc: occupation prob
+  __shared__ double tot_sh;
 
-  const int q = blockIdx.x, lane = threadIdx.x;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = p.T, S = p.S;
   const int sb = p.t.seq_state_off[q], nst = p.t.seq_state_off[q + 1] - sb;
-  const int ab = p.t.seq_arc_off[q];
+  const int ab = p.t.seq_arc_off[q], narc = p.t.seq_arc_off[q + 1] - ab;
   const int ub = p.t.seq_uniq_off[q], nu = p.t.seq_uniq_off[q + 1] - ub;
   const int *level = p.t.level_begin + (int64_t)q * (T + 2);
   const int *out_begin = p.t.out_begin + sb + q;
@@ -45,65 +52,70 @@ __global__ __launch_bounds__(64) void num_fwd_bwd_kernel(const NumParams p) {
   const int *arc_src = p.t.arc_src + ab, *arc_dst = p.t.arc_dst + ab, *arc_uniq = p.t.arc_uniq + ab;
   const float *arc_logw = p.t.arc_logw + ab;
   const float *final_logw = p.t.final_logw + sb;
+  const bool want_beta = p.deriv != nullptr || p.xent != nullptr;
 
   // gather: [K] nnet_output_.Lookup(nnet_output_indexes_, ...); row = t*S + q
-  for (int u = lane; u < nu; u += 64)
+  for (int u = tid; u < nu; u += 128)
     ylp[u] = p.y[((int64_t)p.t.uniq_t[ub + u] * S + q) * p.y_stride + p.t.uniq_pdf[ub + u]];
-  for (int i = lane; i < nst; i += 64) log_alpha[i] = -INFINITY;
+  for (int i = tid; i < nst; i += 128) {
+    log_alpha[i] = i == 0 ? 0.0 : -INFINITY;
+    log_beta[i] = -INFINITY;
+  }
   __syncthreads();
-  if (lane == 0) log_alpha[0] = 0.0;
+  if (wave == 1 && want_beta)
+    for (int st = level[T] + lane; st < level[T + 1]; st += 64) log_beta[st] = (double)final_logw[st];
   __syncthreads();
 
-  // forward: level t+1 states take the log-sum over their in-arcs, in arc order
-  for (int t = 0; t < T; ++t) {
-    const int l0 = level[t + 1], l1 = level[t + 2];
-    for (int st = l0 + lane; st < l1; st += 64) {
-      double acc = -INFINITY;
-      for (int i = in_begin[st]; i < in_begin[st + 1]; ++i) {
-        const int a = in_arc[i];
-        const float sc = ylp[arc_uniq[a]] + arc_logw[a];  // float sum, as Kaldi
-        acc = log_add(acc, (double)sc + log_alpha[arc_src[a]]);
+  for (int step = 0; step < T; ++step) {
+    if (wave == 0) {
+      // forward: level step+1 states take the log-sum over their in-arcs, in arc order
+      const int l0 = level[step + 1], l1 = level[step + 2];
+      for (int st = l0 + lane; st < l1; st += 64) {
+        double acc = -INFINITY;
+        for (int i = in_begin[st]; i < in_begin[st + 1]; ++i) {
+          const int a = in_arc[i];
+          const float sc = ylp[arc_uniq[a]] + arc_logw[a];  // float sum, as Kaldi
+          acc = log_add(acc, (double)sc + log_alpha[arc_src[a]]);
+        }
+        log_alpha[st] = acc;
       }
-      log_alpha[st] = acc;
+    } else if (want_beta) {
+      // backward: level T-1-step states take the log-sum over their out-arcs
+      const int t = T - 1 - step;
+      const int l0 = level[t], l1 = level[t + 1];
+      for (int st = l0 + lane; st < l1; st += 64) {
+        double this_log_beta = -INFINITY;  // interior states are not final
+        for (int a = out_begin[st]; a < out_begin[st + 1]; ++a) {
+          const float sc = ylp[arc_uniq[a]] + arc_logw[a];
+          this_log_beta = log_add(this_log_beta, (double)sc + log_beta[arc_dst[a]]);
+        }
+        log_beta[st] = this_log_beta;
+      }
     }
     __syncthreads();
   }
-  // total: log-add over final states in state order (lane 0; a handful of states)
-  double tot = -INFINITY;
-  if (lane == 0) {
+  // total: log-add over final states in state order (one lane; a handful of states)
+  if (tid == 0) {
+    double tot = -INFINITY;
     for (int st = level[T]; st < level[T + 1]; ++st)
       if (final_logw[st] != -INFINITY) tot = log_add(tot, log_alpha[st] + (double)final_logw[st]);
-    log_beta[0] = tot;  // broadcast slot, overwritten below
+    tot_sh = tot;
+    p.seq_logprob[q] = tot;
   }
   __syncthreads();
-  tot = log_beta[0];
-  __syncthreads();
-  if (lane == 0) p.seq_logprob[q] = tot;
-  if (p.deriv == nullptr && p.xent == nullptr) return;
-
-  // backward
-  for (int st = level[T] + lane; st < level[T + 1]; st += 64) log_beta[st] = (double)final_logw[st];
-  __syncthreads();
-  for (int t = T - 1; t >= 0; --t) {
-    const int l0 = level[t], l1 = level[t + 1];
-    for (int st = l0 + lane; st < l1; st += 64) {
-      double this_log_beta = -INFINITY;  // interior states are not final
-      const double this_log_alpha = log_alpha[st];
-      for (int a = out_begin[st]; a < out_begin[st + 1]; ++a) {
-        const double next_log_beta = log_beta[arc_dst[a]];
-        const float sc = ylp[arc_uniq[a]] + arc_logw[a];
-        this_log_beta = log_add(this_log_beta, (double)sc + next_log_beta);
-        const float occupation_logprob = (float)(this_log_alpha + (double)sc + next_log_beta - tot);
-        occ[a] = __expf(occupation_logprob);
-      }
-      log_beta[st] = this_log_beta;
-    }
-    __syncthreads();
+  if (!want_beta) return;
+  const double tot = tot_sh;
+  // occupation of every arc: exp(alpha(src) + score + beta(dst) - tot)
+  for (int a = tid; a < narc; a += 128) {
+    const float sc = ylp[arc_uniq[a]] + arc_logw[a];
+    const float occupation_logprob = (float)(log_alpha[arc_src[a]] + (double)sc + log_beta[arc_dst[a]] - tot);
+    occ[a] = __expf(occupation_logprob);
   }
+  __syncthreads();
   // scatter: [K] AddElements(weight, indexes, derivs)
   const int *uniq_begin = p.t.uniq_begin + ub + q;
   const int *uniq_arc = p.t.uniq_arc + ab;
-  for (int u = lane; u < nu; u += 64) {
+  for (int u = tid; u < nu; u += 128) {
     float sum = 0.f;
     for (int i = uniq_begin[u]; i < uniq_begin[u + 1]; ++i) sum += occ[uniq_arc[i]];
     const float v = p.weight * sum;
@@ -119,7 +131,7 @@ int launch_num(const NumParams &p, hipStream_t stream) {
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   TC_HIP_CHECK(hipFuncSetAttribute((const void *)num_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-  hipLaunchKernelGGL(num_fwd_bwd_kernel, dim3(p.S), dim3(64), lds, stream, p);
+  hipLaunchKernelGGL(num_fwd_bwd_kernel, dim3(p.S), dim3(128), lds, stream, p);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
 }
