@@ -151,7 +151,7 @@ def main():
             dist.all_reduce(red)  # (objf, l2_term, weight): the path's one exchange, 12 bytes over xGMI
 
     # device warm-up (not a bench step, outside every timed region): the first few dozen launches after
-    # an idle period run 10-30 % slow while the clocks ramp (profiles/r01_kernel_trace_note.txt)
+    # an idle period run 10-30 % slow while the clocks ramp (profiles/r01_summary.json: trace_first8_ns)
     for _ in range(40):
         step(False)
     for _ in range(args.warmup):
