@@ -489,11 +489,16 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   const uint4 *fwd_r = nullptr, *bwd_r = nullptr;
   const uint32_t *fwd_m = nullptr, *bwd_m = nullptr;
   RowCursor fwd_rc, bwd_rc;
-  Pair6 fres0[kChunk / 2], fres1[kChunk / 2];  // forward stream, chunks 0 and 1: resident for the forward phase
+  // forward stream, chunks 0 and 1: register-resident for the forward phase when a thread owns two float4s of
+  // states; with four, the registers are better spent on the per-state arrays
+  constexpr int kFwdRes = JV <= 2 ? 2 : 0;
+  Pair6 fres0[kChunk / 2], fres1[kChunk / 2];
   if (TIED) {
     fwd_r = walk6_base(p.fwd, wave, lane, fwd_n);
-    load_chunk6(fres0, fwd_r, 0);
-    load_chunk6(fres1, fwd_r, kChunk);
+    if (kFwdRes) {
+      load_chunk6(fres0, fwd_r, 0);
+      load_chunk6(fres1, fwd_r, kChunk);
+    }
     bwd_r = walk6_base(p.bwd, wave, lane, bwd_n);
     fwd_m = p.fwd.masks + wave * p.fwd.mask_stride;
     bwd_m = p.bwd.masks + wave * p.bwd.mask_stride;
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
   for (int t = 1; t <= T; ++t) {
     TC_STAMP(0)
     Pair6 q0[kChunk / 2];
-    if (TIED) load_chunk6(q0, fwd_r, 2 * kChunk);
+    if (TIED) load_chunk6(q0, fwd_r, kFwdRes * kChunk);
     __syncthreads();  // A0, PB, ACC ready
     TC_STAMP(1)
     float4 yreg[PV];
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
     if (TIED)
-      walk_rows6<PV * 16 * kThreads, 2>(fwd_r, fwd_n, fwd_m, q0, fwd_rc, fres0, fres1 TC_WALK_PASS);
+      walk_rows6<PV * 16 * kThreads, kFwdRes>(fwd_r, fwd_n, fwd_m, q0, fwd_rc, fres0, fres1 TC_WALK_PASS);
     else
       walk_rows<false, true, false>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
@@ -713,7 +718,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     // all of the thread's table loads first: one L2 round trip per frame, not one per float4 of states
     uint4 bfs[JV];
     float4 bws[JV];
-    if (TIED) {
+    // (only worth its registers with two float4s of states per thread: with four, the hoisted tables spill)
+    constexpr bool kHoistTables = JV <= 2;
+    if (TIED && kHoistTables) {
 #pragma unroll
       for (int j = 0; j < JV; ++j) {
         const int h0 = 4 * (tid + kThreads * j);
@@ -741,8 +748,8 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
           //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
           // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history.  The self-loop arc also
           // adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
-          const uint4 fs = bfs[j];
-          const float4 ws = bws[j];
+          const uint4 fs = kHoistTables ? bfs[j] : *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
+          const float4 ws = kHoistTables ? bws[j] : *reinterpret_cast<const float4 *>(p.tied_w + h0);
           const float asum_up = asum_h[t + 1];
           // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
           const float4 aup = ALPHA_LDS ? *reinterpret_cast<float4 *>(AL + h0)
@@ -825,7 +832,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
         const float4 b = make_float4(b4[j].x + bsum, b4[j].y + bsum, b4[j].z + bsum, b4[j].w + bsum);
         if (TIED) {
           bown[j] = b;
-          const uint4 fs = bfs[j];
+          const uint4 fs = kHoistTables ? bfs[j] : *reinterpret_cast<const uint4 *>(p.tied_fs + h0);
           *reinterpret_cast<float4 *>(A0 + h0) =
               make_float4(b.x * lds_at(PBnext, fs.x & 0xffffu), b.y * lds_at(PBnext, fs.y & 0xffffu),
                           b.z * lds_at(PBnext, fs.z & 0xffffu), b.w * lds_at(PBnext, fs.w & 0xffffu));
