@@ -718,8 +718,9 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     // all of the thread's table loads first: one L2 round trip per frame, not one per float4 of states
     uint4 bfs[JV];
     float4 bws[JV];
-    // (only worth its registers with two float4s of states per thread: with four, the hoisted tables spill)
-    constexpr bool kHoistTables = JV <= 2;
+    // (only worth its registers with two float4s of states and at most two of pdfs per thread: beyond, the
+    // hoisted tables spill)
+    constexpr bool kHoistTables = JV <= 2 && PV <= 2;
     if (TIED && kHoistTables) {
 #pragma unroll
       for (int j = 0; j < JV; ++j) {
