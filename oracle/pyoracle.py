@@ -77,7 +77,10 @@ class DenGraph:
 
     def __del__(self):
         if getattr(self, "ptr", None):
-            lib().oracle_den_graph_free(self.ptr)
+            try:
+                lib().oracle_den_graph_free(self.ptr)
+            except TypeError:  # interpreter shutdown: module globals are already gone
+                pass
             self.ptr = None
 
     def initial_probs(self):
