@@ -18,8 +18,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 REL = 1e-4
 for case in range(n):
     kind = rng.choice(["tied", "nearly", "hubs", "general", "l2r"])
-    H = int(rng.choice([1, 2, 5, 63, 64, 65, 200, 777, 1500, 4096, 4097, 6000]))
-    P = int(rng.choice([1, 3, 17, 64, 100, 333, 1025]))
+    big_mode = len(sys.argv) > 3  # third argument: the large-layout instantiations (JV = 4, PV = 2 / 3, streamed)
+    H = int(rng.choice([8192, 9000, 12000, 16384, 17000] if big_mode else [1, 2, 5, 63, 64, 65, 200, 777, 1500, 4096, 4097, 6000]))
+    P = int(rng.choice([300, 4097, 6000, 9000, 12289] if big_mode else [1, 3, 17, 64, 100, 333, 1025]))
     deg = int(rng.integers(1, 7))
     seed = int(rng.integers(0, 10000))
     if kind == "tied":
