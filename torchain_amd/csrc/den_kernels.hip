@@ -112,14 +112,12 @@ __device__ __forceinline__ void store_row4(float *row, int i, int n, int vec, fl
   }
 }
 
+// ---- general graphs: walk over 8-byte cells with in-band ROW cells ------------------------------------
 // One chunk of kChunk cells of a wave's stream.  All gathers of the chunk are issued before the first
 // use (ROW cells carry valid offsets, so their gathers are harmless); only the commit of a finished
-// row sits behind a branch, and that branch is scalar: `mask` (bit u <=> cell u is a ROW cell) comes
-// from the schedule through scalar loads.
-//   general graph  FWD: acc(row) += alpha'(src) * w * p(pdf)
-//                  BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
-//   tied graph     FWD: acc(row) += alpha'(src) * w                      (p(f(row)) applied by the owner)
-//                  BWD: vf = w * Y(dst), Y = beta * p(f(dst));  acc(row) += vf;  gamma(f(dst)) += vf * ...
+// row sits behind a branch, and that branch is scalar (the ROW flag is the same in all 64 lanes).
+//   FWD: acc(row) += alpha'(src) * w * p(pdf)
+//   BWD: vf = w * beta(dst) * p(pdf); acc(row) += vf; gamma(pdf) += vf * alpha'(row) / alpha_sum
 constexpr int kChunk = 8;
 // gamma_t(pdf) is an occupation posterior (sum over pdfs = 1), accumulated as unsigned fixed point
 // with 31 fractional bits: quantum 4.7e-10, exact (order-independent, bitwise reproducible) sums.
@@ -153,7 +151,7 @@ __device__ __forceinline__ void gamma_add(float *GM, uint32_t byte_off, float v)
   atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(GM) + byte_off), (uint32_t)q);
 }
 
-template <bool BWD, bool ALPHA_LDS, bool TIED>
+template <bool BWD, bool ALPHA_LDS>
 __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState &rs,
                                               const float *__restrict__ SRC, const float *__restrict__ PB,
                                               float *__restrict__ ACC, float *__restrict__ GM,
@@ -163,7 +161,7 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
     a[u] = lds_at(SRC, q[u].y >> 16);
-    if (!TIED) pp[u] = lds_at(PB, q[u].y & 0xfffcu);
+    pp[u] = lds_at(PB, q[u].y & 0xfffcu);
   }
 #pragma unroll
   for (int u = 0; u < kChunk; ++u) {
@@ -183,9 +181,9 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState
       w = 0.f;  // the arc math below then adds nothing for this cell
     }
     if (!BWD) {
-      rs.acc = TIED ? fmaf(a[u], w, rs.acc) : fmaf(a[u] * w, pp[u], rs.acc);
+      rs.acc = fmaf(a[u] * w, pp[u], rs.acc);
     } else {
-      const float vf = TIED ? w * a[u] : w * a[u] * pp[u];
+      const float vf = w * a[u] * pp[u];
       rs.acc += vf;
       gamma_add(GM, q[u].y & 0xfffcu, vf * rs.occf);  // a ROW cell adds 0 at its lane-aligned dummy offset
     }
@@ -197,7 +195,7 @@ __device__ __forceinline__ void process_chunk(const uint2 (&q)[kChunk], RowState
 // iteration is fetched at the top of this one and only made scalar at the bottom, so its L2 round trip
 // is never waited for on its own (vmcnt retires in order: waiting for it early would drain the
 // prefetched chunk as well).
-template <bool BWD, bool ALPHA_LDS, bool TIED>
+template <bool BWD, bool ALPHA_LDS>
 __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int lane, int dummy_row,
                                           const float *__restrict__ SRC, const float *__restrict__ PB,
                                           float *__restrict__ ACC, float *__restrict__ GM,
@@ -236,9 +234,9 @@ __device__ __forceinline__ void walk_rows(const ScheduleDev &sc, int wave, int l
       __builtin_amdgcn_s_setprio(0);
     // the stream is followed by kStreamUnroll readable padding cells, so these loads need no guard
     load_chunk(qb, c + kChunk);
-    process_chunk<BWD, ALPHA_LDS, TIED>(qa, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    process_chunk<BWD, ALPHA_LDS>(qa, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
     load_chunk(qa, c + kStreamUnroll);
-    process_chunk<BWD, ALPHA_LDS, TIED>(qb, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
+    process_chunk<BWD, ALPHA_LDS>(qb, rs, SRC, PB, ACC, GM, AL, hist_t, inv_asum);
   }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -527,7 +525,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     if (TIED)
       walk_rows6<PV * 16 * kThreads, kFwdRes>(fwd_r, fwd_n, fwd_m, q0, fwd_rc, fres0, fres1 TC_WALK_PASS);
     else
-      walk_rows<false, true, false>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
+      walk_rows<false, true>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
     if (!TIED || p.fwd.nfix) {
       __syncthreads();  // all row sums committed (tied graphs: only when rows were split)
@@ -695,7 +693,7 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
     if (TIED)  // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
       walk_rows6<PV * 16 * kThreads, 0>(bwd_r, bwd_n, bwd_m, q0, bwd_rc, q0, q0 TC_WALK_PASS);
     else
-      walk_rows<true, ALPHA_LDS, false>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
+      walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
     if (TIED && ALPHA_LDS) {
       // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
 #pragma unroll
