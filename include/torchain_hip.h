@@ -50,8 +50,8 @@ int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs
                         const float *final_weight, int32_t start_state, int32_t num_pdfs);
 
 /* Replaces my_lib_denominator_graph_new(rxfilename, num_pdf) (src/my_lib.h:29) for a den.fst on disk:
- * reads an OpenFst binary VectorFst<StdArc> file (what fst::ReadFstKaldi accepts for a plain
- * filename) and calls tc_den_graph_create. */
+ * reads an OpenFst binary VectorFst<StdArc> (what fst::ReadFstKaldi accepts) from a plain filename or
+ * from a Kaldi-style piped rxfilename ("gunzip -c den.fst.gz |") and calls tc_den_graph_create. */
 int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pdfs);
 
 /* Replaces my_lib_denominator_graph_free (src/my_lib.h:30). */

@@ -111,6 +111,22 @@ def test_den_fst_file_reader(tmp_path):
         io.DenominatorGraph(str(tmp_path / "junk.fst"), 25)
 
 
+def test_den_fst_piped_rxfilename(tmp_path):
+    """Kaldi rxfilenames may be commands ("gunzip -c den.fst.gz |"): the reader runs them and parses
+    their output; a failing command is an IO error."""
+    import gzip
+    fst = synth.random_den_fst(50, 4, 30, seed=2)
+    path = tmp_path / "den.fst"
+    write_openfst_vector(str(path), fst)
+    with open(path, "rb") as f, gzip.open(str(path) + ".gz", "wb") as g:
+        g.write(f.read())
+    a = io.DenominatorGraph(str(path), 30)
+    b = io.DenominatorGraph("gunzip -c %s.gz |" % path, 30)
+    np.testing.assert_array_equal(a.initial_probs(), b.initial_probs())
+    with pytest.raises(Exception):
+        io.DenominatorGraph("false |", 30)
+
+
 def test_supervision_handle_accessors():
     fst = synth.random_den_fst(30, 3, 20, seed=3)
     sup = synth.random_supervision(fst, 4, 9, 3, seed=1, weight=0.5)

@@ -4,6 +4,7 @@
 // the host replay of the schedules and the per-device immutable copies.
 #include <algorithm>
 #include <array>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -227,7 +228,13 @@ extern "C" {
 int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pdfs) {
   if (!out || !rxfilename) return TC_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  FILE *f = fopen(rxfilename, "rb");
+  // Kaldi rxfilename forms ([K] ParseInputPath): a plain path, or "command |" whose output is read
+  // (e.g. "gunzip -c den.fst.gz |"); "-" / offsets into archives are not needed for a den.fst
+  std::string name(rxfilename);
+  while (!name.empty() && isspace((unsigned char)name.back())) name.pop_back();
+  const bool is_pipe = !name.empty() && name.back() == '|';
+  if (is_pipe) name.pop_back();
+  FILE *f = is_pipe ? popen(name.c_str(), "r") : fopen(name.c_str(), "rb");
   if (!f) return TC_ERR_IO;
   Reader r{f};
   int rc = TC_OK;
@@ -268,7 +275,11 @@ int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pd
     }
     if (!r.ok) rc = TC_ERR_IO;
   } while (0);
-  fclose(f);
+  if (is_pipe) {
+    if (pclose(f) != 0 && rc == TC_OK) rc = TC_ERR_IO;
+  } else {
+    fclose(f);
+  }
   if (rc != TC_OK) return rc;
   return tc_den_graph_create(out, (int32_t)nstates, (int64_t)src.size(), src.data(), dst.data(), il.data(), w.data(),
                              fin.data(), (int32_t)start, num_pdfs);
