@@ -417,6 +417,18 @@ __device__ __forceinline__ float tied_alpha(const float *PB, uint32_t fs, float 
   return fmaf(lds_at(PB, fs & 0xffffu), F, lds_at(PB, fs >> 16) * (ws * a_self));
 }
 
+// The CU serves older waves first wherever waves contend, so the youngest wave of each SIMD finishes its
+// walk last and every frame waits for it.  During the tied walks the four wave generations therefore run
+// at issue priorities 0..3, youngest highest (-1.5 % run time; keeping the priority through the per-state
+// pass as well is worse).
+#define TC_AGE_PRIO_ON                                            \
+  {                                                               \
+    if (wave >= 12) __builtin_amdgcn_s_setprio(3);                \
+    else if (wave >= 8) __builtin_amdgcn_s_setprio(2);            \
+    else if (wave >= 4) __builtin_amdgcn_s_setprio(1);            \
+  }
+#define TC_AGE_PRIO_OFF __builtin_amdgcn_s_setprio(0);
+
 template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV, bool TIED>
 __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p) {
   extern __shared__ __align__(16) float lds[];
@@ -523,7 +535,11 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       for (int v = 0; v < PV; ++v) yreg[v] = load_row4(yrow, 4 * (tid + kThreads * v), P, p.y_vec);
     }
     if (TIED)
+    {
+      TC_AGE_PRIO_ON
       walk_rows6<PV * 16 * kThreads, kFwdRes>(fwd_r, fwd_n, fwd_m, q0, fwd_rc, fres0, fres1 TC_WALK_PASS);
+      TC_AGE_PRIO_OFF
+    }
     else
       walk_rows<false, true>(p.fwd, wave, lane, Hs, A0, PB, ACC, nullptr, nullptr, nullptr, 0.f);
     TC_STAMP(2)
@@ -691,7 +707,11 @@ __global__ __launch_bounds__(kThreads) void den_fwd_bwd_kernel(const DenParams p
       }
     }
     if (TIED)  // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
+    {
+      TC_AGE_PRIO_ON
       walk_rows6<PV * 16 * kThreads, 0>(bwd_r, bwd_n, bwd_m, q0, bwd_rc, q0, q0 TC_WALK_PASS);
+      TC_AGE_PRIO_OFF
+    }
     else
       walk_rows<true, ALPHA_LDS>(p.bwd, wave, lane, Hs, A0, PBcur, ACC, GM, AL, hist_t, inv_as);
     if (TIED && ALPHA_LDS) {
