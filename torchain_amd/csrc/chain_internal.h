@@ -21,8 +21,6 @@ constexpr int kWaves = kThreads / 64;
 // the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 constexpr int kJvSmall = 2048 / kThreads, kPvSmall = 1024 / kThreads, kJvLarge = 4096 / kThreads, kPvLarge = 3072 / kThreads;
 constexpr int kPvMid = 2048 / kThreads;  // 4097..8192 pdfs
-// the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
-// the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 constexpr int kMaxRowLen = 32;             // longer in/out-arc lists are split into virtual rows
 constexpr int kLdsLimitBytes = 160 * 1024; // gfx950 LDS per CU / per workgroup
 
@@ -60,6 +58,9 @@ constexpr uint32_t kRowFlag = 1u;  // low two bits of a cell's offset word are f
 // no gain, and it pushes the fused kernel past 128 VGPRs)
 constexpr int kStreamUnroll = 16;
 constexpr int kStreamUnrollTied = 8;  // tied streams: a wave's range is padded to whole chunks
+// ... and to at least this many chunks: the tied kernel keeps a prefix of every wave's stream in registers
+// (den_tied_kernel.hip), which must exist whatever the graph
+constexpr int kTiedMinChunks = 6;
 constexpr int kMaxIndex = 1 << 14;
 
 struct ScheduleHost {
@@ -268,6 +269,7 @@ int64_t layout_lds_bytes(const DenLayout &L, int T);
 
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
+int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,

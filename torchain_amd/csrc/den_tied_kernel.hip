@@ -1,0 +1,650 @@
+// Fused denominator forward-backward for TIED (chain-structured) graphs on gfx950 -- the kernel the
+// headline metric times.
+//
+// What it computes: [K] DenominatorComputation::Forward() + Backward() (chain-denominator.cc), reached by the
+// reference through src/my_lib_chain.cpp:129-131.  Same mapping as den_kernels.hip (one workgroup = one
+// sequence = one CU, the per-frame working set in LDS) with the factorisation tied graphs allow: every
+// non-self-loop arc entering a state g carries one pdf f(g), so exp(y) leaves the arc sums --
+//   forward   F(g)  = sum_{h->g} w * alpha'_t(h)            one LDS gather + one FMA per arc
+//             alpha_{t+1}(g) * asum_t = p_t(f(g)) * F(g) + p_t(s(g)) * w_s(g) * alpha'_t(g)
+//   backward  B(h)  = sum_{h->g} w * Y_t(g),  Y_t(g) = beta_{t+1}(g) * p_t(f(g))
+//             gamma_t from per-state quantities only (two integer LDS atomics per STATE, none per arc)
+// -- and the schedules are OWNER-COMPUTES (schedule_owner.cpp): the thread that owns a state walks its arc
+// list in both directions, so row sums never cross threads.
+//
+// Where the time went before this file existed: every frame each CU pulled its 6-byte-per-arc cell
+// stream (344 KB per direction at C3) from L2, 26 GB per launch chip-wide -- the L2 -> CU path, not HBM and
+// not the LDS gathers, set the pace.  A wave's stream is the same every frame, so this kernel keeps the
+// first RESF (forward phase) / RESB (backward phase) chunks of every wave's stream in REGISTERS for the
+// whole phase and streams only the remainder.  That needs the registers: addresses are uniform base +
+// 32-bit lane offset (SGPR-pair + one VGPR instead of 64-bit per-lane pointers), the 16-bit LDS offsets of
+// resident cells are unpacked on the fly (the compiler would otherwise hoist the unpacking out of the frame
+// loop and spend one more register per cell), and a row end costs one scalar bit test per cell.
+#include "den_device.h"
+
+namespace tc {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) uint32_t lds_u;
+typedef __attribute__((address_space(3))) f4 lds_f4;
+typedef __attribute__((address_space(3))) u4 lds_u4;
+
+// LDS by absolute byte address: the kernel has no static __shared__, so the dynamic block starts at 0 and
+// constant parts of an address fold into the ds instruction's immediate offset.
+__device__ __forceinline__ float ldsf(uint32_t a) { return *reinterpret_cast<lds_f *>(a); }
+__device__ __forceinline__ void ldsf_st(uint32_t a, float v) { *reinterpret_cast<lds_f *>(a) = v; }
+__device__ __forceinline__ f4 lds4(uint32_t a) { return *reinterpret_cast<lds_f4 *>(a); }
+__device__ __forceinline__ void lds4_st(uint32_t a, f4 v) { *reinterpret_cast<lds_f4 *>(a) = v; }
+__device__ __forceinline__ u4 lds4u(uint32_t a) { return *reinterpret_cast<lds_u4 *>(a); }
+__device__ __forceinline__ void lds_add_u32(uint32_t a, uint32_t v) {
+  __hip_atomic_fetch_add(reinterpret_cast<lds_u *>(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Global memory through buffer descriptors: a wave-uniform 128-bit resource in SGPRs + one 32-bit VGPR
+// byte offset (the same VGPR for every table: 16 * tid or 16 * lane) + an SGPR / immediate offset.  With
+// flat addressing the compiler materialises (and, being loop-invariant, hoists) one 64-bit VGPR address per
+// load -- registers this kernel needs for the resident stream.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *ubase, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ubase), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u4 bld4u(rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ f4 bld4(rsrc_t r, uint32_t voff, uint32_t soff) {
+  const u4 v = bld4u(r, voff, soff);
+  return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+__device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, uint32_t soff, f4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
+                                         r, (int)voff, (int)soff, 0);
+}
+
+__device__ __forceinline__ f4 mk4(float x) { return f4{x, x, x, x}; }
+__device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ f4 exp4(f4 y) { return f4{exp_limited(y.x), exp_limited(y.y), exp_limited(y.z), exp_limited(y.w)}; }
+
+// one row of y or of the derivative through its descriptor (num_records = the row's bytes: reads past the
+// row return 0, writes past it are dropped): a 16-byte access when the caller's rows are 16-byte aligned,
+// else four dword accesses
+__device__ __forceinline__ f4 row_ld(rsrc_t r, uint32_t voff, int vec) {
+  if (vec) return bld4(r, voff, 0);
+  return f4{__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0)),
+            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 4, 0)),
+            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 8, 0)),
+            __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 12, 0))};
+}
+__device__ __forceinline__ void row_st(rsrc_t r, uint32_t voff, int vec, f4 v) {
+  if (vec) {
+    bst4(r, voff, 0, v);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, (int)voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), r, (int)voff, 4, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), r, (int)voff, 8, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), r, (int)voff, 12, 0);
+  }
+}
+
+__device__ __forceinline__ float block_sum_a(float v, uint32_t red, int wave, uint32_t lane) {
+  v = wave_sum(v);
+  if (lane == 0) ldsf_st(red + 4u * (uint32_t)wave, v);
+  __syncthreads();
+  static_assert(kWaves == 16, "one DPP row holds the wave totals");
+  float t = ldsf(red + 4u * (lane & 15u));
+  t = dpp_add<0xB1>(t);
+  t = dpp_add<0x4E>(t);
+  t = dpp_add<0x124>(t);
+  t = dpp_add<0x128>(t);
+  return t;
+}
+
+__device__ __forceinline__ void gamma_add_a(uint32_t addr, float v) {
+  int32_t q;  // floor(v + 0.5), v >= 0 (den_device.h: gamma_add)
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(v));
+  lds_add_u32(addr, (uint32_t)q);
+}
+
+// ---- the cell stream ---------------------------------------------------------------------------------
+// A chunk is 8 cells of one lane: {w0..w3}, {w4..w7}, {off01, off23, off45, off67} with fp32 weights and
+// 16-bit LDS byte offsets of the gathers; stored [chunk][3 blocks][lane]{16 bytes} (schedule_owner.cpp), so
+// a chunk is three coalesced dwordx4 loads.
+struct Chunk6 {
+  u4 wa, wb, oc;
+};
+
+__device__ __forceinline__ void load_chunk(Chunk6 &q, rsrc_t stream, uint32_t lane16, int chunk) {
+  const uint32_t so = (uint32_t)chunk * (3 * 64 * 16);
+  q.wa = bld4u(stream, lane16, so);
+  q.wb = bld4u(stream, lane16, so + 1024);
+  q.oc = bld4u(stream, lane16, so + 2048);
+}
+
+// The unpacking of resident cells is loop-invariant over the frames; left to the compiler it is hoisted
+// and every resident cell then holds a second register.  volatile asm pins it to its use.
+__device__ __forceinline__ uint32_t lo16(uint32_t x) {
+  uint32_t r;
+  asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ uint32_t hi16(uint32_t x) {
+  uint32_t r;
+  asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// Where a finished row sum goes: all 64 lanes of a wave are at the same row index k.  Own rows (k < K)
+// land in the thread's own accumulator slots -- position 4 * (tid + 1024 * (k >> 2)) + (k & 3) -- and are
+// read back by the same thread; secondary rows (k >= K, hub states only) in 64 consecutive private slots.
+struct RowCommit {
+  uint32_t own, fix;
+  int k, K;
+  __device__ __forceinline__ void commit(float v) {
+    const uint32_t addr = k < K ? own + (uint32_t)(((k & 3) << 2) + ((k >> 2) << 14)) : fix + (uint32_t)((k - K) << 8);
+    ldsf_st(addr, v);
+    ++k;
+  }
+};
+
+// acc(row) += w * SRC[off] over one chunk.  Row ends are wave-uniform bits of the schedule's mask word m
+// (one word per two chunks; bit u: a row ends with the SECOND cell of pair u, bit 8 + u: with its FIRST
+// cell), tested with s_bitcmp; the commit is the rare side of a scalar branch.
+template <uint32_t SRC, int HALF>
+__device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc, RowCommit &rc) {
+  uint32_t o[8];
+  o[0] = lo16(q.oc.x);
+  o[1] = hi16(q.oc.x);
+  o[2] = lo16(q.oc.y);
+  o[3] = hi16(q.oc.y);
+  o[4] = lo16(q.oc.z);
+  o[5] = hi16(q.oc.z);
+  o[6] = lo16(q.oc.w);
+  o[7] = hi16(q.oc.w);
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#ifdef TC_ABL_NOGATHER
+    a[i] = __uint_as_float(o[i]);
+#else
+    a[i] = ldsf(SRC + o[i]);
+#endif
+  }
+  const uint32_t w[8] = {q.wa.x, q.wa.y, q.wa.z, q.wa.w, q.wb.x, q.wb.y, q.wb.z, q.wb.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc = fmaf(a[i], __uint_as_float(w[i]), acc);
+    const int bit = (i & 1) ? 4 * HALF + i / 2 : 8 + 4 * HALF + i / 2;
+    if (__builtin_expect((m >> bit) & 1u, 0)) {
+      rc.commit(acc);
+      acc = 0.f;
+    }
+  }
+}
+
+// One walk of a wave's stream: RES resident chunks, then the rest through two register buffers in
+// ping-pong (qa arrives preloaded with chunk RES when there is one; the stream is followed by readable
+// padding, so the look-ahead loads need no guard).  The mask words come through the scalar cache.
+template <uint32_t SRC, int RES>
+__device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chunk6 &qa, rsrc_t sbase,
+                                     uint32_t lane16, int nchunks, const uint32_t *masks, RowCommit rc) {
+  static_assert(RES % 2 == 0, "a mask word covers two chunks");
+  typedef __attribute__((address_space(4))) const uint32_t const_u32;
+  const_u32 *mk = (const_u32 *)masks;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < RES / 2; ++i) {
+    const uint32_t m = mk[i];
+    do_chunk<SRC, 0>(res[2 * i], m, acc, rc);
+    do_chunk<SRC, 1>(res[2 * i + 1], m, acc, rc);
+  }
+  Chunk6 qb;
+  for (int c = RES; c < nchunks; c += 2) {
+    const uint32_t m = mk[c >> 1];
+    load_chunk(qb, sbase, lane16, c + 1);
+    do_chunk<SRC, 0>(qa, m, acc, rc);
+    if (c + 1 >= nchunks) break;
+    load_chunk(qa, sbase, lane16, c + 2);
+    do_chunk<SRC, 1>(qb, m, acc, rc);
+  }
+}
+
+// The CU serves older waves first wherever waves contend, so the youngest wave of each SIMD finishes its
+// walk last and every frame waits for it: during the walks the four wave generations run at issue
+// priorities 0..3, youngest highest.
+__device__ __forceinline__ void age_prio_on(int wave) {
+  if (wave >= 12)
+    __builtin_amdgcn_s_setprio(3);
+  else if (wave >= 8)
+    __builtin_amdgcn_s_setprio(2);
+  else if (wave >= 4)
+    __builtin_amdgcn_s_setprio(1);
+}
+
+// fs = forward-pdf*4 | self-loop-pdf*4 << 16 (LDS byte offsets into exp(y)), ws = self-loop probability
+__device__ __forceinline__ float tied_alpha(uint32_t pb, uint32_t fs, float ws, float F, float a_self) {
+  return fmaf(ldsf(pb + (fs & 0xffffu)), F, ldsf(pb + (fs >> 16)) * (ws * a_self));
+}
+
+constexpr uint32_t kPlane = 16u * kThreads;  // bytes between a thread's float4s of consecutive planes
+
+template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV, int RESF, int RESB>
+__global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x;
+  const int H = p.H, P = p.P, S = p.S, T = p.T;
+  const int Hs = p.L.Hs, Ps = p.L.Ps;
+  // tied graphs are laid out in whole planes of 4096 positions (schedule_owner.cpp build_owner): which of its
+  // JV float4s of states a thread really has is wave-uniform
+  const int planes = Hs / (4 * kThreads);
+  const uint32_t own16 = 16u * tid, lane16 = 16u * lane;
+  constexpr uint32_t kPB = 0u;                  // exp(y_t)
+  constexpr uint32_t kA0 = PV * 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
+  const uint32_t aACC = 4u * (uint32_t)p.L.off_acc;  // row sums: one slot per state, then secondary-row slots
+  const uint32_t aGM = 4u * (uint32_t)p.L.off_g;     // gamma_t, u32 fixed point (backward)
+  const uint32_t aAL = 4u * (uint32_t)p.L.off_al;    // alpha'_{t+1} of the owned states (backward, roomy layout)
+  const uint32_t aRed = 4u * (uint32_t)p.L.off_red;
+  const uint32_t aAsum = 4u * (uint32_t)p.L.off_asum;  // alpha-sum of every frame
+
+  const uint32_t tab_bytes = 4u * (uint32_t)(Hs + 4), row_bytes = 4u * (uint32_t)P;
+  const rsrc_t r_pi = make_rsrc(p.pi, tab_bytes), r_fs = make_rsrc(p.tied_fs, tab_bytes), r_ws = make_rsrc(p.tied_w, tab_bytes);
+  // leaky * pi of the owned states is re-read with the other per-state tables every frame (an L2 hit)
+  // rather than held in registers: the registers go to the resident stream
+  const float leaky = p.leaky;
+  f4 pi4[JV];  // (dead after frame 0)
+  float part = 0.f;
+#pragma unroll
+  for (int j = 0; j < JV; ++j) {
+    pi4[j] = j < planes ? bld4(r_pi, own16, j * kPlane) : mk4(0.f);
+    part += hsum(pi4[j]);
+  }
+  // ---- t = 0: alpha_0 = pi, alpha'_0 = pi + leaky*pi*sum(pi)   ([K] AlphaFirstFrame + AlphaDash(0))
+  float asum = block_sum_a(part, aRed, wave, lane);
+  const int64_t hist_step = (int64_t)S * Hs;
+  float *const hist = p.alpha_hist + (int64_t)s * Hs;  // frame t lives at hist + t * hist_step
+#pragma unroll
+  for (int j = 0; j < JV; ++j)
+    if (j < planes) {
+      const f4 a = pi4[j] + (leaky * pi4[j]) * asum;
+      lds4_st(kA0 + own16 + j * kPlane, a);
+      bst4(make_rsrc(hist, 4u * Hs), own16, j * kPlane, a);
+    }
+  float y2 = 0.f;
+  {
+    const rsrc_t yrow = make_rsrc(p.y + (int64_t)s * p.y_stride, row_bytes);
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * ((int)tid + kThreads * v);
+      if (i0 < Ps) {
+        const f4 yv = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+        y2 += hsum(yv * yv);
+        lds4_st(kPB + 4u * i0, exp4(yv));
+      }
+    }
+  }
+  double logsum = 0.0;  // thread 0 only
+  if (tid == 0) ldsf_st(aAsum, asum);
+  float inv_prev = 1.0f / asum;
+  float asum_prev = asum;
+
+  // ---- forward frames t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
+  {
+    const int2 frange = p.fwd.wave_range[wave];
+    const int fnch = __builtin_amdgcn_readfirstlane(frange.y) / kChunk;
+    // (the descriptor covers the wave's range and the look-ahead past it: the array ends with readable padding)
+    const rsrc_t fbase = make_rsrc(reinterpret_cast<const char *>(p.fwd.cells) +
+                                       (int64_t)(__builtin_amdgcn_readfirstlane(frange.x) / kChunk) * (3 * 64 * 16),
+                                   (uint32_t)(fnch + 2) * (3 * 64 * 16));
+    const uint32_t *const fmask = p.fwd.masks + wave * p.fwd.mask_stride;
+    const int ffx0 = p.fwd.nfix ? p.fwd.fix_begin[tid] : 0, ffx1 = p.fwd.nfix ? p.fwd.fix_begin[tid + 1] : 0;
+    RowCommit frc{aACC + own16, aACC + 4u * (uint32_t)(Hs + 4 + 64 * p.fwd.extra_first[wave]) + 4u * lane, 0,
+                  Hs / kThreads};
+    Chunk6 fres[RESF > 0 ? RESF : 1];
+#pragma unroll
+    for (int i = 0; i < RESF; ++i) load_chunk(fres[i], fbase, lane16, i);
+    TC_STAMP_DECL
+    for (int t = 1; t <= T; ++t) {
+      TC_STAMP(0)
+      Chunk6 q0;
+      load_chunk(q0, fbase, lane16, RESF);  // (past a short stream: readable padding, never processed)
+      __syncthreads();  // alpha'_{t-1}, exp(y_{t-1}) ready
+      TC_STAMP(1)
+      f4 yreg[PV];
+      if (t < T) {  // y_t under the arc walk
+        const rsrc_t yrow = make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes);
+#pragma unroll
+        for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+      }
+      age_prio_on(wave);
+      walk<kA0, RESF>(fres, q0, fbase, lane16, fnch, fmask, frc);
+      __builtin_amdgcn_s_setprio(0);
+      TC_STAMP(2)
+      if (p.fwd.nfix) {
+        __syncthreads();  // secondary rows committed (graphs with hub states only)
+        for (int e = ffx0; e < ffx1; ++e) {
+          const int2 f = p.fwd.fix[e];
+          ldsf_st(aACC + 4u * f.x, ldsf(aACC + 4u * f.x) + ldsf(aACC + 4u * f.y));
+        }
+      }
+      TC_STAMP(3)
+      f4 v4[JV];
+      part = 0.f;
+      u4 fs[JV];
+      f4 ws[JV], cpi[JV];
+#pragma unroll
+      for (int j = 0; j < JV; ++j)
+        if (j < planes) {
+          fs[j] = bld4u(r_fs, own16, j * kPlane);
+          ws[j] = bld4(r_ws, own16, j * kPlane);
+          cpi[j] = leaky * bld4(r_pi, own16, j * kPlane);
+        }
+#pragma unroll
+      for (int j = 0; j < JV; ++j) {
+        v4[j] = mk4(0.f);
+        if (j < planes) {
+          const f4 F = lds4(aACC + own16 + j * kPlane);
+          const f4 al = lds4(kA0 + own16 + j * kPlane);  // alpha'_{t-1} of the owned states
+          // alpha_t(g) * asum_{t-1} = p(f(g)) * sum_{h != g} w alpha'_{t-1}(h) + p(s(g)) * w_s * alpha'_{t-1}(g)
+          const f4 a = f4{tied_alpha(kPB, fs[j].x, ws[j].x, F.x, al.x), tied_alpha(kPB, fs[j].y, ws[j].y, F.y, al.y),
+                          tied_alpha(kPB, fs[j].z, ws[j].z, F.z, al.z), tied_alpha(kPB, fs[j].w, ws[j].w, F.w, al.w)};
+          v4[j] = a * inv_prev;
+          part += hsum(v4[j]);
+        }
+      }
+      asum = block_sum_a(part, aRed, wave, lane);
+      TC_STAMP(4)
+      const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs);
+      float part_tot = 0.f;
+#pragma unroll
+      for (int j = 0; j < JV; ++j)
+        if (j < planes) {
+          const f4 a = v4[j] + cpi[j] * asum;
+          lds4_st(kA0 + own16 + j * kPlane, a);
+          bst4(hist_t, own16, j * kPlane, a);
+          part_tot += hsum(a);
+        }
+      if (t < T) {
+#pragma unroll
+        for (int v = 0; v < PV; ++v) {
+          const int i0 = 4 * ((int)tid + kThreads * v);
+          if (i0 < Ps) {
+            y2 += hsum(yreg[v] * yreg[v]);
+            lds4_st(kPB + 4u * i0, exp4(yreg[v]));
+          }
+        }
+      }
+      if (tid == 0) {
+        ldsf_st(aAsum + 4u * t, asum);
+        logsum += (double)__logf(asum_prev);  // log of the scale divided out of frame t
+      }
+      asum_prev = asum;
+      inv_prev = 1.0f / asum;
+      if (t == T) part = part_tot;
+    }
+    TC_STAMP(0)
+    TC_STAMP_FLUSH(p.stamps)
+  }
+  // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h)
+  const float tot = block_sum_a(part, aRed + 4u * kWaves, wave, lane);
+  {
+    const double y2d = (double)block_sum_a(y2, aRed + 8u * kWaves, wave, lane);
+    if (tid == 0) {
+      p.seq_logprob[s] = logsum + (double)__logf(tot);
+      p.seq_y2[s] = y2d;
+    }
+  }
+  if (!WANT_DERIV) return;
+
+  // ---- backward   ([K] BetaDashLastFrame, Beta(T), then BetaDashGeneralFrame(t) + Beta(t))
+  // beta'_T(h) = 1/tot;  beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h).  The LDS regions now hold
+  // Y (gather source), the row sums, exp(y_t), exp(y_{t-1}), gamma_t and (roomy layout) alpha'_{t+1}.
+  const float inv_tot = 1.0f / tot;
+  part = 0.f;
+#pragma unroll
+  for (int j = 0; j < JV; ++j)
+    if (j < planes) part += hsum(leaky * bld4(r_pi, own16, j * kPlane)) * inv_tot;
+  float bsum = block_sum_a(part, aRed + 12u * kWaves, wave, lane);  // also orders the reuse of the gather buffer
+  f4 areg[JV];
+  f4 ycur[PV], ynext[PV];
+  f4 bown[JV];  // beta_{t+1} of the owned states (the LDS gather source holds Y instead)
+  // two exp(y) buffers: frame t (self-loop terms of the per-state pass) and frame t-1 (written under the arc
+  // walk, needed to form Y for the next frame); the tight layout has one and pays a barrier instead
+  uint32_t pb_cur = kPB, pb_next = ALPHA_LDS ? 4u * (uint32_t)p.L.off_p2 : kPB;
+  const int2 brange = p.bwd.wave_range[wave];
+  const int bnch = __builtin_amdgcn_readfirstlane(brange.y) / kChunk;
+  const rsrc_t bbase = make_rsrc(reinterpret_cast<const char *>(p.bwd.cells) +
+                                     (int64_t)(__builtin_amdgcn_readfirstlane(brange.x) / kChunk) * (3 * 64 * 16),
+                                 (uint32_t)(bnch + 2) * (3 * 64 * 16));
+  const uint32_t *const bmask = p.bwd.masks + wave * p.bwd.mask_stride;
+  const int bfx0 = p.bwd.nfix ? p.bwd.fix_begin[tid] : 0, bfx1 = p.bwd.nfix ? p.bwd.fix_begin[tid + 1] : 0;
+  RowCommit brc{aACC + own16, aACC + 4u * (uint32_t)(Hs + 4 + 64 * p.bwd.extra_first[wave]) + 4u * lane, 0, Hs / kThreads};
+  Chunk6 bres[RESB > 0 ? RESB : 1];
+#pragma unroll
+  for (int i = 0; i < RESB; ++i) load_chunk(bres[i], bbase, lane16, i);
+  {
+    const rsrc_t hist_up = make_rsrc(hist + (int64_t)T * hist_step, 4u * Hs);
+    const rsrc_t yrow = make_rsrc(p.y + ((int64_t)(T - 1) * S + s) * p.y_stride, row_bytes);
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      bown[j] = mk4(0.f);
+      if (j < planes) {
+        const int h0 = 4 * ((int)tid + kThreads * j);
+        const float b = inv_tot + bsum;
+        bown[j] = f4{h0 < H ? b : 0.f, h0 + 1 < H ? b : 0.f, h0 + 2 < H ? b : 0.f, h0 + 3 < H ? b : 0.f};
+        lds4_st(aACC + own16 + j * kPlane, mk4(0.f));  // states with no out-arcs
+        if (ALPHA_LDS) lds4_st(aAL + own16 + j * kPlane, bld4(hist_up, own16, j * kPlane));
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * ((int)tid + kThreads * v);
+      ycur[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+      if (i0 < Ps) {
+        lds4_st(pb_cur + 4u * i0, exp4(ycur[v]));
+        lds4_st(aGM + 4u * i0, mk4(0.f));
+      }
+    }
+    __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = beta_T(g) * p_{T-1}(f(g))
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (j < planes) {
+        const u4 fs = bld4u(r_fs, own16, j * kPlane);
+        lds4_st(kA0 + own16 + j * kPlane,
+                f4{bown[j].x * ldsf(pb_cur + (fs.x & 0xffffu)), bown[j].y * ldsf(pb_cur + (fs.y & 0xffffu)),
+                   bown[j].z * ldsf(pb_cur + (fs.z & 0xffffu)), bown[j].w * ldsf(pb_cur + (fs.w & 0xffffu))});
+      }
+  }
+  TC_STAMP_DECL
+  for (int t = T - 1; t >= 0; --t) {
+    TC_STAMP(0)
+    Chunk6 q0;
+    load_chunk(q0, bbase, lane16, RESB);
+    __syncthreads();  // Y, exp(y_t), alpha'_{t+1} ready; row sums and gamma zero
+    TC_STAMP(1)
+    const float asum_t = ldsf(aAsum + 4u * t);
+    const float inv_as = 1.0f / asum_t;
+    const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs);
+    {
+      // frame t-1's y row and alpha'_t of the owned states under the arc walk; at t == 0 y re-reads frame 0
+      const int tn = t > 0 ? t - 1 : 0;
+      const rsrc_t yrow = make_rsrc(p.y + ((int64_t)tn * S + s) * p.y_stride, row_bytes);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) ynext[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+#pragma unroll
+      for (int j = 0; j < JV; ++j) areg[j] = j < planes ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
+    }
+    // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
+    age_prio_on(wave);
+    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc);
+    __builtin_amdgcn_s_setprio(0);
+    if (ALPHA_LDS) {
+      // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * ((int)tid + kThreads * v);
+        if (i0 < Ps) lds4_st(pb_next + 4u * i0, exp4(ynext[v]));
+      }
+    }
+    TC_STAMP(2)
+    if (p.bwd.nfix) {
+      __syncthreads();  // secondary rows committed (graphs with hub states only)
+      for (int e = bfx0; e < bfx1; ++e) {
+        const int2 f = p.bwd.fix[e];
+        ldsf_st(aACC + 4u * f.x, ldsf(aACC + 4u * f.x) + ldsf(aACC + 4u * f.y));
+      }
+    }
+    TC_STAMP(3)
+    f4 b4[JV];
+    part = 0.f;
+    float part_ab = 0.f, part_g = 0.f;
+    const float asum_up = ldsf(aAsum + 4u * (t + 1));
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      b4[j] = mk4(0.f);
+      if (j < planes) {
+        const u4 fs = bld4u(r_fs, own16, j * kPlane);
+        const f4 ws = bld4(r_ws, own16, j * kPlane);
+        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
+        f4 a = lds4(aACC + own16 + j * kPlane);
+        const f4 al = areg[j];
+        // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
+        const f4 aup = ALPHA_LDS ? lds4(aAL + own16 + j * kPlane) : bld4(make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs), own16, j * kPlane);
+        // Everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
+        //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
+        //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
+        //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
+        // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history.  The self-loop arc also
+        // adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
+        auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float ax) {
+          const float ps_ws = ldsf(pb_cur + (fsx >> 16)) * wsx;
+          const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
+          const float alpha_up = aupx - cpx * asum_up;   // alpha_{t+1}(g)
+          const float bos = kGammaScale * bo;            // power-of-two scale: exact
+          gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
+          gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf(alpha_up - selfpart, 0.f));
+          return fmaf(ps_ws, bo, ax);                    // vf_s into beta'_t(g) * asum_t
+        };
+        a.x = one(fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x);
+        a.y = one(fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y);
+        a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z);
+        a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w);
+        b4[j] = a * inv_as;  // [K] * inv_arbitrary_scale
+        part += hsum(cp * b4[j]);
+        if (t == 0) part_ab += hsum(al * b4[j]);
+      }
+    }
+    bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
+    TC_STAMP(4)
+    {
+      const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * ((int)tid + kThreads * v);
+        if (i0 < Ps) {
+          const u4 gu = lds4u(aGM + 4u * i0);
+          lds4_st(aGM + 4u * i0, mk4(0.f));
+          const f4 g = f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} * kGammaInvScale;
+          if (t == 0) part_g += hsum(g);
+          f4 o = p.deriv_weight * g - p.l2_scale * ycur[v];
+          if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
+          row_st(drow, own16 + v * kPlane, p.d_vec, o);
+        }
+      }
+    }
+    if (t == 0) {
+      // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
+      const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
+      const float gs = block_sum_a(part_g, aRed + 8u * kWaves, wave, lane);
+      if (tid == 0) {
+        p.seq_ab[s] = ab;
+        p.seq_gsum[s] = gs;
+      }
+#ifdef TC_PHASE_STAMPS
+      if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) p.stamps[128 + wave * 8 + i] = st_acc[i];
+#endif
+      break;
+    }
+    if (!ALPHA_LDS) {
+      // tight layout: exp(y_{t-1}) overwrites exp(y_t) in place -- its readers (the per-state pass) are
+      // behind the reduction's barrier -- and one more barrier publishes it to the Y update below
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * ((int)tid + kThreads * v);
+        if (i0 < Ps) lds4_st(kPB + 4u * i0, exp4(ynext[v]));
+      }
+      __syncthreads();
+    }
+    // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (j < planes) {
+        const f4 b = b4[j] + bsum;
+        bown[j] = b;
+        const u4 fs = bld4u(r_fs, own16, j * kPlane);
+        lds4_st(kA0 + own16 + j * kPlane,
+                f4{b.x * ldsf(pb_next + (fs.x & 0xffffu)), b.y * ldsf(pb_next + (fs.y & 0xffffu)),
+                   b.z * ldsf(pb_next + (fs.z & 0xffffu)), b.w * ldsf(pb_next + (fs.w & 0xffffu))});
+        if (ALPHA_LDS) lds4_st(aAL + own16 + j * kPlane, areg[j]);
+      }
+#pragma unroll
+    for (int v = 0; v < PV; ++v) ycur[v] = ynext[v];
+    const uint32_t tmp = pb_cur;
+    pb_cur = pb_next;
+    pb_next = tmp;
+  }
+}
+
+#ifndef TC_RESF
+#define TC_RESF 4
+#endif
+#ifndef TC_RESB
+#define TC_RESB 4
+#endif
+
+template <int JV, int PV>
+int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipStream_t stream) {
+  constexpr int RF = JV <= 2 ? TC_RESF : 0, RB = JV <= 2 ? TC_RESB : 0;
+  const bool want = p.deriv != nullptr;
+  const bool al = p.L.alpha_in_lds;
+  void (*k)(const DenParams) = nullptr;
+  if (!want)
+    k = den_tied_kernel<JV, PV, true, false, false, RF, RB>;
+  else if (accumulate)
+    k = al ? den_tied_kernel<JV, PV, true, true, true, RF, RB> : den_tied_kernel<JV, PV, false, true, true, RF, RB>;
+  else
+    k = al ? den_tied_kernel<JV, PV, true, false, true, RF, RB> : den_tied_kernel<JV, PV, false, false, true, RF, RB>;
+  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+}  // namespace
+
+static_assert(TC_RESF <= kTiedMinChunks && TC_RESB <= kTiedMinChunks, "the resident prefix must exist in every wave's stream");
+
+int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream) {
+  const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
+  if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
+  const int JV = p.L.JV, PV = p.L.PV;
+#define TC_DISPATCH(J, V) \
+  if (JV == J && PV == V) return launch_jp<J, V>(p, accumulate, lds, stream);
+#ifdef TC_ONLY_C3
+  TC_DISPATCH(kJvSmall, kPvSmall)
+#else
+  TC_DISPATCH(kJvSmall, kPvSmall)
+  TC_DISPATCH(kJvSmall, kPvMid)
+  TC_DISPATCH(kJvSmall, kPvLarge)
+  TC_DISPATCH(kJvLarge, kPvSmall)
+  TC_DISPATCH(kJvLarge, kPvMid)
+  TC_DISPATCH(kJvLarge, kPvLarge)
+#endif
+#undef TC_DISPATCH
+  return TC_ERR_UNSUPPORTED;
+}
+
+}  // namespace tc

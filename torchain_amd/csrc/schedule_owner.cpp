@@ -80,9 +80,11 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       // bit 0 (B): the row ends with the pair's second cell; bit 1 (A): with its first cell
       row_end[(cells_before - 1) / 2] |= ((cells_before - 1) & 1) ? 1 : 2;
     }
-    // whole chunks, and at least two of them (the forward walk keeps its first two chunks in registers)
-    while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 || out->cells.size() / 64 - first < 2 * kStreamUnrollTied)
+    // whole chunks, and at least kTiedMinChunks of them (the walks keep a prefix of the stream in registers)
+    while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 ||
+           out->cells.size() / 64 - first < (size_t)kTiedMinChunks * kStreamUnrollTied)
       for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
+    row_end.resize((out->cells.size() / 64 - first) / 2, 0);  // the padding cells end no row
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
     if (getenv("TC_SCHED_DEBUG")) fprintf(stderr, "[sched] wave %d: %d cells, %zu rows\n", w, out->wave_range[w].y, slots[w].size());
     auto &mw = wave_masks[w];
