@@ -66,7 +66,12 @@ __device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, uint32_t soff, f4 
 
 __device__ __forceinline__ f4 mk4(float x) { return f4{x, x, x, x}; }
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
-__device__ __forceinline__ f4 exp4(f4 y) { return f4{exp_limited(y.x), exp_limited(y.y), exp_limited(y.z), exp_limited(y.w)}; }
+// exp(clamp(y, -30, 30)) ([K] later Kaldi: ApplyExpLimited; equal to the 22fbdd ApplyExp() for |y| < 30) with the
+// clamp as one v_med3_f32.  That clamp would turn a NaN input into exp(-30); the sum of y^2, which this kernel
+// forms anyway, carries every NaN / inf of the row into the sequence's log-prob (see seq_logprob below), so the
+// objective still fails softly as in [K].
+__device__ __forceinline__ float exp_med3(float x) { return __expf(__builtin_amdgcn_fmed3f(x, -30.0f, 30.0f)); }
+__device__ __forceinline__ f4 exp4(f4 y) { return f4{exp_med3(y.x), exp_med3(y.y), exp_med3(y.z), exp_med3(y.w)}; }
 
 // one row of y or of the derivative through its descriptor (num_records = the row's bytes: reads past the
 // row return 0, writes past it are dropped): a 16-byte access when the caller's rows are 16-byte aligned,
@@ -187,9 +192,12 @@ __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc
 // One walk of a wave's stream: RES resident chunks, then the rest through two register buffers in
 // ping-pong (qa arrives preloaded with chunk RES when there is one; the stream is followed by readable
 // padding, so the look-ahead loads need no guard).  The mask words come through the scalar cache.
-template <uint32_t SRC, int RES>
+// `pre_last` runs just before the wave's last chunk is processed: the place to request what the per-state
+// pass needs from L2 (one streaming buffer is free by then and the chunk's gathers cover the latency).
+template <uint32_t SRC, int RES, class PreLast>
 __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chunk6 &qa, rsrc_t sbase,
-                                     uint32_t lane16, int nchunks, const uint32_t *masks, RowCommit rc) {
+                                     uint32_t lane16, int nchunks, const uint32_t *masks, RowCommit rc,
+                                     PreLast pre_last) {
   static_assert(RES % 2 == 0, "a mask word covers two chunks");
   typedef __attribute__((address_space(4))) const uint32_t const_u32;
   const_u32 *mk = (const_u32 *)masks;
@@ -200,13 +208,20 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
     do_chunk<SRC, 0>(res[2 * i], m, acc, rc);
     do_chunk<SRC, 1>(res[2 * i + 1], m, acc, rc);
   }
+  if (nchunks == RES) pre_last();  // (only graphs padded up to the resident prefix)
   Chunk6 qb;
   for (int c = RES; c < nchunks; c += 2) {
     const uint32_t m = mk[c >> 1];
-    load_chunk(qb, sbase, lane16, c + 1);
+    if (c + 1 < nchunks)
+      load_chunk(qb, sbase, lane16, c + 1);
+    else
+      pre_last();
     do_chunk<SRC, 0>(qa, m, acc, rc);
     if (c + 1 >= nchunks) break;
-    load_chunk(qa, sbase, lane16, c + 2);
+    if (c + 2 < nchunks)
+      load_chunk(qa, sbase, lane16, c + 2);
+    else
+      pre_last();
     do_chunk<SRC, 1>(qb, m, acc, rc);
   }
 }
@@ -285,10 +300,8 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       }
     }
   }
-  double logsum = 0.0;  // thread 0 only
   if (tid == 0) ldsf_st(aAsum, asum);
-  float inv_prev = 1.0f / asum;
-  float asum_prev = asum;
+  float inv_prev = __builtin_amdgcn_rcpf(asum);
 
   // ---- forward frames t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
   {
@@ -305,6 +318,19 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     Chunk6 fres[RESF > 0 ? RESF : 1];
 #pragma unroll
     for (int i = 0; i < RESF; ++i) load_chunk(fres[i], fbase, lane16, i);
+    // The forward phase does not use the gamma / alpha'_{t+1} / second exp(y) regions: when they hold the two
+    // per-state tables (C3: exactly), each thread parks its own entries there and the per-state pass reads
+    // them at LDS latency instead of waiting for L2 every frame.
+    const bool tabs_lds = (p.L.off_red - p.L.off_g) >= 2 * Hs;
+    const uint32_t aFS = aGM, aWS = aGM + 4u * (uint32_t)Hs;
+    if (tabs_lds) {
+#pragma unroll
+      for (int j = 0; j < JV; ++j)
+        if (j < planes) {
+          *reinterpret_cast<lds_u4 *>(aFS + own16 + j * kPlane) = bld4u(r_fs, own16, j * kPlane);
+          lds4_st(aWS + own16 + j * kPlane, bld4(r_ws, own16, j * kPlane));
+        }
+    }
     TC_STAMP_DECL
     for (int t = 1; t <= T; ++t) {
       TC_STAMP(0)
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
       }
       age_prio_on(wave);
-      walk<kA0, RESF>(fres, q0, fbase, lane16, fnch, fmask, frc);
+      walk<kA0, RESF>(fres, q0, fbase, lane16, fnch, fmask, frc, [] {});
       __builtin_amdgcn_s_setprio(0);
       TC_STAMP(2)
       if (p.fwd.nfix) {
@@ -337,9 +363,9 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
 #pragma unroll
       for (int j = 0; j < JV; ++j)
         if (j < planes) {
-          fs[j] = bld4u(r_fs, own16, j * kPlane);
-          ws[j] = bld4(r_ws, own16, j * kPlane);
-          cpi[j] = leaky * bld4(r_pi, own16, j * kPlane);
+          fs[j] = tabs_lds ? lds4u(aFS + own16 + j * kPlane) : bld4u(r_fs, own16, j * kPlane);
+          ws[j] = tabs_lds ? lds4(aWS + own16 + j * kPlane) : bld4(r_ws, own16, j * kPlane);
+          cpi[j] = leaky * bld4(r_pi, own16, j * kPlane);  // (consumed behind the reduction)
         }
 #pragma unroll
       for (int j = 0; j < JV; ++j) {
@@ -376,12 +402,8 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
           }
         }
       }
-      if (tid == 0) {
-        ldsf_st(aAsum + 4u * t, asum);
-        logsum += (double)__logf(asum_prev);  // log of the scale divided out of frame t
-      }
-      asum_prev = asum;
-      inv_prev = 1.0f / asum;
+      if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
+      inv_prev = __builtin_amdgcn_rcpf(asum);
       if (t == T) part = part_tot;
     }
     TC_STAMP(0)
@@ -392,7 +414,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   {
     const double y2d = (double)block_sum_a(y2, aRed + 8u * kWaves, wave, lane);
     if (tid == 0) {
-      p.seq_logprob[s] = logsum + (double)__logf(tot);
+      // [K] log-prob = log(tot) + sum over t < T of log(alpha-sum_t): the scales divided out of frames 1..T
+      double logsum = 0.0;
+      for (int t = 0; t < T; ++t) logsum += (double)__logf(ldsf(aAsum + 4u * t));
+      p.seq_logprob[s] = logsum + (double)__logf(tot) + (y2d - y2d);  // (+ 0, or NaN for a NaN / inf input)
       p.seq_y2[s] = y2d;
     }
   }
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   // ---- backward   ([K] BetaDashLastFrame, Beta(T), then BetaDashGeneralFrame(t) + Beta(t))
   // beta'_T(h) = 1/tot;  beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h).  The LDS regions now hold
   // Y (gather source), the row sums, exp(y_t), exp(y_{t-1}), gamma_t and (roomy layout) alpha'_{t+1}.
-  const float inv_tot = 1.0f / tot;
+  const float inv_tot = __builtin_amdgcn_rcpf(tot);
   part = 0.f;
 #pragma unroll
   for (int j = 0; j < JV; ++j)
@@ -465,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     __syncthreads();  // Y, exp(y_t), alpha'_{t+1} ready; row sums and gamma zero
     TC_STAMP(1)
     const float asum_t = ldsf(aAsum + 4u * t);
-    const float inv_as = 1.0f / asum_t;
+    const float inv_as = __builtin_amdgcn_rcpf(asum_t);
     const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs);
     {
       // frame t-1's y row and alpha'_t of the owned states under the arc walk; at t == 0 y re-reads frame 0
@@ -478,7 +503,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     }
     // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
     age_prio_on(wave);
-    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc);
+    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [] {});
     __builtin_amdgcn_s_setprio(0);
     if (ALPHA_LDS) {
       // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
@@ -498,6 +523,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     }
     TC_STAMP(3)
     f4 b4[JV];
+    uint32_t fpk[JV][2];  // forward-pdf offsets of the owned states, kept for the Y update below
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
     const float asum_up = ldsf(aAsum + 4u * (t + 1));
@@ -532,6 +558,8 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z);
         a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w);
         b4[j] = a * inv_as;  // [K] * inv_arbitrary_scale
+        fpk[j][0] = (fs.x & 0xffffu) | (fs.y << 16);
+        fpk[j][1] = (fs.z & 0xffffu) | (fs.w << 16);
         part += hsum(cp * b4[j]);
         if (t == 0) part_ab += hsum(al * b4[j]);
       }
@@ -584,10 +612,9 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       if (j < planes) {
         const f4 b = b4[j] + bsum;
         bown[j] = b;
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
         lds4_st(kA0 + own16 + j * kPlane,
-                f4{b.x * ldsf(pb_next + (fs.x & 0xffffu)), b.y * ldsf(pb_next + (fs.y & 0xffffu)),
-                   b.z * ldsf(pb_next + (fs.z & 0xffffu)), b.w * ldsf(pb_next + (fs.w & 0xffffu))});
+                f4{b.x * ldsf(pb_next + (fpk[j][0] & 0xffffu)), b.y * ldsf(pb_next + (fpk[j][0] >> 16)),
+                   b.z * ldsf(pb_next + (fpk[j][1] & 0xffffu)), b.w * ldsf(pb_next + (fpk[j][1] >> 16))});
         if (ALPHA_LDS) lds4_st(aAL + own16 + j * kPlane, areg[j]);
       }
 #pragma unroll
