@@ -141,16 +141,20 @@ __device__ __forceinline__ uint32_t hi16(uint32_t x) {
   return r;
 }
 
-// Where a finished row sum goes: all 64 lanes of a wave are at the same row index k.  Own rows (k < K)
-// land in the thread's own accumulator slots -- position 4 * (tid + 1024 * (k >> 2)) + (k & 3) -- and are
-// read back by the same thread; secondary rows (k >= K, hub states only) in 64 consecutive private slots.
+// Where a finished row sum goes.  All 64 lanes of a wave are at the same row index k, so the row sums are
+// kept [row][lane]: own rows of wave w at rows w * K + k, secondary rows (k >= K, hub states only) behind
+// them.  A commit is then ds_write_addtid_b32 -- address = M0 + 4 * lane, no address VGPR (a VGPR that is only
+// read in the rare commit block is the first thing the register allocator spills, and its reload would sit in
+// the middle of the walk behind a vmcnt(0)), 256 contiguous bytes per wave, twice the rate of ds_write_b32 --
+// and the cursor is one scalar.
 struct RowCommit {
-  uint32_t own, fix;
-  int k, K;
+  uint32_t row;       // byte address of lane 0's slot of the current row
+  uint32_t sec_row;   // ... of the wave's first secondary row
+  int left;           // own rows still to come
   __device__ __forceinline__ void commit(float v) {
-    const uint32_t addr = k < K ? own + (uint32_t)(((k & 3) << 2) + ((k >> 2) << 14)) : fix + (uint32_t)((k - K) << 8);
-    ldsf_st(addr, v);
-    ++k;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(v), "s"(row) : "memory", "m0");
+    --left;
+    row = left == 0 ? sec_row : row + 256u;
   }
 };
 
@@ -243,6 +247,21 @@ __device__ __forceinline__ float tied_alpha(uint32_t pb, uint32_t fs, float ws, 
   return fmaf(ldsf(pb + (fs & 0xffffu)), F, ldsf(pb + (fs >> 16)) * (ws * a_self));
 }
 
+// row sums of the four states of a thread's float4 in plane j: rows 4j .. 4j+3 of its wave
+__device__ __forceinline__ f4 own_rows(uint32_t vrow, int j) {
+  return f4{ldsf(vrow + 256u * (4 * j)), ldsf(vrow + 256u * (4 * j + 1)), ldsf(vrow + 256u * (4 * j + 2)),
+            ldsf(vrow + 256u * (4 * j + 3))};
+}
+
+// Graphs with hub states: adds a secondary row's sum to its state's own row.  f = {position of the state (owned
+// by this thread), logical slot Hs + 4 + 64 * e + lane of the secondary row} as the schedule builder numbers them.
+__device__ __forceinline__ void fold_row(int2 f, uint32_t vrow, uint32_t aACC, int Hs, int K) {
+  const int k = 4 * (f.x / (4 * kThreads)) + (f.x & 3);
+  const uint32_t dst = vrow + 256u * (uint32_t)k;
+  const uint32_t src = aACC + 256u * (uint32_t)(K * kWaves) + 4u * (uint32_t)(f.y - Hs - 4);
+  ldsf_st(dst, ldsf(dst) + ldsf(src));
+}
+
 constexpr uint32_t kPlane = 16u * kThreads;  // bytes between a thread's float4s of consecutive planes
 
 template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV, int RESF, int RESB>
@@ -255,10 +274,12 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   // tied graphs are laid out in whole planes of 4096 positions (schedule_owner.cpp build_owner): which of its
   // JV float4s of states a thread really has is wave-uniform
   const int planes = Hs / (4 * kThreads);
+  const int K = Hs / kThreads;  // own rows per lane
   const uint32_t own16 = 16u * tid, lane16 = 16u * lane;
   constexpr uint32_t kPB = 0u;                  // exp(y_t)
   constexpr uint32_t kA0 = PV * 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
-  const uint32_t aACC = 4u * (uint32_t)p.L.off_acc;  // row sums: one slot per state, then secondary-row slots
+  const uint32_t aACC = 4u * (uint32_t)p.L.off_acc;  // row sums [row][lane]: K per wave, then the secondary rows
+  const uint32_t vrow = aACC + 256u * (uint32_t)(K * wave) + 4u * lane;  // this thread's slot of its wave's row 0
   const uint32_t aGM = 4u * (uint32_t)p.L.off_g;     // gamma_t, u32 fixed point (backward)
   const uint32_t aAL = 4u * (uint32_t)p.L.off_al;    // alpha'_{t+1} of the owned states (backward, roomy layout)
   const uint32_t aRed = 4u * (uint32_t)p.L.off_red;
@@ -313,8 +334,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
                                    (uint32_t)(fnch + 2) * (3 * 64 * 16));
     const uint32_t *const fmask = p.fwd.masks + wave * p.fwd.mask_stride;
     const int ffx0 = p.fwd.nfix ? p.fwd.fix_begin[tid] : 0, ffx1 = p.fwd.nfix ? p.fwd.fix_begin[tid + 1] : 0;
-    RowCommit frc{aACC + own16, aACC + 4u * (uint32_t)(Hs + 4 + 64 * p.fwd.extra_first[wave]) + 4u * lane, 0,
-                  Hs / kThreads};
+    const RowCommit frc{aACC + 256u * (uint32_t)(K * wave), aACC + 256u * (uint32_t)(K * kWaves + p.fwd.extra_first[wave]), K};
     Chunk6 fres[RESF > 0 ? RESF : 1];
 #pragma unroll
     for (int i = 0; i < RESF; ++i) load_chunk(fres[i], fbase, lane16, i);
@@ -350,10 +370,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       TC_STAMP(2)
       if (p.fwd.nfix) {
         __syncthreads();  // secondary rows committed (graphs with hub states only)
-        for (int e = ffx0; e < ffx1; ++e) {
-          const int2 f = p.fwd.fix[e];
-          ldsf_st(aACC + 4u * f.x, ldsf(aACC + 4u * f.x) + ldsf(aACC + 4u * f.y));
-        }
+        for (int e = ffx0; e < ffx1; ++e) fold_row(p.fwd.fix[e], vrow, aACC, Hs, K);
       }
       TC_STAMP(3)
       f4 v4[JV];
@@ -371,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       for (int j = 0; j < JV; ++j) {
         v4[j] = mk4(0.f);
         if (j < planes) {
-          const f4 F = lds4(aACC + own16 + j * kPlane);
+          const f4 F = own_rows(vrow, j);
           const f4 al = lds4(kA0 + own16 + j * kPlane);  // alpha'_{t-1} of the owned states
           // alpha_t(g) * asum_{t-1} = p(f(g)) * sum_{h != g} w alpha'_{t-1}(h) + p(s(g)) * w_s * alpha'_{t-1}(g)
           const f4 a = f4{tied_alpha(kPB, fs[j].x, ws[j].x, F.x, al.x), tied_alpha(kPB, fs[j].y, ws[j].y, F.y, al.y),
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
                                  (uint32_t)(bnch + 2) * (3 * 64 * 16));
   const uint32_t *const bmask = p.bwd.masks + wave * p.bwd.mask_stride;
   const int bfx0 = p.bwd.nfix ? p.bwd.fix_begin[tid] : 0, bfx1 = p.bwd.nfix ? p.bwd.fix_begin[tid + 1] : 0;
-  RowCommit brc{aACC + own16, aACC + 4u * (uint32_t)(Hs + 4 + 64 * p.bwd.extra_first[wave]) + 4u * lane, 0, Hs / kThreads};
+  const RowCommit brc{aACC + 256u * (uint32_t)(K * wave), aACC + 256u * (uint32_t)(K * kWaves + p.bwd.extra_first[wave]), K};
   Chunk6 bres[RESB > 0 ? RESB : 1];
 #pragma unroll
   for (int i = 0; i < RESB; ++i) load_chunk(bres[i], bbase, lane16, i);
@@ -459,7 +476,6 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         const int h0 = 4 * ((int)tid + kThreads * j);
         const float b = inv_tot + bsum;
         bown[j] = f4{h0 < H ? b : 0.f, h0 + 1 < H ? b : 0.f, h0 + 2 < H ? b : 0.f, h0 + 3 < H ? b : 0.f};
-        lds4_st(aACC + own16 + j * kPlane, mk4(0.f));  // states with no out-arcs
         if (ALPHA_LDS) lds4_st(aAL + own16 + j * kPlane, bld4(hist_up, own16, j * kPlane));
       }
     }
@@ -516,10 +532,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     TC_STAMP(2)
     if (p.bwd.nfix) {
       __syncthreads();  // secondary rows committed (graphs with hub states only)
-      for (int e = bfx0; e < bfx1; ++e) {
-        const int2 f = p.bwd.fix[e];
-        ldsf_st(aACC + 4u * f.x, ldsf(aACC + 4u * f.x) + ldsf(aACC + 4u * f.y));
-      }
+      for (int e = bfx0; e < bfx1; ++e) fold_row(p.bwd.fix[e], vrow, aACC, Hs, K);
     }
     TC_STAMP(3)
     f4 b4[JV];
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         const u4 fs = bld4u(r_fs, own16, j * kPlane);
         const f4 ws = bld4(r_ws, own16, j * kPlane);
         const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
-        f4 a = lds4(aACC + own16 + j * kPlane);
+        f4 a = own_rows(vrow, j);
         const f4 al = areg[j];
         // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
         const f4 aup = ALPHA_LDS ? lds4(aAL + own16 + j * kPlane) : bld4(make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs), own16, j * kPlane);
