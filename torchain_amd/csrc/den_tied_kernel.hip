@@ -638,16 +638,20 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   }
 }
 
+// Resident chunks per phase for each instantiation: what the 128 registers of a 1024-thread workgroup hold
+// next to the per-thread state (JV float4s of states, PV float4s of pdfs).
 #ifndef TC_RESF
 #define TC_RESF 4
 #endif
 #ifndef TC_RESB
 #define TC_RESB 4
 #endif
+constexpr int res_fwd(int jv, int pv) { return jv > 2 ? 0 : pv == 1 ? TC_RESF : 2; }
+constexpr int res_bwd(int jv, int pv) { return jv > 2 ? 0 : pv == 1 ? TC_RESB : 2; }
 
 template <int JV, int PV>
 int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipStream_t stream) {
-  constexpr int RF = JV <= 2 ? TC_RESF : 0, RB = JV <= 2 ? TC_RESB : 0;
+  constexpr int RF = res_fwd(JV, PV), RB = res_bwd(JV, PV);
   const bool want = p.deriv != nullptr;
   const bool al = p.L.alpha_in_lds;
   void (*k)(const DenParams) = nullptr;
