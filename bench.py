@@ -5,19 +5,22 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path -- tc_den_forward_backward, i.e. [K] DenominatorComputation
-Forward() + Backward() writing d/dy -- over one synthetic batch resident in HBM.  With N > 1 the
-driver launches one process per GPU (torch.distributed.run); each rank owns its own 256-sequence
-shard (weak scaling, no data-path collective) and every step ends with the path's only exchange, one
-RCCL all-reduce of the three floats (objf, l2_term, weight).  Rank 0 prints ONE JSON line.
+Forward() + Backward() writing d/dy, with the batch's denominator log-prob and the t=0 status reduced on
+the device -- over one synthetic batch resident in HBM.  With N > 1 there is one process per GPU: launched
+by the driver through torch.distributed.run, or, when this script is started plainly with --gpus N, by
+this script itself as N fresh children (before anything here touches the GPU).  Each rank owns its own
+256-sequence shard (weak scaling, no data-path collective) and every step ends with the path's only
+exchange, one RCCL all-reduce of the three floats (objf, l2_term, weight) of the rank's shard.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,30 +32,47 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", help="workload name in torchain_amd.synth.CONFIGS")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the oracle check")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed full-objective / layout measurements")
     ap.add_argument("--cpu-seqs", type=int, default=256, help="sequences in the CPU-baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(fst, cfg, nseq):
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as children of a fresh
+    torch.distributed.run (this process has not touched the GPU and never will) and exit with its code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baseline(fst, cfg, y_np, nseq):
     """Times the oracle (a port of Kaldi's single-threaded CPU DenominatorComputation) on a bounded
-    sample of the same workload: `nseq` of the batch's sequences, all frames.  Work is exactly linear
-    in the number of sequences, so sequence-frames/s transfers to the full batch."""
+    sample of the same workload: the first `nseq` of the batch's sequences, all frames.  Work is exactly
+    linear in the number of sequences, so sequence-frames/s transfers to the full batch.  Returns the
+    baseline record and the oracle's outputs on the sample (the checker of the GPU run)."""
+    import numpy as np
     from oracle import pyoracle
     from torchain_amd import synth
     pyoracle.build()
     g = pyoracle.DenGraph(fst)
-    T, P = cfg["T"], cfg["P"]
-    y = synth.random_nnet_output(nseq, T, P, seed=1234 + 3)
+    S, T, P = cfg["S"], cfg["T"], cfg["P"]
+    y = np.ascontiguousarray(y_np.reshape(T, S, P)[:, :nseq, :].reshape(T * nseq, P))
     reps = 2
+    ref = None
     t0 = time.perf_counter()
     for _ in range(reps):
-        pyoracle.den_forward_backward(g, y, nseq, leaky=cfg["leaky"], deriv_weight=-1.0)
+        ref = pyoracle.den_forward_backward(g, y, nseq, leaky=cfg["leaky"], deriv_weight=-1.0)
     dt = time.perf_counter() - t0
     out = {"value": reps * nseq * T / dt, "unit": "sequence-frames/s", "cores": 1, "kind": "port",
            "sample": "%d x (%d of the batch's %d sequences x %d frames), full graph, single thread (Kaldi's CPU "
-                     "chain path is single-threaded); %.1f s" % (reps, nseq, cfg["S"], T, dt)}
+                     "chain path is single-threaded); %.1f s" % (reps, nseq, S, T, dt)}
     ncpu = os.cpu_count() or 1
     if ncpu > 1:
         threads = min(ncpu, 64)
@@ -63,7 +83,7 @@ def cpu_baseline(fst, cfg, nseq):
         dt2 = time.perf_counter() - t0
         out["all_cores"] = {"value": n2 * T / dt2, "cores": threads,
                             "sample": "%d sequences in blocks of 8, OpenMP over blocks; %.1f s" % (n2, dt2)}
-    return out
+    return out, ref
 
 
 def extras(graph, fst, cfg, S, T, P, dev):
@@ -103,20 +123,57 @@ def extras(graph, fst, cfg, S, T, P, dev):
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))  # before torch / HIP is touched in this process
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+
+    if os.environ.get("TC_BENCH_LAUNCH_TEST"):
+        # CPU check of the launcher alone (tests/test_bench_launcher.py): rendezvous over gloo, the same
+        # 3-float SUM all-reduce, one JSON line from rank 0; no GPU, no kernel.
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([-1.0, -0.5, 38400.0])
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"launch_test": True, "n_gpus": dist.get_world_size(), "weight": float(t[2])}))
+        dist.destroy_process_group()
+        return
+
+    import numpy as np
     import torch
     from torchain_amd import io, synth
     from torchain_amd._lib import check, lib
+    from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    # TC_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank (used to check that path on a 1-GPU box)
+    # TC_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank (checks that path on a 1-GPU box)
     if world > 1 or os.environ.get("TC_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its communicator comes up; stdout must carry rank 0's one
+        # JSON line and nothing else, so fd 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            assert dist.get_world_size() == world
+            dist.all_reduce(torch.zeros(1, device=torch.device("cuda", local_rank)))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -129,17 +186,44 @@ def main():
     H, A = fst.num_states, len(fst.src)
     graph = io.DenominatorGraph(fst, P).prepare(dev)
     gstats = graph.stats()
+    l2 = cfg.get("l2", 0.0)
 
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + 3 + rank)
-    y = torch.randn(S * T, P, device=dev, generator=gen)
+    # this rank's shard of the synthetic batch: N(0, 1) outputs, generated on the host
+    # so that the CPU oracle can be run on exactly the same numbers
+    y_np = synth.random_nnet_output(S, T, P, seed=1234 + 3 + rank)
+    y = torch.from_numpy(y_np).to(dev)
     deriv = torch.empty_like(y)
     nbytes = lib.tc_chain_workspace_bytes(graph.ptr, S, T)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     lp = torch.zeros(1, dtype=torch.float64, device=dev)
     st = torch.zeros(1, dtype=torch.int32, device=dev)
-    red = torch.zeros(3, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()
+
+    def den_step():
+        rc = lib.tc_den_forward_backward(
+            graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), cfg["leaky"], -1.0, l2, 0,
+            C.c_void_p(deriv.data_ptr()), deriv.stride(0), C.c_void_p(lp.data_ptr()), C.c_void_p(st.data_ptr()),
+            C.c_void_p(ws.data_ptr()), nbytes, dev.index, C.c_void_p(stream.cuda_stream))
+        check(rc, "tc_den_forward_backward")
+
+    # The path's one exchange.  The three floats are REAL: (objf, l2_term, weight) of this rank's shard from
+    # one untimed full-objective call; every timed step all-reduces a fresh copy of them.
+    exchange = None
+    local3 = red = None
+    if dist is not None:
+        sup = synth.random_supervision(fst, S, T, 3, seed=7 + rank, initial_probs=graph.initial_probs())
+        hsup = io.Supervision.from_synth(sup)
+        res = ChainResults()
+        compute_chain_objf_and_deriv(graph, hsup, y, res.data, deriv, None, l2, cfg["leaky"], 0.0)
+        local3 = res.data.to(dev)
+        red = local3.clone()
+        dist.all_reduce(red)
+        torch.cuda.synchronize()
+        total = red.cpu()
+        assert float(total[2]) == float(world * S * T), (total, world, S, T)  # reduced weight = N * S * T
+        exchange = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "objf": float(total[0]),
+                    "l2_term": float(total[1]), "weight": float(total[2]),
+                    "loss": float(-total[0] / total[2])}
 
     pending = [None]
 
@@ -148,31 +232,27 @@ def main():
             pending[0].wait()
             pending[0] = None
 
-    def step(with_reduce):
-        rc = lib.tc_den_forward_backward(
-            graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), cfg["leaky"], -1.0, cfg.get("l2", 0.0), 0,
-            C.c_void_p(deriv.data_ptr()), deriv.stride(0),
-            C.c_void_p(lp.data_ptr()) if with_reduce else None, C.c_void_p(st.data_ptr()) if with_reduce else None,
-            C.c_void_p(ws.data_ptr()), nbytes, dev.index, C.c_void_p(stream.cuda_stream))
-        check(rc, "tc_den_forward_backward")
+    def step():
+        den_step()
         if dist is not None:
-            # (objf, l2_term, weight): the path's one exchange, 12 bytes over xGMI.  Nothing on the GPU needs
-            # its result (it feeds logging), so it is issued asynchronously and the next step's kernel runs
-            # under it; the previous step's reduction is waited for first, the last one before the timer stops.
-            if pending[0] is not None:
-                pending[0].wait()
+            # 12 bytes over xGMI.  Nothing on the GPU needs the result (it feeds logging), so it is issued
+            # asynchronously and the next step's kernel runs under it; the previous step's reduction is
+            # waited for first, the last one before the timer stops.
+            drain()
+            red.copy_(local3)
             pending[0] = dist.all_reduce(red, async_op=True)
 
     # device warm-up (not a bench step, outside every timed region): the first few dozen launches after
-    # an idle period run 10-30 % slow while the clocks ramp (profiles/r01_summary.json: trace_first8_ns)
+    # an idle period run 10-30 % slow while the clocks ramp
     for _ in range(40):
-        step(False)
+        den_step()
     for _ in range(args.warmup):
-        step(True)
+        step()
     drain()
     torch.cuda.synchronize()
     status = int(st.item())
     logprob = float(lp.item())
+    deriv_chk = deriv[: T * S].clone() if rank == 0 else None
 
     # ---- the timed region: exactly K steps, barrier + synchronize on both sides
     if dist is not None:
@@ -180,7 +260,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(False)
+        step()
     drain()
     torch.cuda.synchronize()
     if dist is not None:
@@ -191,6 +271,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        assert float(red.cpu()[2]) == float(world * S * T)
 
     # ---- per-launch duration of the dominant kernel, HIP events on the launch stream
     kern_ms = []
@@ -198,7 +279,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         rc = lib.tc_den_forward_backward(
-            graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), cfg["leaky"], -1.0, cfg.get("l2", 0.0), 0,
+            graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), cfg["leaky"], -1.0, l2, 0,
             C.c_void_p(deriv.data_ptr()), deriv.stride(0), None, None, C.c_void_p(ws.data_ptr()), nbytes, dev.index,
             C.c_void_p(stream.cuda_stream))
         e1.record(stream)
@@ -215,13 +296,17 @@ def main():
         bytes_alg = 8.0 * S * T * P + 8.0 * S * (T + 1) * (H + 1)
         peak = 8000.0  # GB/s, MI355X HBM3E spec (MI355X_MICROARCH.md)
         achieved = bytes_alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = ("profiles/traffic_%s.json: rocprofv3 PMC (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, "
+                               "separate passes) of this kernel, collected by scripts/collect_profiles.sh, not by this run"
+                               % args.config)
             except Exception:
                 traffic = None
+        tied = gstats["tied"]
         out = {
             "metric": "sequence-frames/sec through denominator fwd-bwd", "value": value,
             "unit": "sequence-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,14 +317,32 @@ def main():
                        "sequences_per_gpu": S, "frames": T, "pdfs": P, "den_states": H, "den_arcs": A,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic,
-                         "kernel": "den_fwd_bwd_kernel (%s graph path)" % ("tied" if gstats["tied"] else "general"),
-                         "kernel_ms": kern_ms,
-                         "algorithmic_bytes": bytes_alg},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": ("den_tied_kernel (tied graph path)" if tied == 1 else
+                                    "streamed kernels" if tied == 2 else "den_fwd_bwd_kernel (general graph path)"),
+                         "kernel_ms": kern_ms, "algorithmic_bytes": bytes_alg},
             "check": {"den_logprob_per_frame": logprob / (S * T), "status": status},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fst, cfg, args.cpu_seqs)
+            base, ref = cpu_baseline(fst, cfg, y_np, min(args.cpu_seqs, S))
+            out["cpu_baseline"] = base
+            # the oracle's outputs on the sample against the timed kernel's, same y (rows of the sample's
+            # sequences; derivative = -gamma - l2*y for the GPU call, -gamma for the oracle call)
+            n = min(args.cpu_seqs, S)
+            got = deriv_chk.view(T, S, P)[:, :n, :].reshape(T * n, P).cpu().numpy()
+            want = ref["deriv"] - np.float32(l2) * y_np.reshape(T, S, P)[:, :n, :].reshape(T * n, P)
+            err = float(np.abs(got - want).max())
+            chk = out["check"]
+            chk["oracle_sequences"] = n
+            chk["deriv_max_abs_err_vs_oracle"] = err
+            chk["deriv_rel_err_vs_oracle"] = err / max(float(np.abs(want).max()), 1e-30)
+            if n == S:
+                chk["logprob_rel_err_vs_oracle"] = abs(logprob - ref["logprob"]) / abs(ref["logprob"])
+            chk["tolerance"] = 1e-4
+            chk["pass"] = bool(chk["deriv_rel_err_vs_oracle"] <= 1e-4 and
+                               chk.get("logprob_rel_err_vs_oracle", 0.0) <= 1e-4 and status == 0)
         if world == 1 and not args.no_extras:
             out["extras"] = extras(graph, fst, cfg, S, T, P, dev)
         print(json.dumps(out))

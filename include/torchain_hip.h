@@ -161,6 +161,14 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  * direction 1: sum over out-arcs (h->g) of w*gather[g]*pdf_factor[pdf]  (gather: num_states floats,
  * pdf_factor: num_pdfs floats, out: num_states floats).  Lets the schedule builder be tested without a GPU;
  * nothing on the hot path calls it. */
+/* Diagnostic, host only: process-wide switches read when a graph is BUILT (tc_den_graph_create / _read); they
+ * exist so that tests and profiles can put a graph on a kernel family it would not normally take.  Keys:
+ *   "force_general"  (1: never use the tied-graph kernel)      "force_streamed" (1: alpha/beta in HBM, as for graphs
+ *   "no_split"       (1: do not tied-ify nearly tied graphs)                     beyond the on-chip layouts)
+ *   "no_pdf_banks", "no_bank_search" (1: skip those placement passes)   "sched_trace" (1: builder statistics on stderr)
+ * Returns TC_ERR_INVALID_ARGUMENT for an unknown key.  Nothing on the hot path reads these. */
+int tc_debug_set(const char *key, int value);
+
 int tc_den_graph_debug_walk(const tc_den_graph *graph, int direction, const float *gather,
                             const float *pdf_factor, float *out);
 

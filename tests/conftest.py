@@ -19,3 +19,19 @@ def oracle():
     pyoracle.build()
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture
+def kernel_family():
+    """Puts graphs built inside the test on a kernel family they would not normally take, through the
+    library's diagnostic switches (include/torchain_hip.h: tc_debug_set); everything is reset afterwards."""
+    from torchain_amd._lib import check, lib
+    keys = []
+
+    def force(key, value=1):
+        check(lib.tc_debug_set(key.encode(), int(value)), "tc_debug_set(%s)" % key)
+        keys.append(key)
+
+    yield force
+    for key in keys:
+        lib.tc_debug_set(key.encode(), 0)

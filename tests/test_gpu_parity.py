@@ -55,12 +55,12 @@ def test_ragged_small_shapes(oracle, H, deg, P, S, T):
     _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
 
 
-@pytest.mark.parametrize("force", ["TC_FORCE_BIG", "TC_FORCE_GENERAL"])
+@pytest.mark.parametrize("force", ["force_streamed", "force_general"])
 @pytest.mark.parametrize("H,deg,P,S,T", [(1, 1, 1, 1, 2), (7, 3, 5, 1, 1), (130, 4, 77, 3, 9), (70, 3, 65, 65, 3)])
-def test_ragged_small_shapes_other_kernels(oracle, monkeypatch, force, H, deg, P, S, T):
+def test_ragged_small_shapes_other_kernels(oracle, kernel_family, force, H, deg, P, S, T):
     """The same odd sizes through the streamed kernels (sequence counts that are not a multiple of the 64
     lanes included) and through the general on-chip kernel."""
-    monkeypatch.setenv(force, "1")
+    kernel_family(force)
     _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
 
 
@@ -124,7 +124,7 @@ def test_nearly_tied_graph_state_splitting(oracle):
     _check_full(oracle, synth.nearly_tied_den_fst(64, 4, 20, seed=6, fraction=0.3), 2, 9, l2=0.0, leaky=1e-5)
 
 
-def test_streamed_path_for_graphs_beyond_lds(oracle, monkeypatch):
+def test_streamed_path_for_graphs_beyond_lds(oracle, kernel_family):
     """Graphs the on-chip layouts cannot hold (more than 16384 states here) take the streamed kernel
     (alpha/beta in global memory); the same kernel forced onto small graphs, tied and general, must agree
     with the oracle too, including Kaldi's accumulate form."""
@@ -133,7 +133,7 @@ def test_streamed_path_for_graphs_beyond_lds(oracle, monkeypatch):
     g = io.DenominatorGraph(fst, fst.num_pdfs)
     assert g.stats()["tied"] == 2
     _check_full(oracle, fst, 2, 6, l2=1e-4, leaky=0.1)
-    monkeypatch.setenv("TC_FORCE_BIG", "1")
+    kernel_family("force_streamed")
     _check_full(oracle, synth.random_den_fst(300, 5, 100, seed=32), 3, 11, l2=0.0, leaky=1e-5)  # tied streamed kernels
     _check_full(oracle, synth.nearly_tied_den_fst(500, 5, 90, seed=7), 3, 8, l2=1e-4, leaky=0.1)  # ... of a split graph
     _check_full(oracle, synth.skewed_tied_den_fst(400, 7000, 150, seed=8), 2, 9, l2=0.0, leaky=0.05)  # hubs, no-self-loop states
@@ -261,10 +261,10 @@ def test_autograd_wrapper_matches_reference_semantics(oracle):
     assert "ChainResults(loss=" in repr(results)
 
 
-def test_tied_and_general_kernels_agree(oracle, monkeypatch):
+def test_tied_and_general_kernels_agree(oracle, kernel_family):
     """The same chain-structured graph through both device code paths: the factorised "tied" kernel
     (exp(y) taken out of the arc sums, gamma from per-state quantities) and the general kernel
-    (forced with TC_FORCE_GENERAL).  Both must match the oracle; the graph also has states with an
+    (forced with tc_debug_set("force_general")).  Both must match the oracle; the graph also has states with an
     extra self-loop carrying the forward pdf, parallel arcs and a state without a self-loop."""
     from torchain_amd import io
 
@@ -284,9 +284,9 @@ def test_tied_and_general_kernels_agree(oracle, monkeypatch):
     ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1)
     tied_graph = io.DenominatorGraph(fst, fst.num_pdfs)
     assert tied_graph.stats()["tied"] == 1
-    monkeypatch.setenv("TC_FORCE_GENERAL", "1")
+    kernel_family("force_general")
     general_graph = io.DenominatorGraph(fst, fst.num_pdfs)
-    monkeypatch.delenv("TC_FORCE_GENERAL")
+    kernel_family("force_general", 0)
     assert general_graph.stats()["tied"] == 0
     outs = []
     for graph in (tied_graph, general_graph):

@@ -56,27 +56,27 @@ def test_config3_and_config5_graphs_replay():
     check_graph(synth.config_den_fst("C5"), 1)
 
 
-def test_streamed_tables_replay(monkeypatch):
+def test_streamed_tables_replay(kernel_family):
     check_graph(synth.random_den_fst(20000, 3, 700, seed=31), 2)      # tied streamed tables
-    monkeypatch.setenv("TC_FORCE_BIG", "1")
+    kernel_family("force_streamed")
     check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 2)       # general streamed tables
     check_graph(synth.nearly_tied_den_fst(500, 5, 90, seed=7), 2)      # tied streamed tables of a split graph
     check_graph(synth.skewed_tied_den_fst(400, 7000, 150, seed=8), 2)  # tied, hub states, states without self-loop
 
 
-def test_forced_general_matches_tied(monkeypatch):
-    monkeypatch.setenv("TC_FORCE_GENERAL", "1")
+def test_forced_general_matches_tied(kernel_family):
+    kernel_family("force_general")
     check_graph(synth.random_den_fst(1000, 5, 400, seed=3), 0)
 
 
-def test_nearly_tied_graphs_are_split_not_demoted(monkeypatch):
+def test_nearly_tied_graphs_are_split_not_demoted(kernel_family):
     """A few states entered through several pdfs: the builder splits them (exactly) and keeps the graph on
     the tied kernel; with splitting disabled the same graph takes the general path."""
     fst = synth.nearly_tied_den_fst(2000, 6, 300, seed=5)
     check_graph(fst, 1)
     fst2 = synth.nearly_tied_den_fst(64, 4, 20, seed=6, fraction=0.3)
     check_graph(fst2, 1)
-    monkeypatch.setenv("TC_NO_SPLIT", "1")
+    kernel_family("no_split")
     check_graph(fst, 0)
 
 

@@ -284,6 +284,11 @@ int launch_layout(bool to2d, const float *in, float *out, int B, int Cn, int T, 
                   hipStream_t stream);
 
 extern thread_local int g_last_hip_error;
+
+// Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
+// replace what used to be environment variables of the shipping library.
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgCount };
+bool debug_flag(DebugFlag f);
 #define TC_HIP_CHECK(expr)                        \
   do {                                            \
     hipError_t e__ = (expr);                      \

@@ -3,6 +3,7 @@
 // tables (schedule_owner.cpp, schedule_general.cpp, streamed CSR lists here), the OpenFst binary reader,
 // the host replay of the schedules and the per-device immutable copies.
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cctype>
 #include <cmath>
@@ -16,6 +17,9 @@
 namespace tc {
 
 thread_local int g_last_hip_error = 0;
+
+static std::atomic<int> g_debug[kDbgCount];
+bool debug_flag(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed) != 0; }
 
 // CSR lists for the streamed path (chain_internal.h: BigArc)
 static void build_big(tc_den_graph *g) {
@@ -79,7 +83,7 @@ static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
 }
 
 int build_schedules(tc_den_graph *g) {
-  bool want_big = getenv("TC_FORCE_BIG") || g->H > kMaxIndex || g->P > kMaxIndex;
+  bool want_big = debug_flag(kDbgForceStreamed) || g->H > kMaxIndex || g->P > kMaxIndex;
   // ---- the tied path: on the FST as it is, or on its tied-ified work graph
   std::vector<char> special;
   {
@@ -91,8 +95,8 @@ int build_schedules(tc_den_graph *g) {
     g->work_pi = g->initial_probs;
     g->copy_first.resize(g->H + 1);
     std::iota(g->copy_first.begin(), g->copy_first.end(), 0);
-    bool tied = !getenv("TC_FORCE_GENERAL") && detect_tied(g, &special);
-    if (!tied && !getenv("TC_FORCE_GENERAL") && !getenv("TC_NO_SPLIT") && make_work_graph(g)) tied = detect_tied(g, &special);
+    bool tied = !debug_flag(kDbgForceGeneral) && detect_tied(g, &special);
+    if (!tied && !debug_flag(kDbgForceGeneral) && !debug_flag(kDbgNoSplit) && make_work_graph(g)) tied = detect_tied(g, &special);
     g->tied = tied;
   }
   if (!want_big && g->tied) {
@@ -124,6 +128,18 @@ int build_schedules(tc_den_graph *g) {
 using namespace tc;
 
 extern "C" {
+
+int tc_debug_set(const char *key, int value) {
+  static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
+                                               "no_bank_search", "sched_trace"};
+  if (!key) return TC_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < kDbgCount; ++i)
+    if (!strcmp(key, names[i])) {
+      g_debug[i].store(value, std::memory_order_relaxed);
+      return TC_OK;
+    }
+  return TC_ERR_INVALID_ARGUMENT;
+}
 
 int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs, const int32_t *arc_src,
                         const int32_t *arc_dst, const int32_t *arc_ilabel, const float *arc_weight,

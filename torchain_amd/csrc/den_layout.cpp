@@ -173,7 +173,7 @@ int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, 
       mp = std::max(mp, cp[k][b]);
     }
     total += std::max(ms, 1) + use_pdf * std::max(mp, 1);
-    if (getenv("TC_SCHED_DEBUG")) {
+    if (debug_flag(kDbgSchedTrace)) {
       static long long n = 0, sst = 0, spd = 0;
       n++; sst += std::max(ms, 1); spd += std::max(mp, 1);
       if (n % 2000 == 0) fprintf(stderr, "[sched] steps=%lld avg max-mult state=%.3f pdf=%.3f\n", n, (double)sst / n, (double)spd / n);

@@ -86,7 +86,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
     row_end.resize((out->cells.size() / 64 - first) / 2, 0);  // the padding cells end no row
     out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
-    if (getenv("TC_SCHED_DEBUG")) fprintf(stderr, "[sched] wave %d: %d cells, %zu rows\n", w, out->wave_range[w].y, slots[w].size());
+    if (debug_flag(kDbgSchedTrace)) fprintf(stderr, "[sched] wave %d: %d cells, %zu rows\n", w, out->wave_range[w].y, slots[w].size());
     auto &mw = wave_masks[w];
     mw.assign((row_end.size() + 7) / 8, 0u);
     for (size_t i = 0; i < row_end.size(); ++i) {
@@ -168,7 +168,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   // Inside runs of equal (in, out) length the order is free: use it so that every 32 consecutive states --
   // one half-slot, i.e. the 32 lanes that gather exp(y) at f(g) / s(g) and add gamma there in ONE
   // instruction of the per-state passes -- have distinct pdf banks (greedy, first fit).
-  if (!getenv("TC_NO_PDF_BANKS")) {
+  if (!debug_flag(kDbgNoPdfBanks)) {
     auto key = [&](int h) { return lin(h) * 64 + lout(h); };
     int used_f[32], used_s[32];
     size_t run_end = 0;
@@ -252,7 +252,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   // swap lanes WITHIN their half-slot (their own rows stay where they are; only the banks they present
   // to the rows that gather them change) under a greedy local search on sum_b hist[b]^2 over all
   // half-slots of both directions.
-  if (!getenv("TC_NO_BANK_SEARCH")) {
+  if (!debug_flag(kDbgNoBankSearch)) {
     const int nhalf = kWaves * K * 2;
     auto half_of = [&](int p) {
       const int tid = (p >> 2) % kThreads, k = 4 * (p / (4 * kThreads)) + (p & 3);
@@ -317,7 +317,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
         if (u >= 0) move_delta(u, bb, ba);
       }
     }
-    if (getenv("TC_SCHED_DEBUG")) {
+    if (debug_flag(kDbgSchedTrace)) {
       fprintf(stderr, "[sched] bank search: %lld of %lld swaps accepted\n", (long long)accepted, (long long)proposals);
       for (int dir = 0; dir < 2; ++dir) {
         int64_t sum_max = 0, sum_avg = 0;
