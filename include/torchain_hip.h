@@ -90,7 +90,11 @@ int32_t tc_supervision_num_sequence(const tc_supervision *supervision);
 int32_t tc_supervision_num_frame(const tc_supervision *supervision);
 float tc_supervision_weight(const tc_supervision *supervision);
 
-/* Copies the supervision's arc tables to `device` on `stream` (asynchronously, idempotent). */
+/* Copies the supervision's arc tables to `device` on `stream` (asynchronously: pinned staging; idempotent -- a
+ * later call on another stream makes that stream wait for the copy).  The tables live in a slot of a per-device
+ * pool: tc_supervision_free returns the slot, and the pool reuses it once the last launch that read it has
+ * finished (event query, no synchronisation), so fresh supervisions every minibatch cost no hipMalloc / hipFree
+ * after warm-up. */
 int tc_supervision_prepare(tc_supervision *supervision, int device, void *stream);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
@@ -168,6 +172,10 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "no_pdf_banks", "no_bank_search" (1: skip those placement passes)   "sched_trace" (1: builder statistics on stderr)
  * Returns TC_ERR_INVALID_ARGUMENT for an unknown key.  Nothing on the hot path reads these. */
 int tc_debug_set(const char *key, int value);
+/* Diagnostic counters: "pool_device_allocs" = device allocations made so far by the per-device supervision pool
+ * (stops growing once the pool is warm: a training step then allocates and frees nothing), "pool_reuses" = slots
+ * handed out again.  -1 for an unknown key. */
+int64_t tc_debug_counter(const char *key);
 
 int tc_den_graph_debug_walk(const tc_den_graph *graph, int direction, const float *gather,
                             const float *pdf_factor, float *out);

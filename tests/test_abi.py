@@ -79,19 +79,33 @@ def test_den_graph_rejects_bad_fst():
         io.DenominatorGraph(bad, 5)
 
 
-def write_openfst_vector(path, fst, with_symbols=False):
-    """Writes an OpenFst binary VectorFst<StdArc> (what fst::ReadFstKaldi reads for a plain file)."""
+def write_openfst_vector(path, fst, with_symbols=False, fst_type=b"vector", arc_type=b"standard", version=2,
+                         truncate_to=None):
+    """Writes an OpenFst binary VectorFst<StdArc> (what fst::ReadFstKaldi reads for a plain file): FstHeader
+    {int32 magic, string fsttype, string arctype, int32 version, int32 flags, uint64 properties, int64 start,
+    int64 numstates, int64 numarcs}, optional input / output symbol tables (flags bits 0 / 1), then per state
+    {float final, int64 narcs, narcs x {int32 ilabel, int32 olabel, float weight, int32 nextstate}}."""
     def s(b):
         return struct.pack("<i", len(b)) + b
+
+    def symtab(name, n):
+        out = struct.pack("<i", 2125658996) + s(name) + struct.pack("<qq", n, n)
+        for k in range(n):
+            out += s(b"pdf%d" % k if k else b"<eps>") + struct.pack("<q", k)
+        return out
+
+    blob = struct.pack("<i", 2125659606) + s(fst_type) + s(arc_type)
+    blob += struct.pack("<iiQqqq", version, 3 if with_symbols else 0, 0, int(fst.start), fst.num_states, len(fst.src))
+    if with_symbols:
+        blob += symtab(b"isyms", fst.num_pdfs + 1) + symtab(b"osyms", fst.num_pdfs + 1)
+    first = np.searchsorted(fst.src, np.arange(fst.num_states + 1))
+    for st in range(fst.num_states):
+        blob += struct.pack("<fq", float(fst.final[st]), int(first[st + 1] - first[st]))
+        for a in range(first[st], first[st + 1]):
+            blob += struct.pack("<iifi", int(fst.ilabel[a]), int(fst.ilabel[a]), float(fst.weight[a]), int(fst.dst[a]))
     with open(path, "wb") as f:
-        f.write(struct.pack("<i", 2125659606) + s(b"vector") + s(b"standard"))
-        f.write(struct.pack("<iiQqqq", 2, 0, 0, int(fst.start), fst.num_states, len(fst.src)))
-        first = np.searchsorted(fst.src, np.arange(fst.num_states + 1))
-        for st in range(fst.num_states):
-            f.write(struct.pack("<fq", float(fst.final[st]), int(first[st + 1] - first[st])))
-            for a in range(first[st], first[st + 1]):
-                f.write(struct.pack("<iifi", int(fst.ilabel[a]), int(fst.ilabel[a]), float(fst.weight[a]),
-                                    int(fst.dst[a])))
+        f.write(blob if truncate_to is None else blob[:truncate_to])
+    return len(blob)
 
 
 def test_den_fst_file_reader(tmp_path):
@@ -109,6 +123,34 @@ def test_den_fst_file_reader(tmp_path):
     open(str(tmp_path / "junk.fst"), "wb").write(b"not an fst at all")
     with pytest.raises(TorchainHipError):
         io.DenominatorGraph(str(tmp_path / "junk.fst"), 25)
+
+
+def test_den_fst_reader_variants(tmp_path):
+    """What a den.fst from a Kaldi recipe may look like besides the plain case: symbol tables attached
+    (fstcompile --isymbols --keep_isymbols), non-final states, and what must be refused: a ConstFst (Kaldi's
+    ReadFstKaldi goes through VectorFst::Read, which refuses it too), a non-standard arc type, an old version,
+    files cut anywhere."""
+    fst = synth.skewed_den_fst(30, 200, 12, seed=5)
+    base = io.DenominatorGraph(fst, 12)
+    p = str(tmp_path / "sym.fst")
+    write_openfst_vector(p, fst, with_symbols=True)
+    g = io.DenominatorGraph(p, 12)
+    assert (g.num_states, g.num_arcs) == (30, 200)
+    np.testing.assert_array_equal(g.initial_probs(), base.initial_probs())
+    for kw in (dict(fst_type=b"const"), dict(arc_type=b"log"), dict(version=1)):
+        write_openfst_vector(p, fst, **kw)
+        with pytest.raises(TorchainHipError) as e:
+            io.DenominatorGraph(p, 12)
+        assert e.value.code == -6, kw
+    n = write_openfst_vector(p, fst)
+    for cut in (3, 20, 60, n // 2, n - 1):
+        write_openfst_vector(p, fst, truncate_to=cut)
+        with pytest.raises(TorchainHipError):
+            io.DenominatorGraph(p, 12)
+    write_openfst_vector(p, fst)
+    with pytest.raises(TorchainHipError) as e:  # labels beyond the declared number of pdfs
+        io.DenominatorGraph(p, 5)
+    assert e.value.code == -2
 
 
 def test_den_fst_piped_rxfilename(tmp_path):
@@ -160,4 +202,40 @@ def test_supervision_not_separable_is_reported():
     final = np.array([np.inf, np.inf, np.inf, 0.0], np.float32)
     with pytest.raises(TorchainHipError) as e:
         io.Supervision.from_fst(1.0, 2, 1, 3, arc_begin, ilabel, w, nxt, final)
+    assert e.value.code == -7
+
+
+def test_den_graph_rejects_dead_states():
+    """[K] asserts tot_prob > 0 per state: a state with no arcs and an infinite final weight would make the
+    initial probabilities NaN."""
+    fst = synth.random_den_fst(10, 3, 8, seed=1)
+    keep = fst.src != 4
+    final = fst.final.copy()
+    final[4] = np.inf
+    dead = fst._replace(src=fst.src[keep], dst=fst.dst[keep], ilabel=fst.ilabel[keep], weight=fst.weight[keep], final=final)
+    with pytest.raises(TorchainHipError) as e:
+        io.DenominatorGraph(dead, 8)
+    assert e.value.code == -2
+
+
+def test_supervision_with_final_weights_is_accepted_and_perturbation_is_not():
+    """Real merged supervisions carry non-zero final weights folded into the boundary states' arc copies; the
+    split accepts exactly that structure and refuses a merged FST whose copies are not proportional."""
+    fst = synth.random_den_fst(30, 3, 20, seed=3)
+    sup = synth.random_supervision(fst, 4, 6, 3, seed=5, final_weights=True)
+    h = io.Supervision.from_synth(sup)
+    assert (h.n_batch, h.n_frame) == (4, 6)
+    # perturb ONE copied start arc of a boundary state that has a sibling boundary state
+    times = np.full(sup.num_states, -1)
+    times[0] = 0
+    for st in range(sup.num_states):
+        for a in range(sup.arc_begin[st], sup.arc_begin[st + 1]):
+            times[sup.nextstate[a]] = times[st] + 1
+    boundary = [st for st in range(sup.num_states) if times[st] == 6]
+    assert len(boundary) >= 2
+    w = sup.arc_weight.copy()
+    assert sup.arc_begin[boundary[1] + 1] - sup.arc_begin[boundary[1]] >= 2
+    w[sup.arc_begin[boundary[1]]] += 0.5
+    with pytest.raises(TorchainHipError) as e:
+        io.Supervision.from_fst(1.0, 4, 6, 20, sup.arc_begin, sup.ilabel, w, sup.nextstate, sup.final)
     assert e.value.code == -7

@@ -346,3 +346,83 @@ def test_chain_loss_3d_input_fused_path_matches_2d_path(oracle):
         loss2.backward()
         assert torch.equal(res.data, res2.data) and torch.equal(loss, loss2)
         assert torch.equal(x.grad, x2.grad) and torch.equal(xe.grad, xe2.grad)
+
+
+def test_denominator_graph_from_den_fst_file(oracle, tmp_path):
+    """The reference's own entry: io.DenominatorGraph(path, n_pdf) (torchain/io.py:51-54 ->
+    src/my_lib_example.cpp:129-134) on a den.fst written to disk (with symbol tables), then the full objective
+    on the GPU against the oracle built from the in-memory arrays."""
+    from torchain_amd import io
+    from test_abi import write_openfst_vector
+
+    fst = synth.nearly_tied_den_fst(900, 5, 200, seed=17, fraction=0.05)
+    path = str(tmp_path / "den.fst")
+    write_openfst_vector(path, fst, with_symbols=True)
+    graph = io.DenominatorGraph(path, fst.num_pdfs)
+    assert graph.num_states == fst.num_states and graph.num_arcs == len(fst.src)
+    S, T = 4, 25
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 3, seed=18, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=19)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+    out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, xent=True, graph=graph)
+    assert abs(out["results"][0] - ref["objf"]) <= REL * abs(ref["objf"])
+    assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+    assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL
+
+
+def test_supervision_with_nonzero_final_weights(oracle):
+    """The f_i - f_0 re-weighting branch of the per-sequence split (csrc/supervision.cpp): boundary states with
+    distinct non-zero final weights folded into their arc copies, as after [K] AddWeightToSupervisionFst +
+    AppendSupervision.  Objective, posteriors and the xent side output against the oracle on the MERGED FST."""
+    fst = synth.random_den_fst(150, 5, 60, seed=51)
+    S, T = 5, 14
+    g = oracle.DenGraph(fst)
+    for weight in (1.0, 0.5):
+        sup = synth.random_supervision(fst, S, T, 3, seed=52, weight=weight, initial_probs=g.initial_probs(),
+                                       final_weights=True)
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=53)
+        ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+        out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, xent=True)
+        assert abs(out["results"][0] - ref["objf"]) <= REL * abs(ref["objf"])
+        assert rel_err(out["deriv"], ref["deriv"], floor=weight) <= REL
+        assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=weight) <= REL
+
+
+def test_fresh_supervision_every_step_allocates_nothing_after_warmup(oracle):
+    """A training loop makes a new Supervision per minibatch (reference: io.py:20-31 + the egs iterators).  The
+    tables live in slots of a per-device pool with pinned staging: after a few steps the pool's device
+    allocation count stops moving although every step creates, uploads, uses and drops a supervision -- and
+    the results stay right while slots are being recycled under in-flight kernels."""
+    from torchain_amd import io
+    from torchain_amd._lib import lib
+    from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv
+
+    fst = synth.random_den_fst(200, 5, 80, seed=61)
+    S, T, P = 6, 20, 80
+    g = oracle.DenGraph(fst)
+    graph = io.DenominatorGraph(fst, P)
+    sups = [synth.random_supervision(fst, S, T, 3, seed=62 + i, initial_probs=g.initial_probs()) for i in range(4)]
+    y_np = synth.random_nnet_output(S, T, P, seed=63)
+    refs = [oracle.compute_chain_objf_and_deriv(g, sp, y_np, 0.0, 0.1)["objf"] for sp in sups]
+    y = torch.from_numpy(y_np).cuda()
+    deriv = torch.empty_like(y)
+    side = torch.cuda.Stream()
+    allocs = []
+    objfs = []
+    for step in range(50):
+        h = io.Supervision.from_synth(sups[step % 4])
+        res = ChainResults()
+        if step % 5 == 4:  # every few steps from another stream: prepare must order that stream behind the upload
+            with torch.cuda.stream(side):
+                compute_chain_objf_and_deriv(graph, h, y, res.data, deriv, None, 0.0, 0.1, 0.0)
+            side.synchronize()
+        else:
+            compute_chain_objf_and_deriv(graph, h, y, res.data, deriv, None, 0.0, 0.1, 0.0)
+        objfs.append(float(res.data[0]))
+        del h
+        allocs.append(lib.tc_debug_counter(b"pool_device_allocs"))
+    assert allocs[-1] == allocs[9], allocs           # nothing allocated after the first ten steps
+    assert lib.tc_debug_counter(b"pool_reuses") >= 40
+    for step, v in enumerate(objfs):
+        assert abs(v - refs[step % 4]) <= REL * abs(refs[step % 4])

@@ -60,6 +60,8 @@ def _load():
     L.tc_den_graph_stats.argtypes = [vp, vp]
     L.tc_debug_set.restype = C.c_int
     L.tc_debug_set.argtypes = [C.c_char_p, C.c_int]
+    L.tc_debug_counter.restype = C.c_int64
+    L.tc_debug_counter.argtypes = [C.c_char_p]
     L.tc_den_graph_debug_walk.restype = C.c_int
     L.tc_den_graph_debug_walk.argtypes = [vp, C.c_int, vp, vp, vp]
     L.tc_to2d.restype = C.c_int

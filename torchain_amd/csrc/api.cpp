@@ -1,7 +1,8 @@
 // C ABI entry points of the hot path (include/torchain_hip.h).  Replaces the reference's Kaldi
 // bridge src/my_lib_chain.cpp:104-136: validates the borrowed tensors the way common::make_matrix
 // does (2-D, unit column stride, src/common.hpp:109-117), carves the caller's workspace, and enqueues
-// the kernels on the caller's stream.  No allocation, no host synchronisation, no globals.
+// the kernels on the caller's stream.  No host synchronisation; no allocation once the per-device supervision
+// pool (supervision.cpp) is warm.
 #include <algorithm>
 #include <cstring>
 
@@ -212,7 +213,8 @@ int tc_num_forward_backward(tc_supervision *sup, const float *y, int64_t rows, i
   rc = launch_num(p, stream);
   if (rc != TC_OK) return rc;
   if (logprob_dev) rc = launch_sum_double((const double *)workspace, sup->S, (double)sup->weight, logprob_dev, stream);
-  return rc;
+  if (rc != TC_OK) return rc;
+  return supervision_mark_use(sup, device, stream);
 }
 
 int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
@@ -250,6 +252,8 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
   rc = launch_den(dp, stream);
   if (rc != TC_OK) return rc;
   rc = launch_num(np, stream);
+  if (rc != TC_OK) return rc;
+  rc = supervision_mark_use(sup, device, stream);
   if (rc != TC_OK) return rc;
   rc = launch_finalize(w.den_lp, w.num_lp, w.y2, w.ab, w.gs, sup->S, sup->T, wgt, l2_regularize, deriv != nullptr,
                        results_dev3, w.fail, stream);

@@ -220,12 +220,19 @@ struct NumTables {
   int32_t max_states = 0, max_arcs = 0, max_uniq = 0;
 };
 
+// One slot of the per-device supervision pool (supervision.cpp): device blob, pinned staging of the same size,
+// `ready` = the upload has landed, `done` = the last launch that reads the blob has finished.
+struct PoolSlot {
+  char *blob = nullptr, *host = nullptr;
+  size_t cap = 0;
+  hipEvent_t ready = nullptr, done = nullptr;
+};
+
 struct NumDev {
   const int32_t *seq_state_off, *seq_arc_off, *seq_uniq_off, *level_begin, *out_begin, *in_begin, *in_arc,
       *arc_src, *arc_dst, *arc_uniq, *uniq_t, *uniq_pdf, *uniq_begin, *uniq_arc;
   const float *arc_logw, *final_logw;
-  void *blob = nullptr;
-  hipEvent_t ready = nullptr;
+  PoolSlot *slot = nullptr;
 };
 
 struct NumParams {
@@ -248,8 +255,7 @@ struct tc_supervision {
   float weight = 1.f;
   int32_t S = 0, T = 0, P = 0;
   tc::NumTables tab;
-  std::vector<char> pinned_image;  // host image of the device blob
-  std::vector<size_t> blob_off;
+  std::vector<size_t> blob_off;    // offsets of the tables inside a pool slot
   std::mutex mu;
   std::map<int, tc::NumDev> dev;
 };
@@ -289,6 +295,11 @@ extern thread_local int g_last_hip_error;
 // replace what used to be environment variables of the shipping library.
 enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgCount };
 bool debug_flag(DebugFlag f);
+
+int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp
+void pool_release(int device, PoolSlot *slot);
+int64_t pool_counter(int which);  // 0: device allocations made by the pool, 1: slots reused
+int supervision_mark_use(tc_supervision *sup, int device, hipStream_t stream);
 #define TC_HIP_CHECK(expr)                        \
   do {                                            \
     hipError_t e__ = (expr);                      \

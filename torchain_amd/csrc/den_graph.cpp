@@ -141,6 +141,12 @@ int tc_debug_set(const char *key, int value) {
   return TC_ERR_INVALID_ARGUMENT;
 }
 
+int64_t tc_debug_counter(const char *key) {
+  if (key && !strcmp(key, "pool_device_allocs")) return pool_counter(0);
+  if (key && !strcmp(key, "pool_reuses")) return pool_counter(1);
+  return -1;
+}
+
 int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs, const int32_t *arc_src,
                         const int32_t *arc_dst, const int32_t *arc_ilabel, const float *arc_weight,
                         const float *final_weight, int32_t start_state, int32_t num_pdfs) {
@@ -176,6 +182,13 @@ int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs
     std::vector<double> norm(H), cur(H, 0.0), nxt(H, 0.0), avg(H, 0.0);
     for (int s = 0; s < H; ++s) norm[s] = std::exp(-(double)final_weight[s]);
     for (int64_t a = 0; a < num_arcs; ++a) norm[arc_src[a]] += std::exp(-(double)arc_weight[a]);
+    // [K] KALDI_ASSERT(tot_prob > 0): a state with no arcs and an infinite final weight would give norm = inf
+    // and NaN initial probabilities
+    for (int s = 0; s < H; ++s)
+      if (!(norm[s] > 0.0) || !std::isfinite(norm[s])) {
+        delete g;
+        return TC_ERR_BAD_FST;
+      }
     for (int s = 0; s < H; ++s) norm[s] = 1.0 / norm[s];
     cur[start_state] = 1.0;
     for (int iter = 0; iter < 100; ++iter) {

@@ -59,9 +59,14 @@ __device__ __forceinline__ f4 bld4(rsrc_t r, uint32_t voff, uint32_t soff) {
   const u4 v = bld4u(r, voff, soff);
   return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
-__device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, uint32_t soff, f4 v) {
+// Stores never put their offset into the SGPR soffset field.  Measured on gfx950 (this kernel's history rows, 2nd
+// plane): `buffer_store_dwordx4 v[76:79], v106, s[40:43], s0 offen` followed directly by a VALU write of v76
+// stored corrupted data -- the >64-bit store-data hazard.  The compiler pads that hazard with s_nop only when
+// soffset is an immediate (it takes the hardware to be safe when soffset is a register), so the offset goes
+// into the VGPR and soffset stays 0.
+__device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, f4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
-                                         r, (int)voff, (int)soff, 0);
+                                         r, (int)voff, 0, 0);
 }
 
 __device__ __forceinline__ f4 mk4(float x) { return f4{x, x, x, x}; }
@@ -85,7 +90,7 @@ __device__ __forceinline__ f4 row_ld(rsrc_t r, uint32_t voff, int vec) {
 }
 __device__ __forceinline__ void row_st(rsrc_t r, uint32_t voff, int vec, f4 v) {
   if (vec) {
-    bst4(r, voff, 0, v);
+    bst4(r, voff, v);
   } else {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, (int)voff, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), r, (int)voff, 4, 0);
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     if (j < planes) {
       const f4 a = pi4[j] + (leaky * pi4[j]) * asum;
       lds4_st(kA0 + own16 + j * kPlane, a);
-      bst4(make_rsrc(hist, 4u * Hs), own16, j * kPlane, a);
+      bst4(make_rsrc(hist, 4u * Hs), own16 + j * kPlane, pi4[j]);  // the history holds the UN-dashed alpha_t (below)
     }
   float y2 = 0.f;
   {
@@ -406,7 +411,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         if (j < planes) {
           const f4 a = v4[j] + cpi[j] * asum;
           lds4_st(kA0 + own16 + j * kPlane, a);
-          bst4(hist_t, own16, j * kPlane, a);
+          // The history holds alpha_t, not alpha'_t: the backward pass needs both, alpha'_t = alpha_t + leaky*pi*asum_t
+          // is an addition, while recovering alpha_t from alpha'_t would be a subtraction that loses everything
+          // where alpha_t << leaky*pi*asum_t -- states that peaky outputs can still give a large posterior.
+          bst4(hist_t, own16 + j * kPlane, v4[j]);
           part_tot += hsum(a);
         }
       if (t < T) {
@@ -539,7 +547,6 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     uint32_t fpk[JV][2];  // forward-pdf offsets of the owned states, kept for the Y update below
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
-    const float asum_up = ldsf(aAsum + 4u * (t + 1));
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       b4[j] = mk4(0.f);
@@ -548,28 +555,27 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         const f4 ws = bld4(r_ws, own16, j * kPlane);
         const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
         f4 a = own_rows(vrow, j);
-        const f4 al = areg[j];
-        // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
+        const f4 al = areg[j] + cp * asum_t;  // alpha'_t of the owned states
+        // alpha_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
         const f4 aup = ALPHA_LDS ? lds4(aAL + own16 + j * kPlane) : bld4(make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs), own16, j * kPlane);
         // Everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
         //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
         //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
         //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
-        // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history.  The self-loop arc also
-        // adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
-        auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float ax) {
+        // with alpha_{t+1} (un-dashed) from the history.  The self-loop arc also adds
+        // vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
+        auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float ax) {
           const float ps_ws = ldsf(pb_cur + (fsx >> 16)) * wsx;
           const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
-          const float alpha_up = aupx - cpx * asum_up;   // alpha_{t+1}(g)
           const float bos = kGammaScale * bo;            // power-of-two scale: exact
           gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
-          gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf(alpha_up - selfpart, 0.f));
+          gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf(aupx - selfpart, 0.f));
           return fmaf(ps_ws, bo, ax);                    // vf_s into beta'_t(g) * asum_t
         };
-        a.x = one(fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x);
-        a.y = one(fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y);
-        a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z);
-        a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w);
+        a.x = one(fs.x, ws.x, bown[j].x, al.x, aup.x, a.x);
+        a.y = one(fs.y, ws.y, bown[j].y, al.y, aup.y, a.y);
+        a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, a.z);
+        a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, a.w);
         b4[j] = a * inv_as;  // [K] * inv_arbitrary_scale
         fpk[j][0] = (fs.x & 0xffffu) | (fs.y << 16);
         fpk[j][1] = (fs.z & 0xffffu) | (fs.w << 16);

@@ -4,6 +4,7 @@
 // num_sequences independent per-sequence acceptors so that the HIP kernel can run one wavefront per
 // sequence; the split is exact (see split comment below).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -43,6 +44,87 @@ int32_t state_times(int32_t n, const int32_t *arc_begin, const int32_t *ilabel, 
 }
 
 }  // namespace
+
+namespace tc {
+
+// ---- per-device pool of supervision slots -------------------------------------------------------------
+namespace {
+struct DevPool {
+  std::mutex mu;
+  std::vector<PoolSlot *> idle;
+};
+std::mutex g_pools_mu;
+std::map<int, DevPool> g_pools;
+std::atomic<int64_t> g_pool_device_allocs{0}, g_pool_reuses{0};
+
+DevPool &pool_of(int device) {
+  std::lock_guard<std::mutex> lock(g_pools_mu);
+  return g_pools[device];
+}
+}  // namespace
+
+int64_t pool_counter(int which) { return which == 0 ? g_pool_device_allocs.load() : g_pool_reuses.load(); }
+
+// Smallest idle slot that is large enough AND whose last recorded use has completed (hipEventQuery: no
+// waiting); a new slot otherwise -- which happens only while the pool warms up.
+int pool_acquire(int device, size_t bytes, PoolSlot **out) {
+  DevPool &dp = pool_of(device);
+  {
+    std::lock_guard<std::mutex> lock(dp.mu);
+    int best = -1;
+    for (int i = 0; i < (int)dp.idle.size(); ++i) {
+      PoolSlot *s = dp.idle[i];
+      if (s->cap < bytes || (best >= 0 && s->cap >= dp.idle[best]->cap)) continue;
+      if (hipEventQuery(s->done) != hipSuccess) continue;
+      best = i;
+    }
+    if (best >= 0) {
+      *out = dp.idle[best];
+      dp.idle.erase(dp.idle.begin() + best);
+      g_pool_reuses++;
+      return TC_OK;
+    }
+  }
+  int prev = 0;
+  TC_HIP_CHECK(hipGetDevice(&prev));
+  TC_HIP_CHECK(hipSetDevice(device));
+  PoolSlot *s = new PoolSlot();
+  s->cap = std::max<size_t>((bytes + bytes / 4 + 65535) & ~(size_t)65535, 1 << 20);  // room for the next, larger batch
+  hipError_t e = hipMalloc((void **)&s->blob, s->cap);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->host, s->cap, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    if (s->blob) (void)hipFree(s->blob);
+    if (s->host) (void)hipHostFree(s->host);
+    delete s;
+    return TC_ERR_HIP;
+  }
+  g_pool_device_allocs++;
+  *out = s;
+  return TC_OK;
+}
+
+void pool_release(int device, PoolSlot *slot) {
+  if (!slot) return;
+  DevPool &dp = pool_of(device);
+  std::lock_guard<std::mutex> lock(dp.mu);
+  dp.idle.push_back(slot);
+}
+
+// Every launch that reads a supervision's device tables moves the slot's `done` event behind itself on its
+// stream, so the pool never hands the slot out while a kernel may still be reading it.
+int supervision_mark_use(tc_supervision *sup, int device, hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(sup->mu);
+  auto it = sup->dev.find(device);
+  if (it == sup->dev.end()) return TC_OK;
+  TC_HIP_CHECK(hipEventRecord(it->second.slot->done, stream));
+  return TC_OK;
+}
+
+}  // namespace tc
 
 extern "C" {
 
@@ -165,9 +247,9 @@ int tc_supervision_create(tc_supervision **out, float weight, int32_t S, int32_t
       std::vector<int32_t> map_this_frame(label_dim, -1), touched;
       std::vector<std::vector<int32_t>> members;
       int32_t cur_t = 0;
+      int32_t t = 0;  // arcs are emitted in source-state order, so the frame only ever moves forward
       for (int32_t a = 0; a < narc; ++a) {
         const int32_t ls = tb.arc_src[abase + a];
-        int32_t t = 0;
         while (t + 1 <= T && tb.level_begin[(size_t)q * (T + 2) + t + 1] <= ls) ++t;
         if (t != cur_t) {
           for (int32_t p : touched) map_this_frame[p] = -1;
@@ -208,15 +290,8 @@ int tc_supervision_create(tc_supervision **out, float weight, int32_t S, int32_t
 
 void tc_supervision_free(tc_supervision *sup) {
   if (!sup) return;
-  for (auto &kv : sup->dev) {
-    int cur = 0;
-    if (hipGetDevice(&cur) == hipSuccess) {
-      (void)hipSetDevice(kv.first);
-      if (kv.second.ready) (void)hipEventDestroy(kv.second.ready);
-      if (kv.second.blob) (void)hipFree(kv.second.blob);
-      (void)hipSetDevice(cur);
-    }
-  }
+  // the device tables go back to the per-device pool; they are reused once the work recorded on them is done
+  for (auto &kv : sup->dev) pool_release(kv.first, kv.second.slot);
   delete sup;
 }
 
@@ -229,7 +304,12 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   if (!sup) return TC_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_v;
   std::lock_guard<std::mutex> lock(sup->mu);
-  if (sup->dev.count(device)) return TC_OK;
+  auto it = sup->dev.find(device);
+  if (it != sup->dev.end()) {
+    // uploaded earlier, possibly on another stream: order this stream behind the copy
+    TC_HIP_CHECK(hipStreamWaitEvent(stream, it->second.slot->ready, 0));
+    return TC_OK;
+  }
   NumTables &tb = sup->tab;
   struct Part { const void *src; size_t bytes; };
   const Part parts[] = {
@@ -243,33 +323,32 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
       {tb.arc_logw.data(), tb.arc_logw.size() * 4},           {tb.final_logw.data(), tb.final_logw.size() * 4},
   };
   const int nparts = (int)(sizeof(parts) / sizeof(parts[0]));
-  if (sup->pinned_image.empty()) {
-    size_t total = 0;
-    sup->blob_off.clear();
-    for (int i = 0; i < nparts; ++i) {
-      sup->blob_off.push_back(total);
-      total += (parts[i].bytes + 255) & ~(size_t)255;
-    }
-    sup->pinned_image.assign(total + 256, 0);
-    for (int i = 0; i < nparts; ++i)
-      if (parts[i].bytes) memcpy(sup->pinned_image.data() + sup->blob_off[i], parts[i].src, parts[i].bytes);
+  size_t total = 0;
+  sup->blob_off.clear();
+  for (int i = 0; i < nparts; ++i) {
+    sup->blob_off.push_back(total);
+    total += (parts[i].bytes + 255) & ~(size_t)255;
   }
-  int prev = 0;
-  TC_HIP_CHECK(hipGetDevice(&prev));
-  TC_HIP_CHECK(hipSetDevice(device));
-  char *blob = nullptr;
-  hipError_t e = hipMalloc((void **)&blob, sup->pinned_image.size());
-  // pageable source: the copy is staged by the runtime before the call returns, so the host image may
-  // be reused freely; it is ordered on `stream` ahead of the kernels that read it.
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(blob, sup->pinned_image.data(), sup->pinned_image.size(), hipMemcpyHostToDevice, stream);
-  (void)hipSetDevice(prev);
+  total += 256;
+  // A new supervision arrives with every minibatch: its tables live in a slot of a per-device pool (device
+  // blob + PINNED host staging + two events), so that after warm-up a step neither allocates nor frees
+  // device memory and the upload is a true asynchronous copy.
+  PoolSlot *slot = nullptr;
+  int rc = pool_acquire(device, total, &slot);
+  if (rc != TC_OK) return rc;
+  for (int i = 0; i < nparts; ++i)
+    if (parts[i].bytes) memcpy(slot->host + sup->blob_off[i], parts[i].src, parts[i].bytes);
+  hipError_t e = hipMemcpyAsync(slot->blob, slot->host, total, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipEventRecord(slot->ready, stream);
+  if (e == hipSuccess) e = hipEventRecord(slot->done, stream);  // (moved forward by every launch that reads the slot)
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
+    pool_release(device, slot);
     return TC_ERR_HIP;
   }
   NumDev d;
-  d.blob = blob;
+  d.slot = slot;
+  char *blob = slot->blob;
   auto P = [&](int i) { return (const int32_t *)(blob + sup->blob_off[i]); };
   d.seq_state_off = P(0); d.seq_arc_off = P(1); d.seq_uniq_off = P(2); d.level_begin = P(3);
   d.out_begin = P(4); d.in_begin = P(5); d.in_arc = P(6); d.arc_src = P(7); d.arc_dst = P(8);

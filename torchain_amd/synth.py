@@ -153,14 +153,19 @@ def initial_probs_f64(fst, num_iters=100):
 
 
 def random_supervision(fst, num_sequences, frames_per_sequence, paths_per_sequence=3, seed=7, weight=1.0,
-                       initial_probs=None):
+                       initial_probs=None, final_weights=False):
     """Numerator supervision: per sequence the union of k random length-T paths through ``fst``
     stored as a time-sorted epsilon-free acceptor trie; arc weight = -log(den arc prob), the first
     arc of each path also carrying -log pi(start state).  The S per-sequence FSTs are then merged
     the way [K] AppendSupervision does (fst::Concat + RmEpsilon + breadth-first renumbering): the
     final states of sequence k-1 receive copies of sequence k's start arcs.  Because the numerator
     is a weighted subset of denominator paths, objf <= 0 must hold
-    (``src/chain-supervision-test.hpp:285``)."""
+    (``src/chain-supervision-test.hpp:285``).
+
+    ``final_weights=True`` gives every sequence's final states distinct non-zero final weights, as real
+    supervisions have after [K] AddWeightToSupervisionFst: Concat + RmEpsilon then folds final weight f_i of
+    boundary state i into its copies of the next sequence's start arcs (the f_i - f_0 re-weighting branch of
+    the per-sequence split in ``csrc/supervision.cpp``)."""
     rng = np.random.default_rng(seed)
     S, T, k = int(num_sequences), int(frames_per_sequence), int(paths_per_sequence)
     H = fst.num_states
@@ -212,6 +217,7 @@ def random_supervision(fst, num_sequences, frames_per_sequence, paths_per_sequen
             n += seq_nodes[q][t]
         state_base.append(bases)
     num_states = n
+    fw = [rng.uniform(0.1, 2.0, size=seq_nodes[q][T]) if final_weights else np.zeros(seq_nodes[q][T]) for q in range(S)]
     out = [[] for _ in range(num_states)]
     for q in range(S):
         for t in range(T):
@@ -219,7 +225,7 @@ def random_supervision(fst, num_sequences, frames_per_sequence, paths_per_sequen
                 dst = state_base[q][t + 1] + b
                 if t == 0 and q > 0:
                     for f in range(seq_nodes[q - 1][T]):  # copies on every final state of q-1
-                        out[state_base[q][0] + f].append((il, w, dst))
+                        out[state_base[q][0] + f].append((il, w + float(fw[q - 1][f]), dst))
                 else:
                     out[state_base[q][t] + a].append((il, w, dst))
     arc_begin = np.zeros(num_states + 1, np.int32)
@@ -231,7 +237,7 @@ def random_supervision(fst, num_sequences, frames_per_sequence, paths_per_sequen
             aw.append(w)
             nxt.append(d)
     final = np.full(num_states, np.inf, np.float32)
-    final[state_base[S - 1][T]: state_base[S - 1][T] + seq_nodes[S - 1][T]] = 0.0
+    final[state_base[S - 1][T]: state_base[S - 1][T] + seq_nodes[S - 1][T]] = fw[S - 1]
     return SupFst(float(weight), S, T, fst.num_pdfs, num_states, arc_begin, np.array(ilabel, np.int32),
                   np.array(aw, np.float32), np.array(nxt, np.int32), final)
 
