@@ -138,6 +138,14 @@ int tc_num_forward_backward(tc_supervision *supervision, const float *nnet_outpu
                             double *logprob_dev, void *workspace, int64_t workspace_bytes, int device,
                             void *stream);
 
+/* The cross-entropy objective Kaldi's chain trainer reports next to the chain objective ([K]
+ * nnet-chain-training.cc: TraceMatMat(xent_output, xent_deriv, kTrans), xent_deriv = w * numerator posteriors);
+ * the reference leaves it as a TODO (torchain/functions.py:88-89).  objf_dev: device double[1].  Needs
+ * tc_chain_workspace_bytes-sized or at least 4096 bytes of 16-byte aligned device scratch. */
+int tc_xent_objf(const float *xent_output, int64_t num_rows, int32_t num_cols, int64_t output_stride,
+                 const float *xent_output_deriv, int64_t deriv_stride, double *objf_dev, void *workspace,
+                 int64_t workspace_bytes, int device, void *stream);
+
 /* Diagnostics for bench.py / DESIGN.md: copies a few schedule statistics of the graph
  * (out[0]=padded forward arc slots, out[1]=padded backward arc slots, out[2]=LDS bytes of the fused
  * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows,

@@ -426,3 +426,44 @@ def test_fresh_supervision_every_step_allocates_nothing_after_warmup(oracle):
     assert lib.tc_debug_counter(b"pool_reuses") >= 40
     for step, v in enumerate(objfs):
         assert abs(v - refs[step % 4]) <= REL * abs(refs[step % 4])
+
+
+def test_xent_objective_value_and_rccl_branch(oracle):
+    """(a) ChainResults.xent_objf = sum(xent_output * w * numerator posteriors), the cross-entropy objective
+    Kaldi's chain trainer logs (a TODO in the reference, torchain/functions.py:88-89), against the oracle's
+    xent derivative; (b) chain_loss_data_parallel through the REAL RCCL path with a process group of one rank
+    (the recipe's per-device loss, example/chime5/parallel_train.py:59-75: results summed over devices,
+    loss = -sum(objf) / sum(weight))."""
+    import os
+    import torch.distributed as dist
+    from torchain_amd import io, parallel
+    from torchain_amd.functions import chain_loss
+
+    fst = synth.random_den_fst(120, 5, 64, seed=71)
+    B, T, P = 4, 15, 64
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, B, T, 3, seed=72, weight=0.5, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(B, T, P, seed=73)
+    xe = torch.log_softmax(torch.from_numpy(synth.random_nnet_output(B, T, P, seed=74)), dim=1).numpy()
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+    want_xent_objf = float((xe.astype(np.float64) * ref["xent_deriv"].astype(np.float64)).sum())
+    den, hsup = io.DenominatorGraph(fst, P), io.Supervision.from_synth(sup)
+    to3d = lambda a: torch.from_numpy(a.reshape(T, B, P).transpose(1, 2, 0).copy()).cuda()
+    loss, res = chain_loss(to3d(y).requires_grad_(True), den, hsup, 1e-4, 0.1, 0.1, to3d(xe).requires_grad_(True),
+                           kaldi_way=True)
+    assert abs(res.xent_objf - want_xent_objf) <= REL * abs(want_xent_objf)
+    assert abs(res.xent_loss - (-want_xent_objf / ref["weight"])) <= REL * abs(want_xent_objf / ref["weight"])
+    _, res0 = chain_loss(to3d(y), den, hsup, 1e-4, 0.1)
+    assert res0.xent_objf is None and res0.xent_loss is None
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        loss2, res2 = parallel.chain_loss_data_parallel(to3d(y).requires_grad_(True), den, hsup, 1e-4, 0.1, 0.1,
+                                                        to3d(xe).requires_grad_(True), kaldi_way=True, even_if_alone=True)
+        assert dist.get_backend() == "nccl"
+        assert torch.equal(res2.data, res.data) and float(loss2) == float(loss)
+        assert abs(res2.xent_objf - res.xent_objf) <= 1e-9 * abs(res.xent_objf)
+    finally:
+        dist.destroy_process_group()

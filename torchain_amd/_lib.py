@@ -87,6 +87,8 @@ def _load():
     L.tc_den_forward_backward.restype = C.c_int
     L.tc_den_forward_backward.argtypes = [vp, i32, vp, i64, i32, i64, f32, f32, f32, C.c_int, vp, i64, vp, vp, vp,
                                           i64, C.c_int, vp]
+    L.tc_xent_objf.restype = C.c_int
+    L.tc_xent_objf.argtypes = [vp, i64, i32, i64, vp, i64, vp, vp, i64, C.c_int, vp]
     L.tc_num_forward_backward.restype = C.c_int
     L.tc_num_forward_backward.argtypes = [vp, vp, i64, i32, i64, vp, i64, vp, vp, i64, C.c_int, vp]
     return L

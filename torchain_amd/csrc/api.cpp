@@ -262,6 +262,18 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
                              cols, stream);
 }
 
+int tc_xent_objf(const float *xent_output, int64_t rows, int32_t cols, int64_t output_stride, const float *xent_deriv,
+                 int64_t deriv_stride, double *objf_dev, void *workspace, int64_t workspace_bytes, int device,
+                 void *stream_v) {
+  if (!xent_output || !xent_deriv || !objf_dev || rows <= 0 || cols <= 0 || output_stride < cols || deriv_stride < cols)
+    return TC_ERR_INVALID_ARGUMENT;
+  if (!workspace || workspace_bytes < trace_workspace_bytes() || !aligned16(workspace)) return TC_ERR_WORKSPACE;
+  DeviceGuard guard(device);
+  if (!guard.ok) return TC_ERR_HIP;
+  return launch_trace_mat_mat(xent_output, output_stride, xent_deriv, deriv_stride, rows, cols, (double *)workspace,
+                              objf_dev, (hipStream_t)stream_v);
+}
+
 int tc_to2d(const float *in_bct, int32_t B, int32_t Cn, int32_t T, float *out2d, int64_t out_stride, int device,
             void *stream_v) {
   if (!in_bct || !out2d || B <= 0 || Cn <= 0 || T <= 0 || out_stride < Cn) return TC_ERR_INVALID_ARGUMENT;

@@ -46,7 +46,49 @@ __global__ __launch_bounds__(kLayoutThreads) void layout_kernel(const float *__r
   }
 }
 
+// sum_{r,c} a[r][c] * b[r][c] in double: per-block partials in a fixed order, then one block adds them in
+// index order -- deterministic.  [K] TraceMatMat(xent_output, xent_deriv, kTrans), the cross-entropy objective
+// Kaldi's chain trainer reports (the reference leaves it as a TODO, torchain/functions.py:88-89).
+constexpr int kTraceBlocks = 512, kTraceThreads = 256;
+__global__ __launch_bounds__(kTraceThreads) void trace_partial_kernel(const float *__restrict__ a, int64_t a_stride,
+                                                                      const float *__restrict__ b, int64_t b_stride,
+                                                                      int64_t rows, int cols, double *partial) {
+  __shared__ double sh[kTraceThreads];
+  double acc = 0.0;
+  for (int64_t r = blockIdx.x; r < rows; r += kTraceBlocks) {
+    const float *ar = a + r * a_stride, *br = b + r * b_stride;
+    float row = 0.f;
+    for (int c = threadIdx.x; c < cols; c += kTraceThreads) row = fmaf(ar[c], br[c], row);
+    acc += (double)row;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = kTraceThreads / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(64) void trace_final_kernel(const double *partial, double *out) {
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < kTraceBlocks; ++i) t += partial[i];
+    *out = t;
+  }
+}
+
 }  // namespace
+
+int64_t trace_workspace_bytes() { return (int64_t)kTraceBlocks * 8; }
+
+int launch_trace_mat_mat(const float *a, int64_t a_stride, const float *b, int64_t b_stride, int64_t rows, int cols,
+                         double *partial, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(trace_partial_kernel, dim3(kTraceBlocks), dim3(kTraceThreads), 0, stream, a, a_stride, b, b_stride,
+                     rows, cols, partial);
+  hipLaunchKernelGGL(trace_final_kernel, dim3(1), dim3(64), 0, stream, partial, out);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
 
 int launch_layout(bool to2d, const float *in, float *out, int B, int Cn, int T, int64_t stride2d, float scale,
                   hipStream_t stream) {

@@ -27,6 +27,9 @@ from ._lib import check, lib
 class ChainResults:
     def __init__(self):
         self.data = torch.zeros(3)
+        # Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the
+        # reference, functions.py:88-89): filled by chain_loss when a xent branch is trained, else None
+        self.xent_objf = None
 
     def __repr__(self):
         return "ChainResults(loss=%f, objf=%f, l2_term=%f, weight=%lf)" % (
@@ -35,6 +38,11 @@ class ChainResults:
     @property
     def loss(self):
         return -self.data[0] / self.data[2]
+
+    @property
+    def xent_loss(self):
+        """-xent_objf / weight, the per-frame cross-entropy Kaldi logs as 'output-xent'; None without a xent branch."""
+        return None if self.xent_objf is None else -self.xent_objf / float(self.data[2])
 
 
 _workspaces = {}
@@ -87,6 +95,20 @@ def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, n
     return results
 
 
+def xent_objective(xent_output, xent_output_deriv):
+    """sum(xent_output * xent_output_deriv) on the device (``tc_xent_objf``), as a Python float."""
+    device = xent_output.device
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        ws = _workspace(device, stream, 4096)
+        out = torch.empty(1, dtype=torch.float64, device=device)
+        rc = lib.tc_xent_objf(_ptr(xent_output), xent_output.shape[0], xent_output.shape[1], xent_output.stride(0),
+                              _ptr(xent_output_deriv), xent_output_deriv.stride(0), _ptr(out), _ptr(ws), ws.numel(),
+                              device.index, C.c_void_p(stream))
+        check(rc, "tc_xent_objf")
+        return float(out.item())
+
+
 class _ChainLoss(Function):
     """Lattice-free MMI loss; see the reference docstring ``torchain/functions.py:23-60`` for the
     meaning of every argument (identical here)."""
@@ -102,6 +124,7 @@ class _ChainLoss(Function):
                                      l2_regularize, leaky_hmm_coefficient, xent_regularize)
         ctx.mmi_grad = mmi_grad
         if use_xent:
+            results.xent_objf = xent_objective(xent_input.detach(), xent_grad)
             if kaldi_way:
                 ctx.xent_grad = xent_regularize * xent_grad
             else:
@@ -157,6 +180,8 @@ class _ChainLoss3d(Function):
         xent_grad = torch.empty_like(xe2d) if use_xent else None
         compute_chain_objf_and_deriv(den_graph, supervision, x2d, results.data, mmi_grad, xent_grad,
                                      l2_regularize, leaky_hmm_coefficient, xent_regularize)
+        if use_xent:
+            results.xent_objf = xent_objective(xe2d, xent_grad)
         if use_xent and not kaldi_way:  # the reference's second call (functions.py:96-103)
             compute_chain_objf_and_deriv(den_graph, supervision, xe2d, results.data, mmi_grad, xent_grad,
                                          l2_regularize, leaky_hmm_coefficient, xent_regularize)

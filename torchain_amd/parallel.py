@@ -67,13 +67,16 @@ def shard_supervision_fst(sup, lo, hi):
                      np.asarray(il, np.int32), np.asarray(aw, np.float32), np.asarray(nx, np.int32), final)
 
 
-def all_reduce_results(results, group=None, device=None):
+def all_reduce_results(results, group=None, device=None, even_if_alone=False):
     """SUM-all-reduces ``results.data = [objf, l2_term, weight]`` over the process group in place (one
     12-byte collective) and returns ``results``.  With the ``nccl`` backend (RCCL) the three floats
-    travel through a device tensor on ``device`` (default: current CUDA device)."""
+    travel through a device tensor on ``device`` (default: current CUDA device).  A group of one rank is
+    a no-op unless ``even_if_alone`` (which lets a 1-GPU box exercise the RCCL branch)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return results
+    if dist.get_world_size(group) == 1 and not even_if_alone:
         return results
     backend = dist.get_backend(group)
     if backend == "nccl":
@@ -81,20 +84,28 @@ def all_reduce_results(results, group=None, device=None):
         buf = results.data.to(dev)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         results.data.copy_(buf)
+        if getattr(results, "xent_objf", None) is not None:
+            xe = torch.tensor([results.xent_objf], dtype=torch.float64, device=dev)
+            dist.all_reduce(xe, op=dist.ReduceOp.SUM, group=group)
+            results.xent_objf = float(xe.item())
     else:
         dist.all_reduce(results.data, op=dist.ReduceOp.SUM, group=group)
+        if getattr(results, "xent_objf", None) is not None:
+            xe = torch.tensor([results.xent_objf], dtype=torch.float64)
+            dist.all_reduce(xe, op=dist.ReduceOp.SUM, group=group)
+            results.xent_objf = float(xe.item())
     return results
 
 
 def chain_loss_data_parallel(input, den_graph, supervision, l2_regularize=0.0, leaky_hmm_coefficient=1e-5,
-                             xent_regularize=0.0, xent_input=None, kaldi_way=False, group=None):
+                             xent_regularize=0.0, xent_input=None, kaldi_way=False, group=None, even_if_alone=False):
     """``chain_loss`` on this rank's shard followed by the one all-reduce.  Returns
     ``(loss, results)`` where ``results`` holds the GLOBAL ``[objf, l2_term, weight]`` and ``loss`` is a
     tensor whose value is the global ``-objf/weight`` and whose backward is this rank's local
     gradient (``-deriv``, exactly as the single-GPU wrapper; DDP then averages parameter grads)."""
     loss, results = chain_loss(input, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
                                xent_regularize, xent_input, kaldi_way)
-    all_reduce_results(results, group=group, device=input.device if input.is_cuda else None)
+    all_reduce_results(results, group=group, device=input.device if input.is_cuda else None, even_if_alone=even_if_alone)
     with torch.no_grad():
         loss.copy_(results.loss)
     return loss, results
