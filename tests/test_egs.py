@@ -1,0 +1,167 @@
+"""The Kaldi chain-egs reader (torchain_amd/egs.py + io.Example / RandExample / open_example / print_key_length,
+reference torchain/io.py:60-175 over src/my_lib_example*.cpp) on archives written by tests/kaldi_egs_writer.py and on
+the committed fixture tests/golden/chain_egs.ark.  CPU only; the GPU leg is in test_gpu_parity.py."""
+import io as pyio
+import os
+
+import numpy as np
+import pytest
+
+from torchain_amd import egs, io, synth
+
+import kaldi_egs_writer as kw
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def make_example(fst, T, seed, n_seq=1, feat_dim=7, ivec_dim=3, left=4, weight=1.0, final_weights=False):
+    """A synthetic chain eg: T output frames at t = 0, 3, 6, ... (frame-subsampling 3 as in the recipe), an input
+    window of 3*T + 2*left frames, a one-row i-vector, a supervision of `n_seq` sequences."""
+    rng = np.random.default_rng(seed)
+    sup = synth.random_supervision(fst, n_seq, T, 2, seed=seed, weight=weight, final_weights=final_weights)
+    n_in = 3 * T + 2 * left
+    feats = rng.standard_normal((n_seq * n_in, feat_dim)).astype(np.float32)
+    in_idx = np.array([(n, t, 0) for n in range(n_seq) for t in range(-left, 3 * T + left)], np.int32)
+    ivec = rng.standard_normal((n_seq, ivec_dim)).astype(np.float32)
+    iv_idx = np.array([(n, 0, 0) for n in range(n_seq)], np.int32)
+    out_idx = np.array([(n, 3 * t, 0) for t in range(T) for n in range(n_seq)], np.int32)  # frame-major
+    dw = rng.choice([0.0, 1.0], size=n_seq * T, p=[0.1, 0.9]).astype(np.float32)
+    return dict(inputs=[dict(name="input", indexes=in_idx, features=feats), dict(name="ivector", indexes=iv_idx, features=ivec)],
+                outputs=[dict(name="output", indexes=out_idx, supervision=sup, deriv_weights=dw)])
+
+
+def same_fst(a, b):
+    return (a.num_states == b.num_states and np.array_equal(a.arc_begin, b.arc_begin) and np.array_equal(a.ilabel, b.ilabel)
+            and np.array_equal(a.nextstate, b.nextstate) and np.allclose(a.arc_weight, b.arc_weight)
+            and np.array_equal(np.isinf(a.final), np.isinf(b.final)) and np.allclose(a.final[~np.isinf(a.final)], b.final[~np.isinf(b.final)]))
+
+
+@pytest.mark.parametrize("kind,tol", [("FM", 0.0), ("CM2", 2e-4), ("CM3", 3e-2), ("CM", 8e-2)])
+@pytest.mark.parametrize("dw", ["DW2", "DW"])
+def test_example_round_trip(kind, tol, dw):
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    eg = make_example(fst, 9, seed=3, n_seq=2, final_weights=True, weight=0.5)
+    blob = kw.chain_example(eg, matrix_kind=kind, dw=dw, e2e_flag=(kind == "CM2"))
+    got = egs.read_chain_example(pyio.BytesIO(blob))
+    assert [i["name"] for i in got["inputs"]] == ["input", "ivector"]
+    for a, b in zip(got["inputs"], eg["inputs"]):
+        np.testing.assert_array_equal(a["indexes"], b["indexes"])
+        assert a["features"].shape == b["features"].shape
+        scale = float(np.ptp(b["features"]))
+        assert np.abs(a["features"] - b["features"]).max() <= tol * scale + 1e-7
+    o, ref = got["outputs"][0], eg["outputs"][0]
+    np.testing.assert_array_equal(o["indexes"], ref["indexes"])
+    np.testing.assert_allclose(o["deriv_weights"], ref["deriv_weights"], atol=1e-6)
+    s, r = o["supervision"], ref["supervision"]
+    assert (s.weight, s.num_sequences, s.frames_per_sequence, s.label_dim) == (0.5, 2, 9, 24)
+    assert same_fst(s, r)
+
+
+def test_malformed_examples_are_refused():
+    fst = synth.random_den_fst(20, 3, 10, seed=2)
+    blob = kw.chain_example(make_example(fst, 4, seed=1))
+    for cut in (5, 40, len(blob) // 2, len(blob) - 3):
+        with pytest.raises(egs.EgsFormatError):
+            egs.read_chain_example(pyio.BytesIO(blob[:cut]))
+    with pytest.raises(egs.EgsFormatError):
+        egs.read_chain_example(pyio.BytesIO(blob.replace(b"<Nnet3ChainEg>", b"<Nnet3Eg>     ")))
+    with pytest.raises(egs.EgsFormatError):  # a ConstFst / VectorFst where the compact acceptor must be
+        egs.read_chain_example(pyio.BytesIO(blob.replace(b"compact_acceptor", b"compact_xcceptor")))
+
+
+def test_append_supervisions_is_the_product_of_the_pieces(oracle):
+    """[K] AppendSupervision semantics: the merged acceptor's log-partition is the sum of the pieces' and the
+    posteriors are the pieces' posteriors (checked with the oracle's numerator on the merged FST), the states are in
+    time order, and the merged FST is what tc_supervision_create accepts -- non-zero final weights included."""
+    fst = synth.random_den_fst(30, 3, 16, seed=4)
+    T = 6
+    pieces = [synth.random_supervision(fst, n, T, 2, seed=10 + n, final_weights=True) for n in (1, 2, 1, 1)]
+    merged = egs.append_supervisions(pieces)
+    S = sum(p.num_sequences for p in pieces)
+    assert (merged.num_sequences, merged.frames_per_sequence) == (S, T)
+    h = io.Supervision.from_synth(merged)
+    assert h.shape == (S, T, 16)
+    y = synth.random_nnet_output(S, T, 16, seed=5)  # rows t*S + s
+    tot = oracle.num_forward_backward(merged, y)
+    acc, derivs, s0 = 0.0, np.zeros_like(y).reshape(T, S, 16), 0
+    for p in pieces:
+        n = p.num_sequences
+        yp = np.ascontiguousarray(y.reshape(T, S, 16)[:, s0:s0 + n, :].reshape(T * n, 16))
+        r = oracle.num_forward_backward(p, yp)
+        acc += r["logprob_weighted"]
+        derivs[:, s0:s0 + n, :] = r["deriv"].reshape(T, n, 16)
+        s0 += n
+    assert abs(tot["logprob_weighted"] - acc) <= 1e-5 * abs(acc)
+    assert np.abs(tot["deriv"].reshape(T, S, 16) - derivs).max() <= 1e-5
+
+
+def _write_set(tmp_path, fst, lengths, **kwargs):
+    keyed = [("utt%03d-%d" % (i, L), make_example(fst, L, seed=20 + i)) for i, L in enumerate(lengths)]
+    ark, scp = str(tmp_path / "egs.ark"), str(tmp_path / "egs.scp")
+    kw.write_ark(ark, keyed, scp_path=scp, **kwargs)
+    return keyed, ark, scp
+
+
+def test_sequential_reader_delivers_every_example(tmp_path):
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    keyed, ark, scp = _write_set(tmp_path, fst, [5, 5, 8, 5], matrix_kind="CM")
+    for rspec in ("ark:" + ark, "ark,bg:" + ark, "scp:" + scp, ark, "ark:cat %s |" % ark):
+        rd = io.Example(rspec)
+        seen = 0
+        for (inp, aux), sup in rd:
+            L = keyed[seen][1]["outputs"][0]["supervision"].frames_per_sequence
+            assert sup.shape == (1, L, 24)
+            assert tuple(inp.shape) == (1, 7, 3 * L + 8) and tuple(aux.shape) == (1, 3)
+            assert rd.indexes.shape == (1, L) and rd.indexes[0, 1] == 3
+            assert rd.deriv_weights.shape == (L,)
+            seen += 1
+        assert seen == 4
+        with pytest.raises(ValueError):
+            rd.supervision  # past the end: "null supervision ptr", as in the reference
+    with io.open_example("cat " + ark) as rd:
+        assert sum(1 for _ in rd) == 4
+
+
+def test_rand_reader_batches_by_length(tmp_path):
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    lengths = [5] * 7 + [8] * 4 + [11]
+    keyed, ark, scp = _write_set(tmp_path, fst, lengths)
+    io.print_key_length("scp:" + scp, scp + ".len")
+    assert len(open(scp + ".len").read().split()) == 2 * len(lengths)
+    for len_file in ("", str(tmp_path / "absent.len")):  # from the .len file / from the egs themselves
+        rd = io.RandExample(scp, seed=3, batchsize=3, len_file=len_file) if len_file == "" else None
+        if rd is None:
+            os.rename(scp + ".len", scp + ".len.away")
+            rd = io.RandExample(scp, seed=3, batchsize=3)
+            os.rename(scp + ".len.away", scp + ".len")
+        assert rd.n_data == 12 and rd.n_batch == 3 + 2 + 1  # ceil(7/3) + ceil(4/3) + 1
+        total = 0
+        for (inp, aux), sup in rd:
+            B, L, P = sup.shape
+            assert P == 24 and L in (5, 8, 11) and 1 <= B <= 3
+            assert tuple(inp.shape) == (B, 7, 3 * L + 8) and tuple(aux.shape) == (B, 3)
+            assert rd.indexes.shape == (B, L) and rd.deriv_weights.shape == (B * L,)
+            total += B
+        assert total == 12
+    first = [tuple(b) for b in rd._key_batch]
+    rd.reset()
+    assert sum(1 for _ in rd) == 6
+    assert [tuple(b) for b in rd._key_batch] != first  # reshuffled
+
+
+def test_committed_fixture(oracle):
+    """tests/golden/chain_egs.ark (+ .scp, .json): written once by tests/golden/make_egs_fixture.py; the reader must
+    keep giving the recorded numbers."""
+    import json
+    meta = json.load(open(os.path.join(HERE, "golden", "chain_egs.json")))
+    got = list(egs.iter_archive(os.path.join(HERE, "golden", "chain_egs.ark")))
+    assert [k for k, _ in got] == meta["keys"]
+    for (key, eg), m in zip(got, meta["examples"]):
+        sup = eg["outputs"][0]["supervision"]
+        assert [sup.num_sequences, sup.frames_per_sequence, sup.label_dim, sup.num_states, int(sup.arc_begin[-1])] == m["sup"]
+        assert abs(float(eg["inputs"][0]["features"].sum()) - m["feat_sum"]) <= 1e-3 * max(1.0, abs(m["feat_sum"]))
+        assert abs(float(sup.arc_weight.sum()) - m["arc_weight_sum"]) <= 1e-4 * max(1.0, abs(m["arc_weight_sum"]))
+    merged = egs.merge_chain_examples([eg for _, eg in got if eg["outputs"][0]["supervision"].frames_per_sequence == meta["merge_len"]])
+    sup = merged["outputs"][0]["supervision"]
+    y = synth.random_nnet_output(sup.num_sequences, sup.frames_per_sequence, sup.label_dim, seed=meta["y_seed"])
+    assert abs(oracle.num_forward_backward(sup, y)["logprob_weighted"] - meta["merged_num_logprob"]) <= 1e-4 * abs(meta["merged_num_logprob"])

@@ -467,3 +467,36 @@ def test_xent_objective_value_and_rccl_branch(oracle):
         assert abs(res2.xent_objf - res.xent_objf) <= 1e-9 * abs(res.xent_objf)
     finally:
         dist.destroy_process_group()
+
+
+def test_chain_loss_on_minibatches_from_the_egs_reader(oracle, tmp_path):
+    """The recipe's loop (example/chime5/train_faster.py:79-129): io.RandExample(scp, seed, batchsize) yields
+    ((mfcc, ivector), supervision); chain_loss on a network output of the supervision's shape.  The merged
+    supervision comes out of the Kaldi-free egs reader and goes through tc_supervision_create; objective and
+    derivative against the oracle on the same merged FST."""
+    import kaldi_egs_writer as kw
+    from test_egs import make_example
+    from torchain_amd import egs, io
+    from torchain_amd.functions import chain_loss
+
+    fst = synth.random_den_fst(80, 4, 40, seed=81)
+    keyed = [("utt%02d" % i, make_example(fst, L, seed=300 + i, final_weights=True)) for i, L in enumerate([7, 7, 7, 10, 10])]
+    ark, scp = str(tmp_path / "egs.ark"), str(tmp_path / "egs.scp")
+    kw.write_ark(ark, keyed, scp_path=scp, matrix_kind="CM")
+    g = oracle.DenGraph(fst)
+    den = io.DenominatorGraph(fst, 40)
+    rd = io.RandExample(scp, seed=1, batchsize=3)
+    n = 0
+    for (mfcc, ivec), sup in rd:
+        B, T, P = sup.shape
+        merged = rd._cur["outputs"][0]["supervision"]
+        y = synth.random_nnet_output(B, T, P, seed=90 + n)
+        ref = oracle.compute_chain_objf_and_deriv(g, merged, y, 1e-4, 0.1)
+        x = torch.from_numpy(y.reshape(T, B, P).transpose(1, 2, 0).copy()).cuda().requires_grad_(True)
+        loss, res = chain_loss(x, den, sup, l2_regularize=1e-4, leaky_hmm_coefficient=0.1)
+        loss.backward()
+        assert abs(float(res.data[0]) - ref["objf"]) <= REL * abs(ref["objf"])
+        gx = x.grad.permute(2, 0, 1).reshape(T * B, P).cpu().numpy()
+        assert rel_err(gx, -ref["deriv"], floor=1.0) <= REL
+        n += 1
+    assert n == rd.n_batch == 2

@@ -3,14 +3,17 @@
 ``DenominatorGraph`` (reference ``io.py:51-57``) and ``Supervision`` (``io.py:20-31``) keep the
 attributes the reference exposes (``.ptr``, ``.n_pdf``, ``.n_batch``, ``.n_frame``, ``.shape``) but
 wrap the C-ABI handles of libtorchain_hip.so instead of heap Kaldi objects.  The Kaldi egs readers
-of the reference (``Example``, ``RandExample``, ``open_example``, ``io.py:60-175``) are out of
-scope: supervisions are built from FST arrays.
+of the reference (``Example``, ``RandExample``, ``open_example``, ``print_key_length``, ``io.py:60-175``) are
+here too, on top of ``torchain_amd.egs`` (a Kaldi-free parser of the ``<Nnet3ChainEg>`` formats).
 """
 import ctypes as C
+import os
+from contextlib import contextmanager
 
 import numpy as np
 import torch
 
+from . import egs as _egs
 from ._lib import check, lib
 
 
@@ -141,3 +144,171 @@ class Supervision:
         if ptr:
             _free(ptr)
             self.ptr = None
+
+
+# ---- Kaldi chain-egs readers (reference io.py:60-175) ------------------------------------------------------
+class Example:
+    """``Example(rspec)``: sequential reader of chain egs (reference ``io.py:60-113`` over Kaldi's
+    SequentialNnetChainExampleReader, ``src/my_lib_example.cpp:35-127``).  ``rspec`` is a Kaldi rspecifier
+    (``ark:file``, ``ark,bg:file``, ``scp:file``, ``ark:command |``).  Same surface as the reference: ``next()``,
+    ``load_feats``, ``supervision``, ``indexes``, ``inputs``, ``value()``, iteration yielding
+    ``((inp (B, F, T_in), aux), Supervision)``.
+
+    One deliberate difference: the reference's ``next()`` advances a reader that already stands on the first
+    example, so its iteration silently drops the first example of every archive (and ends on a null supervision);
+    here every example is delivered.  ``deriv_weights`` -- which the reference drops (``README.md:41``) -- is
+    available as a property."""
+
+    def __init__(self, rspec):
+        self.rspec = rspec
+        self._it = _egs.iter_rspecifier(rspec)
+        self._cur = None
+
+    def next(self):
+        try:
+            _key, eg = next(self._it)
+        except StopIteration:
+            self._cur = None
+            return False
+        self._cur = eg
+        return True
+
+    def _need(self):
+        if self._cur is None:
+            raise ValueError("null supervision ptr")  # what the reference raises past the end (io.py:23-24)
+        return self._cur
+
+    def load_feats(self, inp=None, aux=None):
+        """Reference ``my_lib_example_feats``: number of inputs of the current example (tensors are returned by
+        ``inputs``; the in-place TH resize of the reference has no counterpart)."""
+        return len(self._need()["inputs"])
+
+    @property
+    def supervision(self):
+        sup = self._need()["outputs"][0]["supervision"]
+        return Supervision.from_synth(sup)
+
+    @property
+    def indexes(self):
+        """(B, T) LongTensor of the output frames' ``t`` (reference ``my_lib_example_reader_indexes``)."""
+        out = self._need()["outputs"][0]
+        sup = out["supervision"]
+        t = out["indexes"][:, 1].reshape(sup.frames_per_sequence, sup.num_sequences)
+        return torch.from_numpy(np.ascontiguousarray(t.T).astype(np.int64))
+
+    @property
+    def deriv_weights(self):
+        """(T*B,) float tensor, frame-major like the nnet output rows ([K] NnetChainSupervision::deriv_weights)."""
+        return torch.from_numpy(self._need()["outputs"][0]["deriv_weights"].astype(np.float32))
+
+    @property
+    def inputs(self):
+        ins = self._need()["inputs"]
+        if len(ins) == 1:
+            return torch.from_numpy(ins[0]["features"]), None
+        if len(ins) == 2:
+            return torch.from_numpy(ins[0]["features"]), torch.from_numpy(ins[1]["features"])
+        raise ValueError("unsupported number of inputs (up to 2): %d" % len(ins))
+
+    def value(self):
+        supervision = self.supervision
+        n_batch, n_out_frame, n_pdf = supervision.shape
+        inp, aux = self.inputs
+        if inp is not None:
+            inp = inp.view(n_batch, -1, inp.shape[1]).transpose(1, 2)
+        return (inp, aux), supervision
+
+    def __iter__(self):
+        while self.next():
+            try:
+                yield self.value()
+            except ValueError:
+                continue
+
+
+def feats(egs):
+    """Reference ``io.py:34-48`` (broken there: it refers to ``self``): (input, aux-or-None) of the current example."""
+    if isinstance(egs, Example):
+        return egs.inputs
+    raise ValueError("unknown reader type")
+
+
+@contextmanager
+def open_example(cmd):
+    """Reference ``io.py:116-131``: runs ``cmd`` (e.g. ``nnet3-chain-copy-egs ... ark:-``) and reads the egs it writes
+    to stdout.  The reference goes through a FIFO and Kaldi's ``ark,bg:`` reader; a pipe does the same job."""
+    set_kaldi_device()
+    example = Example("ark:" + cmd + " |")
+    try:
+        yield example
+    finally:
+        del example
+
+
+def print_key_length(scp_path, len_file="/dev/stdout"):
+    """Reference ``io.py:134-135`` / ``my_lib_example_rand.cpp:168-177``: ``key frames_per_sequence`` per example."""
+    with open(len_file, "w") as f:
+        for key, eg in _egs.iter_rspecifier(scp_path):
+            f.write("%s %d\n" % (key, eg["outputs"][0]["supervision"].frames_per_sequence))
+
+
+class RandExample(Example):
+    """``RandExample(scp_path, seed, batchsize, len_file="")``: random-access reader that groups examples of equal
+    ``frames_per_sequence`` into minibatches, shuffles inside and across groups and merges each minibatch
+    ([K] MergeChainExamples) -- reference ``io.py:138-175`` over ``src/my_lib_example_rand.cpp:35-177``.  The
+    length file (``scp_path + ".len"`` unless given) holds ``key length`` pairs; without it the lengths are read
+    from the egs.  The shuffle uses NumPy's MT19937 seeded with ``seed``: the same generator as the reference's
+    ``std::mt19937`` but not the same draw order as ``std::shuffle``, whose algorithm is not specified."""
+
+    def __init__(self, scp_path, seed, batchsize, len_file=""):
+        assert os.path.exists(scp_path)
+        self.scp_path = scp_path
+        self.rspec = scp_path
+        self.batchsize = int(batchsize)
+        self._rng = np.random.RandomState(int(seed))
+        self._where = {key: (p, off) for key, p, off in _egs.read_scp(scp_path)}
+        self._length_to_keys = {}
+        lf = len_file or scp_path + ".len"
+        if os.path.exists(lf):
+            toks = open(lf).read().split()
+            for key, length in zip(toks[0::2], toks[1::2]):
+                self._length_to_keys.setdefault(int(length), []).append(key)
+        else:
+            for key, (p, off) in self._where.items():
+                eg = _egs.read_scp_entry(p, off)
+                self._length_to_keys.setdefault(eg["outputs"][0]["supervision"].frames_per_sequence, []).append(key)
+        self._n_data = sum(len(v) for v in self._length_to_keys.values())
+        self._shuffle_keys()
+        self._pos = -1
+        self._cur = None
+
+    def _shuffle_keys(self):
+        self._key_batch = []
+        for length in sorted(self._length_to_keys):
+            keys = list(self._length_to_keys[length])
+            self._rng.shuffle(keys)
+            for i in range(0, len(keys), self.batchsize):
+                self._key_batch.append(keys[i:i + self.batchsize])
+        self._rng.shuffle(self._key_batch)
+
+    def reset(self):
+        self._pos = -1
+        self._cur = None
+        self._shuffle_keys()
+
+    @property
+    def n_batch(self):
+        return len(self._key_batch)
+
+    @property
+    def n_data(self):
+        return self._n_data
+
+    def next(self):
+        self._pos += 1
+        if self._pos >= len(self._key_batch):
+            self._cur = None
+            return False
+        batch = [_egs.read_scp_entry(*self._where[k]) for k in self._key_batch[self._pos]]
+        self._cur = _egs.merge_chain_examples(batch)
+        return True
