@@ -3,7 +3,7 @@
 # default bench.py workload.  Each PMC group is its own pass (never combined with tracing).
 # Output: gpurun_out/prof_$1/{kt,fetch,write,sq1,sq2}/...  then scripts/summarize_profiles.py.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"

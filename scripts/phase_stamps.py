@@ -40,5 +40,5 @@ for ph, name in enumerate(("forward", "backward")):
     for i in range(5):
         print("  %-13s" % names[i], " ".join("%6.0f" % v for v in st[ph, :, i]))
     print("  total        ", " ".join("%6.0f" % v for v in st[ph, :, :5].sum(axis=1)))
-    print("  walk: wait   ", " ".join("%6.0f" % v for v in st[ph, :, 5]))
-    print("  walk: process", " ".join("%6.0f" % v for v in st[ph, :, 6]))
+    print("  walk: resident", " ".join("%6.0f" % v for v in st[ph, :, 5]))
+    print("  walk: streamed", " ".join("%6.0f" % v for v in st[ph, :, 6]))

@@ -6,7 +6,7 @@ import os
 import sys
 
 out, tag = sys.argv[1], sys.argv[2]
-KERNEL = "den_fwd_bwd_kernel"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "den_tied_kernel"  # the dominant kernel of the default bench workload
 
 
 def find(sub, pattern):

@@ -20,7 +20,11 @@ namespace tc {
 #define TC_STAMP_FLUSH(ptr)                                                         \
   if (blockIdx.x == 0 && lane == 0)                                                 \
     for (int i = 0; i < 8; ++i) (ptr)[wave * 8 + i] = st_acc[i];
+#define TC_WALK_ARG , long long *wst
+#define TC_WALK_PASS , wst
 #else
+#define TC_WALK_ARG
+#define TC_WALK_PASS
 #define TC_STAMP_DECL
 #define TC_STAMP(i)
 #define TC_STAMP_FLUSH(ptr)

@@ -65,8 +65,11 @@ __device__ __forceinline__ f4 bld4(rsrc_t r, uint32_t voff, uint32_t soff) {
 // soffset is an immediate (it takes the hardware to be safe when soffset is a register), so the offset goes
 // into the VGPR and soffset stays 0.
 __device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, f4 v) {
+#ifndef TC_STORE_AUX
+#define TC_STORE_AUX 2  /* nt: streaming stores, -1 % at C3 */
+#endif
   __builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
-                                         r, (int)voff, 0, 0);
+                                         r, (int)voff, 0, TC_STORE_AUX);
 }
 
 __device__ __forceinline__ f4 mk4(float x) { return f4{x, x, x, x}; }
@@ -165,7 +168,11 @@ struct RowCommit {
 
 // acc(row) += w * SRC[off] over one chunk.  Row ends are wave-uniform bits of the schedule's mask word m
 // (one word per two chunks; bit u: a row ends with the SECOND cell of pair u, bit 8 + u: with its FIRST
-// cell), tested with s_bitcmp; the commit is the rare side of a scalar branch.
+// cell), tested with s_bitcmp; the commit is the rare side of a scalar branch.  (Measured alternatives,
+// profiles/microbench/walk_variants.hip: rows padded to quads with one test per quad and packed FMAs run 8 %
+// faster per cell but need 14-21 % more cells; issuing the next chunk's gathers ahead of this chunk's sums
+// gains nothing; without any row ends the same loop would run 1.6x faster -- the commits, two taken branches
+// each, are what the rows cost.)
 template <uint32_t SRC, int HALF>
 __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc, RowCommit &rc) {
   uint32_t o[8];
@@ -201,50 +208,86 @@ __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc
 // One walk of a wave's stream: RES resident chunks, then the rest through two register buffers in
 // ping-pong (qa arrives preloaded with chunk RES when there is one; the stream is followed by readable
 // padding, so the look-ahead loads need no guard).  The mask words come through the scalar cache.
-// `pre_last` runs just before the wave's last chunk is processed: the place to request what the per-state
-// pass needs from L2 (one streaming buffer is free by then and the chunk's gathers cover the latency).
-template <uint32_t SRC, int RES, class PreLast>
+// `after_chunk(i)` runs after resident chunk i (once, with i = -1, when nothing is resident): the hook through
+// which the frame's global STORES are spread over the walk (see the kernel).
+template <uint32_t SRC, int RES, class AfterChunk>
 __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chunk6 &qa, rsrc_t sbase,
                                      uint32_t lane16, int nchunks, const uint32_t *masks, RowCommit rc,
-                                     PreLast pre_last) {
+                                     AfterChunk after_chunk TC_WALK_ARG) {
   static_assert(RES % 2 == 0, "a mask word covers two chunks");
   typedef __attribute__((address_space(4))) const uint32_t const_u32;
   const_u32 *mk = (const_u32 *)masks;
   float acc = 0.f;
+#ifdef TC_PHASE_STAMPS
+  wst[2] = clock64();
+#endif
 #pragma unroll
   for (int i = 0; i < RES / 2; ++i) {
     const uint32_t m = mk[i];
     do_chunk<SRC, 0>(res[2 * i], m, acc, rc);
+    after_chunk(2 * i);
     do_chunk<SRC, 1>(res[2 * i + 1], m, acc, rc);
+    after_chunk(2 * i + 1);
   }
-  if (nchunks == RES) pre_last();  // (only graphs padded up to the resident prefix)
+  if (RES == 0) after_chunk(-1);
+#ifdef TC_PHASE_STAMPS
+  {
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */
+    const long long now = clock64();
+    wst[0] += now - wst[2];  // resident part
+    wst[2] = now;
+  }
+#endif
+  // Streamed part.  Inside the loop both look-ahead loads are unconditional, so the compiler knows how many
+  // loads are in flight when it waits for a buffer (a load behind a condition makes it fall back to vmcnt(0),
+  // which serialises every chunk behind an L2 round trip); the last one or two chunks are peeled.
   Chunk6 qb;
-  for (int c = RES; c < nchunks; c += 2) {
+  int c = RES;
+  for (; c + 2 < nchunks; c += 2) {
     const uint32_t m = mk[c >> 1];
-    if (c + 1 < nchunks)
-      load_chunk(qb, sbase, lane16, c + 1);
-    else
-      pre_last();
+    load_chunk(qb, sbase, lane16, c + 1);
     do_chunk<SRC, 0>(qa, m, acc, rc);
-    if (c + 1 >= nchunks) break;
-    if (c + 2 < nchunks)
-      load_chunk(qa, sbase, lane16, c + 2);
-    else
-      pre_last();
+    load_chunk(qa, sbase, lane16, c + 2);
     do_chunk<SRC, 1>(qb, m, acc, rc);
   }
+  if (c + 1 < nchunks) {
+    const uint32_t m = mk[c >> 1];
+    load_chunk(qb, sbase, lane16, c + 1);
+    do_chunk<SRC, 0>(qa, m, acc, rc);
+    do_chunk<SRC, 1>(qb, m, acc, rc);
+  } else if (c < nchunks) {
+    do_chunk<SRC, 0>(qa, mk[c >> 1], acc, rc);
+  }
+#ifdef TC_PHASE_STAMPS
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  wst[1] += clock64() - wst[2];  // streamed part
+#endif
 }
 
 // The CU serves older waves first wherever waves contend, so the youngest wave of each SIMD finishes its
 // walk last and every frame waits for it: during the walks the four wave generations run at issue
 // priorities 0..3, youngest highest.
 __device__ __forceinline__ void age_prio_on(int wave) {
+#ifndef TC_PRIO_MODE
+#define TC_PRIO_MODE 0
+#endif
+#if TC_PRIO_MODE == 0
   if (wave >= 12)
     __builtin_amdgcn_s_setprio(3);
   else if (wave >= 8)
     __builtin_amdgcn_s_setprio(2);
   else if (wave >= 4)
     __builtin_amdgcn_s_setprio(1);
+#elif TC_PRIO_MODE == 1
+  (void)wave;
+#elif TC_PRIO_MODE == 2
+  if (wave >= 8) __builtin_amdgcn_s_setprio(1);
+#elif TC_PRIO_MODE == 3
+  if (wave >= 12)
+    __builtin_amdgcn_s_setprio(2);
+  else if (wave >= 4)
+    __builtin_amdgcn_s_setprio(1);
+#endif
 }
 
 // fs = forward-pdf*4 | self-loop-pdf*4 << 16 (LDS byte offsets into exp(y)), ws = self-loop probability
@@ -274,6 +317,12 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = blockIdx.x;
+#ifdef TC_STAGGER
+  // All workgroups run the same phases in lockstep, so every CU issues its history / derivative stores and its
+  // y / history loads at the same instant: the memory system sees bursts.  A start offset of a fraction of a
+  // frame per workgroup spreads them over the frame period.
+  for (int i = 0; i < (int)(blockIdx.x % TC_STAGGER); ++i) __builtin_amdgcn_s_sleep(TC_STAGGER_SLEEP);
+#endif
   const int H = p.H, P = p.P, S = p.S, T = p.T;
   const int Hs = p.L.Hs, Ps = p.L.Ps;
   // tied graphs are laid out in whole planes of 4096 positions (schedule_owner.cpp build_owner): which of its
@@ -311,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     if (j < planes) {
       const f4 a = pi4[j] + (leaky * pi4[j]) * asum;
       lds4_st(kA0 + own16 + j * kPlane, a);
-      bst4(make_rsrc(hist, 4u * Hs), own16 + j * kPlane, pi4[j]);  // the history holds the UN-dashed alpha_t (below)
+      bst4(make_rsrc(hist, 4u * Hs), own16 + j * kPlane, a);
     }
   float y2 = 0.f;
   {
@@ -332,7 +381,11 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   // ---- forward frames t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
   {
     const int2 frange = p.fwd.wave_range[wave];
+#ifdef TC_ABL_NOSTREAM
+    const int fnch = RESF;
+#else
     const int fnch = __builtin_amdgcn_readfirstlane(frange.y) / kChunk;
+#endif
     // (the descriptor covers the wave's range and the look-ahead past it: the array ends with readable padding)
     const rsrc_t fbase = make_rsrc(reinterpret_cast<const char *>(p.fwd.cells) +
                                        (int64_t)(__builtin_amdgcn_readfirstlane(frange.x) / kChunk) * (3 * 64 * 16),
@@ -356,6 +409,8 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
           lds4_st(aWS + own16 + j * kPlane, bld4(r_ws, own16, j * kPlane));
         }
     }
+    // which resident chunk a wave issues its deferred stores after: one wave generation per chunk
+    const int store_slot = RESF >= 4 ? wave >> 2 : RESF >= 2 ? wave >> 3 : 0;
     TC_STAMP_DECL
     for (int t = 1; t <= T; ++t) {
       TC_STAMP(0)
@@ -369,8 +424,21 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
 #pragma unroll
         for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
       }
+      // The history row of frame t-1 is stored from here, not from the end of frame t-1: a CU issues a 1 KB
+      // store instruction only every ~60 cycles, so the 32 of a frame, issued back to back by 16 waves,
+      // held the frame's tail for ~1.9k cycles (profiles/r02_phase_stamps_before_spread.txt).  Under the walk
+      // the store path is idle: the four wave generations issue theirs after resident chunk 0, 1, 2, 3.
       age_prio_on(wave);
-      walk<kA0, RESF>(fres, q0, fbase, lane16, fnch, fmask, frc, [] {});
+      walk<kA0, RESF>(fres, q0, fbase, lane16, fnch, fmask, frc, [&](int i) {
+        if (t > 1 && (i < 0 || i == store_slot)) {
+          const rsrc_t hist_prev = make_rsrc(hist + (int64_t)(t - 1) * hist_step, 4u * Hs);
+#ifndef TC_ABL_NOHIST
+#pragma unroll
+          for (int j = 0; j < JV; ++j)  // alpha'_{t-1} of the owned states: still in the gather buffer
+            if (j < planes) bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
+#endif
+        }
+      } TC_WALK_PASS);
       __builtin_amdgcn_s_setprio(0);
       TC_STAMP(2)
       if (p.fwd.nfix) {
@@ -387,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         if (j < planes) {
           fs[j] = tabs_lds ? lds4u(aFS + own16 + j * kPlane) : bld4u(r_fs, own16, j * kPlane);
           ws[j] = tabs_lds ? lds4(aWS + own16 + j * kPlane) : bld4(r_ws, own16, j * kPlane);
-          cpi[j] = leaky * bld4(r_pi, own16, j * kPlane);  // (consumed behind the reduction)
+          cpi[j] = bld4(r_pi, own16, j * kPlane);  // pi: first touched behind the reduction, which hides its L2 trip
         }
 #pragma unroll
       for (int j = 0; j < JV; ++j) {
@@ -403,18 +471,14 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         }
       }
       asum = block_sum_a(part, aRed, wave, lane);
+      __builtin_amdgcn_sched_barrier(0);  // (keeps the multiply by leaky, and with it the wait for pi, down here)
       TC_STAMP(4)
-      const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs);
       float part_tot = 0.f;
 #pragma unroll
       for (int j = 0; j < JV; ++j)
         if (j < planes) {
-          const f4 a = v4[j] + cpi[j] * asum;
+          const f4 a = v4[j] + (leaky * cpi[j]) * asum;
           lds4_st(kA0 + own16 + j * kPlane, a);
-          // The history holds alpha_t, not alpha'_t: the backward pass needs both, alpha'_t = alpha_t + leaky*pi*asum_t
-          // is an addition, while recovering alpha_t from alpha'_t would be a subtraction that loses everything
-          // where alpha_t << leaky*pi*asum_t -- states that peaky outputs can still give a large posterior.
-          bst4(hist_t, own16 + j * kPlane, v4[j]);
           part_tot += hsum(a);
         }
       if (t < T) {
@@ -430,6 +494,12 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
       inv_prev = __builtin_amdgcn_rcpf(asum);
       if (t == T) part = part_tot;
+    }
+    {
+      const rsrc_t hist_T = make_rsrc(hist + (int64_t)T * hist_step, 4u * Hs);
+#pragma unroll
+      for (int j = 0; j < JV; ++j)
+        if (j < planes) bst4(hist_T, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
     }
     TC_STAMP(0)
     TC_STAMP_FLUSH(p.stamps)
@@ -464,7 +534,11 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   // walk, needed to form Y for the next frame); the tight layout has one and pays a barrier instead
   uint32_t pb_cur = kPB, pb_next = ALPHA_LDS ? 4u * (uint32_t)p.L.off_p2 : kPB;
   const int2 brange = p.bwd.wave_range[wave];
+#ifdef TC_ABL_NOSTREAM
+  const int bnch = RESB;
+#else
   const int bnch = __builtin_amdgcn_readfirstlane(brange.y) / kChunk;
+#endif
   const rsrc_t bbase = make_rsrc(reinterpret_cast<const char *>(p.bwd.cells) +
                                      (int64_t)(__builtin_amdgcn_readfirstlane(brange.x) / kChunk) * (3 * 64 * 16),
                                  (uint32_t)(bnch + 2) * (3 * 64 * 16));
@@ -506,6 +580,26 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
                    bown[j].z * ldsf(pb_cur + (fs.z & 0xffffu)), bown[j].w * ldsf(pb_cur + (fs.w & 0xffffu))});
       }
   }
+  const int bstore_slot = RESB >= 4 ? wave >> 2 : RESB >= 2 ? wave >> 3 : 0;
+  f4 dpend[PV];  // derivative row of the frame just finished, stored under the next frame's walk
+#pragma unroll
+  for (int v = 0; v < PV; ++v) dpend[v] = mk4(0.f);
+  auto store_deriv_row = [&](int frame) {
+    const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)frame * S + s) * p.deriv_stride, row_bytes);
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * ((int)tid + kThreads * v);
+      if (i0 < Ps) {
+        f4 o = dpend[v];
+        if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
+#ifndef TC_ABL_NODERIV
+        row_st(drow, own16 + v * kPlane, p.d_vec, o);
+#else
+        if (o.x == 123.456f) row_st(drow, own16 + v * kPlane, p.d_vec, o);
+#endif
+      }
+    }
+  };
   TC_STAMP_DECL
   for (int t = T - 1; t >= 0; --t) {
     TC_STAMP(0)
@@ -526,8 +620,13 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       for (int j = 0; j < JV; ++j) areg[j] = j < planes ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
     }
     // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
+    // (the derivative row of frame t+1 leaves from here, for the reason given at the forward walk)
     age_prio_on(wave);
-    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [] {});
+    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
+#ifndef TC_NO_BWD_DEFER
+      if (t < T - 1 && (i < 0 || i == bstore_slot)) store_deriv_row(t + 1);
+#endif
+    } TC_WALK_PASS);
     __builtin_amdgcn_s_setprio(0);
     if (ALPHA_LDS) {
       // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
@@ -547,6 +646,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     uint32_t fpk[JV][2];  // forward-pdf offsets of the owned states, kept for the Y update below
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
+    const float asum_up = ldsf(aAsum + 4u * (t + 1));
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       b4[j] = mk4(0.f);
@@ -555,27 +655,28 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
         const f4 ws = bld4(r_ws, own16, j * kPlane);
         const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
         f4 a = own_rows(vrow, j);
-        const f4 al = areg[j] + cp * asum_t;  // alpha'_t of the owned states
-        // alpha_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
+        const f4 al = areg[j];  // alpha'_t of the owned states
+        // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
         const f4 aup = ALPHA_LDS ? lds4(aAL + own16 + j * kPlane) : bld4(make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs), own16, j * kPlane);
         // Everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
         //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
         //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
         //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
-        // with alpha_{t+1} (un-dashed) from the history.  The self-loop arc also adds
-        // vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
-        auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float ax) {
+        // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history (measured against float64 on peaky
+        // outputs, profiles/r02_peaky.txt: keeping the un-dashed alpha in the history instead changes nothing).
+        // The self-loop arc also adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
+        auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float ax) {
           const float ps_ws = ldsf(pb_cur + (fsx >> 16)) * wsx;
           const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
           const float bos = kGammaScale * bo;            // power-of-two scale: exact
           gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
-          gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf(aupx - selfpart, 0.f));
+          gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
           return fmaf(ps_ws, bo, ax);                    // vf_s into beta'_t(g) * asum_t
         };
-        a.x = one(fs.x, ws.x, bown[j].x, al.x, aup.x, a.x);
-        a.y = one(fs.y, ws.y, bown[j].y, al.y, aup.y, a.y);
-        a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, a.z);
-        a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, a.w);
+        a.x = one(fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x);
+        a.y = one(fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y);
+        a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z);
+        a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w);
         b4[j] = a * inv_as;  // [K] * inv_arbitrary_scale
         fpk[j][0] = (fs.x & 0xffffu) | (fs.y << 16);
         fpk[j][1] = (fs.z & 0xffffu) | (fs.w << 16);
@@ -586,7 +687,6 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
     TC_STAMP(4)
     {
-      const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
 #pragma unroll
       for (int v = 0; v < PV; ++v) {
         const int i0 = 4 * ((int)tid + kThreads * v);
@@ -595,12 +695,15 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
           lds4_st(aGM + 4u * i0, mk4(0.f));
           const f4 g = f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} * kGammaInvScale;
           if (t == 0) part_g += hsum(g);
-          f4 o = p.deriv_weight * g - p.l2_scale * ycur[v];
-          if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
-          row_st(drow, own16 + v * kPlane, p.d_vec, o);
+          dpend[v] = p.deriv_weight * g - p.l2_scale * ycur[v];
         }
       }
     }
+#ifdef TC_NO_BWD_DEFER
+    store_deriv_row(t);
+#else
+    if (t == 0) store_deriv_row(0);
+#endif
     if (t == 0) {
       // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
       const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
