@@ -4,7 +4,8 @@
 // functions.py:112 negates the gradient -- three more passes over a 629 MB tensor at C3.  These two
 // kernels do the forward permutation in one pass and the backward permutation, the negation and the
 // xent scale in one pass.  Both are plain HBM-bound transposes through LDS: a workgroup moves a
-// [64 channels] x [<= 240 frames] tile of one sequence, reading and writing 256-byte (or longer) runs.
+// [64 channels] x [<= 240 frames] tile of one sequence, reading and writing 256-byte (or longer) runs; the
+// backward one reads its 2-D rows with 16-byte loads and writes 8-byte pairs where alignment allows.
 #include "chain_internal.h"
 
 namespace tc {
@@ -14,7 +15,7 @@ namespace {
 constexpr int kTileC = 64, kTileTMax = 240, kLayoutThreads = 512;
 
 // TO2D: in (B, C, T) contiguous -> out[(t*B + b) * out_stride + c];  !TO2D: the inverse, times `scale`
-template <bool TO2D>
+template <bool TO2D, bool VEC>
 __global__ __launch_bounds__(kLayoutThreads) void layout_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                                 int B, int Cn, int T, int64_t stride2d, float scale) {
   extern __shared__ float tile[];  // kTileC x (frames of the tile | 1): sized by the launch, several blocks per CU
@@ -25,7 +26,8 @@ __global__ __launch_bounds__(kLayoutThreads) void layout_kernel(const float *__r
   const float *bct = TO2D ? in : out;  // the (B, C, T) side
   (void)bct;
   if (TO2D) {
-    // read runs of tc floats along t (for tc == T the whole tile is one contiguous block)
+    // read runs of tc floats along t (for tc == T the whole tile is one contiguous block); dword accesses on both
+    // sides: 16-byte row stores and 8-byte run loads were measured here and are slower (0.30 vs 0.26 ms at C3)
     for (int idx = tid; idx < nc * tc; idx += kLayoutThreads) {
       const int c = idx / tc, t = idx - c * tc;
       tile[c * pitch + t] = in[((int64_t)b * Cn + c0 + c) * T + t0 + t];
@@ -35,13 +37,44 @@ __global__ __launch_bounds__(kLayoutThreads) void layout_kernel(const float *__r
     for (int t = tid / kTileC; t < tc; t += kLayoutThreads / kTileC)
       if (cx < nc) out[((int64_t)(t0 + t) * B + b) * stride2d + c0 + cx] = tile[cx * pitch + t];
   } else {
-    const int cx = tid & (kTileC - 1);
-    for (int t = tid / kTileC; t < tc; t += kLayoutThreads / kTileC)
-      if (cx < nc) tile[cx * pitch + t] = in[((int64_t)(t0 + t) * B + b) * stride2d + c0 + cx];
+    // Read side: 16-byte loads when the 2-D rows are 16-byte aligned -- a wave then reads four 256-byte row
+    // segments per instruction instead of one (the dword form left this kernel at 41 % of the HBM peak).
+    if (VEC) {
+      const int cq = (tid & 15) * 4, tr = tid >> 4;  // 16 threads per row segment, 32 rows per pass
+      for (int t = tr; t < tc; t += kLayoutThreads / 16) {
+        const float *src = in + ((int64_t)(t0 + t) * B + b) * stride2d + c0 + cq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cq + 3 < nc) {
+          v = *reinterpret_cast<const float4 *>(src);
+        } else {
+          if (cq < nc) v.x = src[0];
+          if (cq + 1 < nc) v.y = src[1];
+          if (cq + 2 < nc) v.z = src[2];
+        }
+        tile[(cq + 0) * pitch + t] = v.x;
+        tile[(cq + 1) * pitch + t] = v.y;
+        tile[(cq + 2) * pitch + t] = v.z;
+        tile[(cq + 3) * pitch + t] = v.w;
+      }
+    } else {
+      const int cx = tid & (kTileC - 1);
+      for (int t = tid / kTileC; t < tc; t += kLayoutThreads / kTileC)
+        if (cx < nc) tile[cx * pitch + t] = in[((int64_t)(t0 + t) * B + b) * stride2d + c0 + cx];
+    }
     __syncthreads();
-    for (int idx = tid; idx < nc * tc; idx += kLayoutThreads) {
-      const int c = idx / tc, t = idx - c * tc;
-      out[((int64_t)b * Cn + c0 + c) * T + t0 + t] = scale * tile[c * pitch + t];
+    // Write side: runs of tc floats per channel; 8-byte stores when every run starts 8-byte aligned
+    if (VEC && (T & 1) == 0 && (tc & 1) == 0) {
+      const int half = tc / 2;
+      for (int idx = tid; idx < nc * half; idx += kLayoutThreads) {
+        const int c = idx / half, t = 2 * (idx - c * half);
+        *reinterpret_cast<float2 *>(out + ((int64_t)b * Cn + c0 + c) * T + t0 + t) =
+            make_float2(scale * tile[c * pitch + t], scale * tile[c * pitch + t + 1]);
+      }
+    } else {
+      for (int idx = tid; idx < nc * tc; idx += kLayoutThreads) {
+        const int c = idx / tc, t = idx - c * tc;
+        out[((int64_t)b * Cn + c0 + c) * T + t0 + t] = scale * tile[c * pitch + t];
+      }
     }
   }
 }
@@ -94,10 +127,14 @@ int launch_layout(bool to2d, const float *in, float *out, int B, int Cn, int T, 
                   hipStream_t stream) {
   const dim3 grid((Cn + kTileC - 1) / kTileC, B, (T + kTileTMax - 1) / kTileTMax);
   const size_t lds = sizeof(float) * kTileC * ((size_t)(T < kTileTMax ? T : kTileTMax) | 1);
+  // 16-byte path of the 2-D side: rows and base 16-byte aligned, whole float4s of channels in every tile
+  const bool vec = stride2d % 4 == 0 && ((uintptr_t)(to2d ? out : in) & 15) == 0 && ((uintptr_t)(to2d ? in : out) & 7) == 0;
   if (to2d)
-    hipLaunchKernelGGL(layout_kernel<true>, grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
+    hipLaunchKernelGGL((layout_kernel<true, false>), grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
+  else if (vec)
+    hipLaunchKernelGGL((layout_kernel<false, true>), grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
   else
-    hipLaunchKernelGGL(layout_kernel<false>, grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
+    hipLaunchKernelGGL((layout_kernel<false, false>), grid, dim3(kLayoutThreads), lds, stream, in, out, B, Cn, T, stride2d, scale);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
 }
