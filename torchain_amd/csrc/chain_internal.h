@@ -273,6 +273,9 @@ inline int round4(int x) { return (x + 3) & ~3; }
 bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L);
 int64_t layout_lds_bytes(const DenLayout &L, int T);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size class) instead of before every
+// launch: it is a driver call on the launch path of the hot loop.
+hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes);                    // den_graph.cpp
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip

@@ -18,6 +18,20 @@ namespace tc {
 
 thread_local int g_last_hip_error = 0;
 
+hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> granted;  // largest size already granted
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &have = granted[std::make_pair(kernel, device)];
+  if (have >= lds_bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimitBytes);
+  if (e == hipSuccess) have = kLdsLimitBytes;
+  return e;
+}
+
 static std::atomic<int> g_debug[kDbgCount];
 bool debug_flag(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed) != 0; }
 

@@ -427,7 +427,7 @@ static int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipSt
     k = al ? den_fwd_bwd_kernel<JV, PV, true, true, true> : den_fwd_bwd_kernel<JV, PV, false, true, true>;
   else
     k = al ? den_fwd_bwd_kernel<JV, PV, true, false, true> : den_fwd_bwd_kernel<JV, PV, false, false, true>;
-  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds_bytes));
   hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;

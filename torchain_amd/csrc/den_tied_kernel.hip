@@ -770,7 +770,7 @@ int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipStream_t 
     k = al ? den_tied_kernel<JV, PV, true, true, true, RF, RB> : den_tied_kernel<JV, PV, false, true, true, RF, RB>;
   else
     k = al ? den_tied_kernel<JV, PV, true, false, true, RF, RB> : den_tied_kernel<JV, PV, false, false, true, RF, RB>;
-  TC_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds_bytes));
   hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;

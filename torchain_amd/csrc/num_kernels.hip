@@ -129,8 +129,7 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
 int launch_num(const NumParams &p, hipStream_t stream) {
   const size_t lds = (size_t)p.lds_states * 16 + (size_t)p.lds_uniq * 4 + (size_t)p.lds_arcs * 4;
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
-  TC_HIP_CHECK(hipFuncSetAttribute((const void *)num_fwd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+  TC_HIP_CHECK(allow_dynamic_lds((const void *)num_fwd_bwd_kernel, lds));
   hipLaunchKernelGGL(num_fwd_bwd_kernel, dim3(p.S), dim3(128), lds, stream, p);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
