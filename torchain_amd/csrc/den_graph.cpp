@@ -27,8 +27,9 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes) {
   std::lock_guard<std::mutex> lock(mu);
   size_t &have = granted[std::make_pair(kernel, device)];
   if (have >= lds_bytes) return hipSuccess;
-  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimitBytes);
-  if (e == hipSuccess) have = kLdsLimitBytes;
+  // the request itself, not the chip's limit: a kernel with static LDS of its own cannot be granted all of it
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e == hipSuccess) have = lds_bytes;
   return e;
 }
 

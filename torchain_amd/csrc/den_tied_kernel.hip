@@ -580,26 +580,6 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
                    bown[j].z * ldsf(pb_cur + (fs.z & 0xffffu)), bown[j].w * ldsf(pb_cur + (fs.w & 0xffffu))});
       }
   }
-  const int bstore_slot = RESB >= 4 ? wave >> 2 : RESB >= 2 ? wave >> 3 : 0;
-  f4 dpend[PV];  // derivative row of the frame just finished, stored under the next frame's walk
-#pragma unroll
-  for (int v = 0; v < PV; ++v) dpend[v] = mk4(0.f);
-  auto store_deriv_row = [&](int frame) {
-    const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)frame * S + s) * p.deriv_stride, row_bytes);
-#pragma unroll
-    for (int v = 0; v < PV; ++v) {
-      const int i0 = 4 * ((int)tid + kThreads * v);
-      if (i0 < Ps) {
-        f4 o = dpend[v];
-        if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
-#ifndef TC_ABL_NODERIV
-        row_st(drow, own16 + v * kPlane, p.d_vec, o);
-#else
-        if (o.x == 123.456f) row_st(drow, own16 + v * kPlane, p.d_vec, o);
-#endif
-      }
-    }
-  };
   TC_STAMP_DECL
   for (int t = T - 1; t >= 0; --t) {
     TC_STAMP(0)
@@ -620,13 +600,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       for (int j = 0; j < JV; ++j) areg[j] = j < planes ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
     }
     // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
-    // (the derivative row of frame t+1 leaves from here, for the reason given at the forward walk)
+    // (deferring the derivative row's store into the next walk, as the forward phase does with the history row,
+    // was measured: no gain, and the four registers it holds across the barrier spill)
     age_prio_on(wave);
-    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
-#ifndef TC_NO_BWD_DEFER
-      if (t < T - 1 && (i < 0 || i == bstore_slot)) store_deriv_row(t + 1);
-#endif
-    } TC_WALK_PASS);
+    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [](int) {} TC_WALK_PASS);
     __builtin_amdgcn_s_setprio(0);
     if (ALPHA_LDS) {
       // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
@@ -687,6 +664,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
     TC_STAMP(4)
     {
+      const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
 #pragma unroll
       for (int v = 0; v < PV; ++v) {
         const int i0 = 4 * ((int)tid + kThreads * v);
@@ -695,15 +673,16 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
           lds4_st(aGM + 4u * i0, mk4(0.f));
           const f4 g = f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} * kGammaInvScale;
           if (t == 0) part_g += hsum(g);
-          dpend[v] = p.deriv_weight * g - p.l2_scale * ycur[v];
+          f4 o = p.deriv_weight * g - p.l2_scale * ycur[v];
+          if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
+#ifndef TC_ABL_NODERIV
+          row_st(drow, own16 + v * kPlane, p.d_vec, o);
+#else
+          if (o.x == 123.456f) row_st(drow, own16 + v * kPlane, p.d_vec, o);
+#endif
         }
       }
     }
-#ifdef TC_NO_BWD_DEFER
-    store_deriv_row(t);
-#else
-    if (t == 0) store_deriv_row(0);
-#endif
     if (t == 0) {
       // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
       const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
