@@ -39,6 +39,12 @@ __device__ __forceinline__ float ldsf(uint32_t a) { return *reinterpret_cast<lds
 __device__ __forceinline__ void ldsf_st(uint32_t a, float v) { *reinterpret_cast<lds_f *>(a) = v; }
 __device__ __forceinline__ f4 lds4(uint32_t a) { return *reinterpret_cast<lds_f4 *>(a); }
 __device__ __forceinline__ void lds4_st(uint32_t a, f4 v) { *reinterpret_cast<lds_f4 *>(a) = v; }
+// ds_write_b128 base + compile-time offset, the offset pinned into the instruction's immediate field: left to
+// the compiler, "16 * tid + constant" addresses of the per-frame tail become loop-invariant VGPRs of their own, and
+// in the backward loop of the full kernel those are what it spills (reloaded behind a vmcnt(0) every frame).
+__device__ __forceinline__ void lds4_st_at(uint32_t base, uint32_t off, f4 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(base), "v"(v), "i"(off) : "memory");
+}
 __device__ __forceinline__ u4 lds4u(uint32_t a) { return *reinterpret_cast<lds_u4 *>(a); }
 __device__ __forceinline__ void lds_add_u32(uint32_t a, uint32_t v) {
   __hip_atomic_fetch_add(reinterpret_cast<lds_u *>(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -580,6 +586,12 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
                    bown[j].z * ldsf(pb_cur + (fs.z & 0xffffu)), bown[j].w * ldsf(pb_cur + (fs.w & 0xffffu))});
       }
   }
+#ifdef TC_NO_BWD_DEFER
+  constexpr bool kDeferDeriv = false;
+#else
+  constexpr bool kDeferDeriv = ALPHA_LDS;  // (the tight layout has one exp(y) buffer: nowhere to wait)
+#endif
+  const int bstore_slot = RESB >= 4 ? wave >> 2 : RESB >= 2 ? wave >> 3 : 0;
   TC_STAMP_DECL
   for (int t = T - 1; t >= 0; --t) {
     TC_STAMP(0)
@@ -600,10 +612,19 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       for (int j = 0; j < JV; ++j) areg[j] = j < planes ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
     }
     // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
-    // (deferring the derivative row's store into the next walk, as the forward phase does with the history row,
-    // was measured: no gain, and the four registers it holds across the barrier spill)
+    // The derivative row of frame t+1 leaves from here, for the reason given at the forward walk (16 stores in
+    // a row held the backward tail for ~1k cycles: profiles/r02_phase_stamps.txt, tail of waves 0-3 vs 12-15).
+    // It waits, thread-private, in the exp(y) buffer that went dead with frame t+1's per-state pass and that
+    // this thread overwrites only after its walk.
     age_prio_on(wave);
-    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [](int) {} TC_WALK_PASS);
+    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
+      if (kDeferDeriv && t < T - 1 && (i < 0 || i == bstore_slot)) {
+        const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)(t + 1) * S + s) * p.deriv_stride, row_bytes);
+#pragma unroll
+        for (int v = 0; v < PV; ++v)
+          if (4 * ((int)tid + kThreads * v) < Ps) row_st(drow, own16 + v * kPlane, p.d_vec, lds4(pb_next + own16 + v * kPlane));
+      }
+    } TC_WALK_PASS);
     __builtin_amdgcn_s_setprio(0);
     if (ALPHA_LDS) {
       // exp(y_{t-1}) into the other buffer while the slower waves finish their walk
@@ -676,7 +697,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
           f4 o = p.deriv_weight * g - p.l2_scale * ycur[v];
           if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
 #ifndef TC_ABL_NODERIV
-          row_st(drow, own16 + v * kPlane, p.d_vec, o);
+          if (kDeferDeriv && t > 0)
+            lds4_st(pb_cur + 4u * i0, o);
+          else
+            row_st(drow, own16 + v * kPlane, p.d_vec, o);
 #else
           if (o.x == 123.456f) row_st(drow, own16 + v * kPlane, p.d_vec, o);
 #endif
@@ -713,9 +737,12 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       if (j < planes) {
         const f4 b = b4[j] + bsum;
         bown[j] = b;
-        lds4_st(kA0 + own16 + j * kPlane,
-                f4{b.x * ldsf(pb_next + (fpk[j][0] & 0xffffu)), b.y * ldsf(pb_next + (fpk[j][0] >> 16)),
-                   b.z * ldsf(pb_next + (fpk[j][1] & 0xffffu)), b.w * ldsf(pb_next + (fpk[j][1] >> 16))});
+        const f4 yv = f4{b.x * ldsf(pb_next + (fpk[j][0] & 0xffffu)), b.y * ldsf(pb_next + (fpk[j][0] >> 16)),
+                         b.z * ldsf(pb_next + (fpk[j][1] & 0xffffu)), b.w * ldsf(pb_next + (fpk[j][1] >> 16))};
+        if constexpr (kA0 + (JV - 1) * kPlane < 65536u)
+          lds4_st_at(own16, kA0 + j * kPlane, yv);
+        else
+          lds4_st(kA0 + own16 + j * kPlane, yv);
         if (ALPHA_LDS) lds4_st(aAL + own16 + j * kPlane, areg[j]);
       }
 #pragma unroll
