@@ -14,9 +14,13 @@ pytestmark = pytest.mark.gpu
 REL = 1e-4
 
 
-def test_config2_full_size_full_objective(oracle):
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_config2_full_size_full_objective(oracle, kernel_family, form):
     """configs[1]: CHiME5-like den graph (H=8192, A=65536, P=4096), batch 64 x 150 frames, objf / l2 / weight /
-    derivative / xent derivative vs the oracle."""
+    derivative / xent derivative vs the oracle -- in the two-CU form a batch of 64 takes by default and in the
+    fused kernel."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     c = synth.CONFIGS["C2"]
     fst = synth.config_den_fst("C2")
     S, T, P = c["S"], c["T"], c["P"]

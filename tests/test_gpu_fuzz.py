@@ -40,8 +40,10 @@ def _case(oracle, rng, big_mode):
     l2 = float(rng.choice([0.0, 1e-4]))
     scale = float(rng.choice([1.0, 1.0, 3.0]))
     force = str(rng.choice(["", "", "force_streamed", "force_general"]))
+    fused = bool(rng.integers(0, 2))  # tied on-chip graphs: the fused kernel instead of the two-CU form of small batches
     for key in ("force_streamed", "force_general"):
         lib.tc_debug_set(key.encode(), 1 if key == force else 0)
+    lib.tc_debug_set(b"no_phase_split", 1 if fused else 0)
     try:
         g = oracle.DenGraph(fst)
         sup = synth.random_supervision(fst, S, T, 2, seed=seed + 1, initial_probs=g.initial_probs())
@@ -50,7 +52,7 @@ def _case(oracle, rng, big_mode):
         out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True)
         kern = io.DenominatorGraph(fst, fst.num_pdfs).stats()["tied"]
     finally:
-        for key in ("force_streamed", "force_general"):
+        for key in ("force_streamed", "force_general", "no_phase_split"):
             lib.tc_debug_set(key.encode(), 0)
     res = out["results"]
     # objf = num - den is a difference of two log-probs of size ~S*T: when the numerator covers the whole
@@ -58,8 +60,9 @@ def _case(oracle, rng, big_mode):
     e_obj = abs(res[0] - ref["objf"]) / max(abs(ref["objf"]), 0.05 * S * T)
     e_der = rel_err(out["deriv"], ref["deriv"], floor=1.0)
     e_x = rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0)
-    desc = "%s H=%d A=%d P=%d S=%d T=%d leaky=%g l2=%g scale=%g %s kernel=%d: objf %.1e deriv %.1e xent %.1e" % (
-        kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, scale, force, kern, e_obj, e_der, e_x)
+    desc = "%s H=%d A=%d P=%d S=%d T=%d leaky=%g l2=%g scale=%g %s%s kernel=%d: objf %.1e deriv %.1e xent %.1e" % (
+        kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, scale, force, " fused" if fused else "", kern,
+        e_obj, e_der, e_x)
     assert e_obj <= REL and e_der <= REL and e_x <= REL and res[2] == ref["weight"], desc
     return desc
 

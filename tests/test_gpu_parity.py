@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from torchain_amd import synth
+from torchain_amd import io, synth
 
 from helpers import hip_chain, hip_den, rel_err
 
@@ -151,9 +151,12 @@ def test_streamed_path_for_graphs_beyond_lds(oracle, kernel_family):
     assert abs(out3["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
 
 
-def test_denominator_alone_and_accumulate(oracle):
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_denominator_alone_and_accumulate(oracle, kernel_family, form):
     """[K] DenominatorComputation used directly (chain-supervision-test.hpp:403-423): log-prob,
     Backward(1.0, &deriv) semantics (adds into deriv), sum(deriv) = S*T."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     fst = synth.random_den_fst(200, 6, 90, seed=11)
     S, T = 5, 19
     g = oracle.DenGraph(fst)
@@ -297,9 +300,81 @@ def test_tied_and_general_kernels_agree(oracle, kernel_family):
     assert rel_err(outs[0], outs[1], floor=1.0) <= REL
 
 
-def test_results_are_bitwise_reproducible():
+def test_two_cu_form_agrees_with_fused_kernel(oracle, kernel_family):
+    """Small batches of tied graphs run forward and backward recursion side by side on two CUs and form gamma in a
+    third pass (den_tied_split.hip).  Same results as the fused kernel -- to rounding: the backward recursion keeps
+    normalisers of its own -- on plain tied graphs, graphs with hub states (secondary rows) and nearly tied graphs
+    (split states), overwrite and accumulate forms, one frame and many."""
+    cases = [(synth.config_den_fst("C2"), 5, 40, 0.1), (synth.config_den_fst("C2"), 2, 1, 1e-5),
+             (synth.skewed_tied_den_fst(600, 6000, 300, seed=5), 3, 25, 0.05),
+             (synth.nearly_tied_den_fst(900, 5, 400, seed=8, fraction=0.2), 4, 33, 0.2),
+             (synth.random_den_fst(5000, 4, 6000, seed=3), 2, 12, 0.1)]
+    for fst, S, T, leaky in cases:
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=21, scale=2.0)
+        ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=leaky, deriv_weight=1.0)
+        outs = {}
+        for form in ("two_cu", "fused"):
+            kernel_family("no_phase_split", 1 if form == "fused" else 0)
+            a = hip_den(fst, y, S, leaky=leaky, deriv_weight=-1.0, l2_scale=1e-3)
+            b = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, accumulate=True, init=0.5, graph=a["graph"])
+            assert a["status"] == 0 and b["status"] == 0
+            assert abs(a["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+            assert rel_err(a["deriv"], -ref["deriv"] - 1e-3 * y) <= REL
+            assert rel_err(b["deriv"] - 0.5, ref["deriv"]) <= REL
+            outs[form] = a
+        assert outs["two_cu"]["logprob"] == outs["fused"]["logprob"]  # the forward recursion is the same code
+        assert np.abs(outs["two_cu"]["deriv"] - outs["fused"]["deriv"]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_hot_call_can_be_captured_in_a_hip_graph(kernel_family, form):
+    """include/torchain_hip.h promises no allocation and no host synchronisation in the hot calls: then a training
+    loop may capture them in a HIP graph (stream capture forbids both) and replay it on new data.  The two-CU form
+    forks to a side stream and joins again inside the call, which capture follows."""
+    import ctypes as C
+    from torchain_amd._lib import check, lib
+    if form == "fused":
+        kernel_family("no_phase_split")
+    fst = synth.config_den_fst("C2")
+    S, T, P = 4, 20, fst.num_pdfs
+    graph = io.DenominatorGraph(fst, P).prepare(torch.device("cuda", 0))
+    y = torch.randn(S * T, P, device="cuda")
+    deriv = torch.zeros_like(y)
+    lp = torch.zeros(1, dtype=torch.float64, device="cuda")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    nbytes = lib.tc_chain_workspace_bytes(graph.ptr, S, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+
+    def call():
+        check(lib.tc_den_forward_backward(
+            graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), 0.1, -1.0, 1e-4, 0,
+            C.c_void_p(deriv.data_ptr()), deriv.stride(0), C.c_void_p(lp.data_ptr()), C.c_void_p(st.data_ptr()),
+            C.c_void_p(ws.data_ptr()), nbytes, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "den")
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call()  # warm-up outside the capture: per-device tables, kernel attributes, side stream
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        call()
+    for seed in (1, 2):
+        y.copy_(torch.randn(S * T, P, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed)))
+        g.replay()
+        torch.cuda.synchronize()
+        got, got_lp = deriv.clone(), float(lp)
+        call()
+        torch.cuda.synchronize()
+        assert int(st) == 0 and float(lp) == got_lp
+        assert torch.equal(deriv, got)
+
+
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_results_are_bitwise_reproducible(kernel_family, form):
     """gamma is accumulated in integer fixed point and every float sum has a fixed order, so two runs on
     the same inputs give identical bits (Kaldi's float atomics do not)."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     fst = synth.config_den_fst("C2")
     S, T = 8, 30
     y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=3)

@@ -47,14 +47,22 @@ def _check(oracle, fst, S, T, scale, leaky, beyond_clamp=False):
     assert abs(out["logprob"] - ref["logprob"]) <= 1e-4 * abs(ref["logprob"])
 
 
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
 @pytest.mark.parametrize("leaky", [1e-5, 0.1])
 @pytest.mark.parametrize("scale", [5.0, 10.0, 20.0])
-def test_tied_kernel_peaky_outputs_t150(oracle, scale, leaky):
-    """CHiME5-like graph (the C2 / C3 graph, tied kernel, roomy layout), T = 150, API-default and config leaky."""
+def test_tied_kernel_peaky_outputs_t150(oracle, kernel_family, scale, leaky, form):
+    """CHiME5-like graph (the C2 / C3 graph, tied kernel, roomy layout), T = 150, API-default and config leaky;
+    as a small batch runs it (forward and backward recursion on two CUs, den_tied_split.hip) and as the fused
+    kernel that batches beyond half the chip take."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     _check(oracle, synth.config_den_fst("C2"), 1, 150, scale, leaky)
 
 
-def test_rows_beyond_the_exp_clamp(oracle):
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_rows_beyond_the_exp_clamp(oracle, kernel_family, form):
+    if form == "fused":
+        kernel_family("no_phase_split")
     _check(oracle, synth.config_den_fst("C2"), 1, 60, 10.0, 1e-5, beyond_clamp=True)
 
 

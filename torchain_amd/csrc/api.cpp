@@ -20,6 +20,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
   float *big_expy, *big_beta, *big_small, *big_y;  // streamed path only
+  float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU form of small batches only (den_tied_split.hip)
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
   float *ab, *gs;
@@ -35,9 +36,12 @@ int hist_states(const tc_den_graph *g) {
 }
 int big_p(const tc_den_graph *g) { return g->big ? g->P : 0; }
 int big_h(const tc_den_graph *g) { return g->big ? (g->tied ? g->work_H : g->H) : 0; }  // tied: work-graph states
+// Batches the tied on-chip kernel may run as two CUs per sequence get room for the second history.  (Whether
+// they do is decided at launch: device size, layout for this T, diagnostic switch.)
+bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq; }
 
 // big_P != 0 selects the streamed path's layout: sequences padded to 64 lanes, [state][sequence] matrices
-Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0) {
+Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, bool split = false) {
   Workspace w;
   const int Sp = (S + 63) & ~63;
   size_t off = 0;
@@ -58,6 +62,9 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0) 
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
   w.big_y = big_P ? (float *)take((size_t)Sp * big_H * sizeof(float)) : nullptr;
+  w.beta_hist = split ? (float *)take((size_t)(T + 1) * S * Hs * sizeof(float)) : nullptr;
+  w.fwd_norm = split ? (float *)take((size_t)S * (T + 2) * sizeof(float)) : nullptr;
+  w.bwd_norm = split ? (float *)take((size_t)S * (T + 1) * sizeof(float)) : nullptr;
   w.total = off;
   return w;
 }
@@ -108,6 +115,9 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->big_beta = w.big_beta;
   p->big_small = w.big_small;
   p->big_y = w.big_y;
+  p->beta_hist = w.beta_hist;
+  p->fwd_norm = w.fwd_norm;
+  p->bwd_norm = w.bwd_norm;
   p->big_Sp = (S + 63) & ~63;
   p->big_sum_pi = g->big_sum_pi;
   p->tied_fs = tied ? d.tied_fs : nullptr;
@@ -172,7 +182,7 @@ extern "C" {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g)).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S)).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -181,7 +191,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g));
+  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -225,7 +235,7 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g));
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), split_room(g, sup->S));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;

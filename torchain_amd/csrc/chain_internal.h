@@ -160,6 +160,12 @@ struct DenParams {
   int big_Sp;           // sequences rounded up to a multiple of 64
   float big_sum_pi;     // sum of the initial probabilities
   long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
+  // Two-CU form for small batches (den_tied_split.hip): the forward recursion writes its per-frame sums, the
+  // backward recursion -- which does not need alpha -- runs at the same time on another CU with normalisers of
+  // its own, and a third pass forms gamma from the two histories.  Null on the fused path.
+  float *beta_hist = nullptr;   // [(T+1)][S][Hs]  B_t (row 0: B'_0), see den_tied_split.hip
+  float *fwd_norm = nullptr;    // [S][T+2]        asum_0 .. asum_T, tot
+  float *bwd_norm = nullptr;    // [S][T+1]        n_0 .. n_{T-1}
 };
 
 }  // namespace tc
@@ -279,6 +285,11 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes);             
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip
+// den_tied_split.hip: the backward recursion alone (to run beside a forward-only launch_den_tied), and the pass
+// that forms gamma / the derivative from the two histories
+int launch_den_tied_backward_only(const DenParams &p, hipStream_t stream);
+int launch_den_tied_combine(const DenParams &p, int accumulate, int num_cus, hipStream_t stream);
+constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most half the chip's CUs
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
@@ -299,7 +310,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

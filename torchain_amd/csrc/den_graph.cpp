@@ -146,7 +146,7 @@ extern "C" {
 
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
-                                               "no_bank_search", "sched_trace"};
+                                               "no_bank_search", "sched_trace", "no_phase_split"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {

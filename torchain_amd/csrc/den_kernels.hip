@@ -433,13 +433,64 @@ static int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipSt
   return TC_OK;
 }
 
+// Per-device side stream and fork / join events of the two-CU form (den_tied_split.hip), made on first use; the
+// hot path then only records and waits.
+struct SplitCtx {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int num_cus = 0;
+};
+
+static int split_ctx(SplitCtx **out) {
+  static std::mutex mu;
+  static std::map<int, SplitCtx> ctx;
+  int device = 0;
+  TC_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mu);
+  SplitCtx &c = ctx[device];
+  if (!c.side) {
+    TC_HIP_CHECK(hipDeviceGetAttribute(&c.num_cus, hipDeviceAttributeMultiprocessorCount, device));
+    TC_HIP_CHECK(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+    TC_HIP_CHECK(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
+    TC_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+  }
+  *out = &c;
+  return TC_OK;
+}
+
+// Tied graph, batch of at most half the CUs, workspace with room for the second history: forward and backward
+// recursion side by side on two CUs per sequence, then the combining pass.
+static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t stream, SplitCtx *c) {
+  TC_HIP_CHECK(hipEventRecord(c->fork, stream));
+  TC_HIP_CHECK(hipStreamWaitEvent(c->side, c->fork, 0));
+  DenParams pf = p;
+  pf.deriv = nullptr;  // forward only
+  int rc = launch_den_tied(pf, 0, stream);
+  if (rc != TC_OK) return rc;
+  rc = launch_den_tied_backward_only(p, c->side);
+  if (rc != TC_OK) return rc;
+  TC_HIP_CHECK(hipEventRecord(c->join, c->side));
+  TC_HIP_CHECK(hipStreamWaitEvent(stream, c->join, 0));
+  return launch_den_tied_combine(p, accumulate, c->num_cus, stream);
+}
+
 // accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
 int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   if (p.big.in_begin) return launch_den_big(p, accumulate, stream);  // graph beyond the on-chip layout
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
-  if (p.tied_fs != nullptr) return launch_den_tied(p, accumulate, stream);  // den_tied_kernel.hip
+  if (p.tied_fs != nullptr) {
+    if (p.deriv && p.beta_hist && p.L.alpha_in_lds && JV == kJvSmall && !debug_flag(kDbgNoPhaseSplit)) {
+      SplitCtx *c = nullptr;
+      const int rc = split_ctx(&c);
+      if (rc != TC_OK) return rc;
+      if (2 * p.S <= c->num_cus) return launch_den_tied_split(p, accumulate, stream, c);
+    }
+    DenParams pq = p;
+    pq.fwd_norm = nullptr;
+    return launch_den_tied(pq, accumulate, stream);  // den_tied_kernel.hip
+  }
 #define TC_DISPATCH(J, V) \
   if (JV == J && PV == V) return launch_jp<J, V>(p, accumulate, lds, stream);
   TC_DISPATCH(kJvSmall, kPvSmall)
