@@ -308,7 +308,9 @@ def test_two_cu_form_agrees_with_fused_kernel(oracle, kernel_family):
     cases = [(synth.config_den_fst("C2"), 5, 40, 0.1), (synth.config_den_fst("C2"), 2, 1, 1e-5),
              (synth.skewed_tied_den_fst(600, 6000, 300, seed=5), 3, 25, 0.05),
              (synth.nearly_tied_den_fst(900, 5, 400, seed=8, fraction=0.2), 4, 33, 0.2),
-             (synth.random_den_fst(5000, 4, 6000, seed=3), 2, 12, 0.1)]
+             (synth.random_den_fst(5000, 4, 6000, seed=3), 2, 12, 0.1),
+             (synth.config_den_fst("C5"), 2, 12, 0.1),                  # the fused kernel's tight layout
+             (synth.random_den_fst(9000, 3, 5000, seed=23), 2, 9, 1e-5)]  # 16 states per thread
     for fst, S, T, leaky in cases:
         y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=21, scale=2.0)
         ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=leaky, deriv_weight=1.0)

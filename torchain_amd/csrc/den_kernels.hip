@@ -481,7 +481,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
   if (p.tied_fs != nullptr) {
-    if (p.deriv && p.beta_hist && p.L.alpha_in_lds && JV == kJvSmall && !debug_flag(kDbgNoPhaseSplit)) {
+    if (p.deriv && p.beta_hist && split_bwd_fits(p.L) && !debug_flag(kDbgNoPhaseSplit)) {
       SplitCtx *c = nullptr;
       const int rc = split_ctx(&c);
       if (rc != TC_OK) return rc;

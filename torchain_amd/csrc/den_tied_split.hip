@@ -43,8 +43,9 @@ __device__ __forceinline__ void block_sum2_a(float &v1, float &v2, uint32_t red,
 }
 
 // ---- the backward recursion alone -------------------------------------------------------------------
-// LDS as in the fused kernel's roomy layout (exp(y) buffers at PB and P2, gather source A0, row sums ACC); the
-// gamma and alpha'_{t+1} regions are not used.
+// LDS: [exp(y) buffer | gather source A0 | row sums ACC | second exp(y) buffer | red] -- the fused kernel's regions
+// without gamma and alpha'_{t+1}, so graphs that get the fused kernel's tight layout fit here with both exp(y)
+// buffers (split_bwd_layout below).
 template <int JV, int PV, int RESB>
 __global__ __launch_bounds__(kThreads) void den_tied_bwd_kernel(const DenParams p) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -239,13 +240,16 @@ __global__ __launch_bounds__(kThreads) void den_tied_combine_kernel(const DenPar
     for (int v = T - 1; v >= u; --v) acc += *reinterpret_cast<lds_d *>(aD + 8u * (uint32_t)v);
     ldsf_st(aC + 4u * (uint32_t)u, (float)exp(acc));
   }
+  // the per-state tables stay in registers for the run when a thread owns 8 states; with 16 they are re-read
+  // (L2) every frame
+  constexpr bool kTablesResident = JV <= 2;
   u4 fs[JV];
   f4 ws[JV], cp[JV];
 #pragma unroll
   for (int j = 0; j < JV; ++j) {
     fs[j] = u4{0u, 0u, 0u, 0u};
     ws[j] = cp[j] = mk4(0.f);
-    if (j < planes) {
+    if (kTablesResident && j < planes) {
       fs[j] = bld4u(r_fs, own16, j * kPlane);
       ws[j] = bld4(r_ws, own16, j * kPlane);
       cp[j] = p.leaky * bld4(r_pi, own16, j * kPlane);
@@ -294,10 +298,13 @@ __global__ __launch_bounds__(kThreads) void den_tied_combine_kernel(const DenPar
           gamma_add_a(kGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
         };
         const f4 b = bt[j] * c_up;
-        one(fs[j].x, ws[j].x, b.x, al[j].x, aup[j].x, cp[j].x);
-        one(fs[j].y, ws[j].y, b.y, al[j].y, aup[j].y, cp[j].y);
-        one(fs[j].z, ws[j].z, b.z, al[j].z, aup[j].z, cp[j].z);
-        one(fs[j].w, ws[j].w, b.w, al[j].w, aup[j].w, cp[j].w);
+        const u4 fsj = kTablesResident ? fs[j] : bld4u(r_fs, own16, j * kPlane);
+        const f4 wsj = kTablesResident ? ws[j] : bld4(r_ws, own16, j * kPlane);
+        const f4 cpj = kTablesResident ? cp[j] : p.leaky * bld4(r_pi, own16, j * kPlane);
+        one(fsj.x, wsj.x, b.x, al[j].x, aup[j].x, cpj.x);
+        one(fsj.y, wsj.y, b.y, al[j].y, aup[j].y, cpj.y);
+        one(fsj.z, wsj.z, b.z, al[j].z, aup[j].z, cpj.z);
+        one(fsj.w, wsj.w, b.w, al[j].w, aup[j].w, cpj.w);
         if (t == 0) part_ab += hsum(al[j] * (bld4(make_rsrc(bhist, 4u * Hs), own16, j * kPlane) * ldsf(aC)));
         aup[j] = al[j];
       }
@@ -352,15 +359,33 @@ int launch_combine_jp(const DenParams &p, int accumulate, int groups, hipStream_
 
 }  // namespace
 
-// (graphs of more than 8192 states never get the roomy layout this form needs: JV = 2 only)
 #define TC_SPLIT_DISPATCH(CALL)                            \
   if (JV == kJvSmall && PV == kPvSmall) return CALL(kJvSmall, kPvSmall); \
   if (JV == kJvSmall && PV == kPvMid) return CALL(kJvSmall, kPvMid);     \
-  if (JV == kJvSmall && PV == kPvLarge) return CALL(kJvSmall, kPvLarge);
+  if (JV == kJvSmall && PV == kPvLarge) return CALL(kJvSmall, kPvLarge); \
+  if (JV == kJvLarge && PV == kPvSmall) return CALL(kJvLarge, kPvSmall); \
+  if (JV == kJvLarge && PV == kPvMid) return CALL(kJvLarge, kPvMid);     \
+  if (JV == kJvLarge && PV == kPvLarge) return CALL(kJvLarge, kPvLarge);
 
-int launch_den_tied_backward_only(const DenParams &p, hipStream_t stream) {
-  const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
-  if (lds > (size_t)kLdsLimitBytes || !p.L.alpha_in_lds) return TC_ERR_UNSUPPORTED;
+// The backward-only kernel's LDS: the fused layout's exp(y), A0 and ACC regions as they are (compile-time bases),
+// then the second exp(y) buffer and the reduction scratch.  Returns the bytes, or 0 if it does not fit.
+size_t split_bwd_layout(DenLayout *L) {
+  L->off_p2 = L->off_acc + L->acc_floats;
+  L->off_red = L->off_p2 + L->Ps;
+  L->off_asum = L->off_red + 4 * kWaves;  // (unused here)
+  const size_t bytes = 4 * (size_t)L->off_asum;
+  return bytes <= (size_t)kLdsLimitBytes ? bytes : 0;
+}
+
+bool split_bwd_fits(const DenLayout &L0) {
+  DenLayout L = L0;
+  return split_bwd_layout(&L) != 0;
+}
+
+int launch_den_tied_backward_only(const DenParams &p0, hipStream_t stream) {
+  DenParams p = p0;
+  const size_t lds = split_bwd_layout(&p.L);
+  if (lds == 0) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
 #define TC_CALL_BWD(J, V) launch_bwd_jp<J, V>(p, lds, stream)
   TC_SPLIT_DISPATCH(TC_CALL_BWD)
