@@ -99,7 +99,10 @@ int tc_supervision_prepare(tc_supervision *supervision, int device, void *stream
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 
-/* Bytes of device scratch the calls below need for this problem size (alpha history etc.). */
+/* Bytes of device scratch the calls below need for this problem size (alpha history etc.; for batches of at most
+ * 128 sequences of graphs on the on-chip tied kernel also a second history of the same size: such batches run the
+ * forward and the backward recursion of a sequence on two CUs at once -- inside the call, forking to a per-device
+ * side stream and joining `stream` again, which HIP-graph capture follows). */
 int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);
 
 /* Replaces my_lib_ComputeChainObjfAndDeriv (src/my_lib.h:33-42, src/my_lib_chain.cpp:104-136), i.e.
@@ -173,12 +176,15 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  * direction 1: sum over out-arcs (h->g) of w*gather[g]*pdf_factor[pdf]  (gather: num_states floats,
  * pdf_factor: num_pdfs floats, out: num_states floats).  Lets the schedule builder be tested without a GPU;
  * nothing on the hot path calls it. */
-/* Diagnostic, host only: process-wide switches read when a graph is BUILT (tc_den_graph_create / _read); they
- * exist so that tests and profiles can put a graph on a kernel family it would not normally take.  Keys:
+/* Diagnostic, host only: process-wide switches; they exist so that tests and profiles can put a graph or a batch on
+ * a kernel family it would not normally take.  Read when a graph is BUILT (tc_den_graph_create / _read):
  *   "force_general"  (1: never use the tied-graph kernel)      "force_streamed" (1: alpha/beta in HBM, as for graphs
  *   "no_split"       (1: do not tied-ify nearly tied graphs)                     beyond the on-chip layouts)
  *   "no_pdf_banks", "no_bank_search" (1: skip those placement passes)   "sched_trace" (1: builder statistics on stderr)
- * Returns TC_ERR_INVALID_ARGUMENT for an unknown key.  Nothing on the hot path reads these. */
+ * Read at launch (one relaxed atomic load):
+ *   "no_phase_split" (1: batches of at most 128 sequences of tied on-chip graphs take the fused kernel instead of
+ *                     running forward and backward recursion on two CUs at once)
+ * Returns TC_ERR_INVALID_ARGUMENT for an unknown key. */
 int tc_debug_set(const char *key, int value);
 /* Diagnostic counters: "pool_device_allocs" = device allocations made so far by the per-device supervision pool
  * (stops growing once the pool is warm: a training step then allocates and frees nothing), "pool_reuses" = slots
