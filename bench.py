@@ -114,7 +114,27 @@ def extras(graph, fst, cfg, S, T, P, dev):
     full = timeit(lambda: compute_chain_objf_and_deriv(graph, hsup, y, res.data, deriv, None, cfg.get("l2", 0.0),
                                                        cfg["leaky"], 0.0))
     x = y.view(T, S, P).permute(1, 2, 0).contiguous()  # (B, C, T)
+
+    # BASELINE.json configs[1] (the reference recipe's batch: 64 sequences, same graph): the denominator alone, as a
+    # small batch runs it (forward and backward recursion on two CUs, den_tied_split.hip) and in the fused kernel
+    def den_ms(S2, fused):
+        import ctypes as C
+        from torchain_amd._lib import check, lib
+        check(lib.tc_debug_set(b"no_phase_split", 1 if fused else 0), "tc_debug_set")
+        y2, d2 = y[:S2 * T], deriv[:S2 * T]
+        nb = lib.tc_chain_workspace_bytes(graph.ptr, S2, T)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        try:
+            return timeit(lambda: check(lib.tc_den_forward_backward(
+                graph.ptr, S2, C.c_void_p(y2.data_ptr()), S2 * T, P, y2.stride(0), cfg["leaky"], -1.0, 0.0, 0,
+                C.c_void_p(d2.data_ptr()), d2.stride(0), None, None, C.c_void_p(ws.data_ptr()), nb, dev.index or 0,
+                C.c_void_p(st)), "den"), n=20, warm=20)
+        finally:
+            lib.tc_debug_set(b"no_phase_split", 0)
+
     out = {"full_objective_ms": full, "objf_per_frame": float(res.data[0] / res.data[2]),
+           "batch64_den_ms": den_ms(64, False), "batch64_den_fused_kernel_ms": den_ms(64, True),
            "to2d_hip_ms": timeit(lambda: to2d_hip(x)), "to2d_torch_ms": timeit(lambda: to2d(x)),
            "from2d_neg_hip_ms": timeit(lambda: from2d_hip(y, (S, P, T), -1.0)),
            "from2d_neg_torch_ms": timeit(lambda: (-y).view(T, S, P).permute(1, 2, 0).contiguous())}

@@ -439,6 +439,7 @@ struct SplitCtx {
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   int num_cus = 0;
+  std::mutex enqueue;  // one caller at a time records / waits on the two events (a wait binds to the latest record)
 };
 
 static int split_ctx(SplitCtx **out) {
@@ -461,6 +462,7 @@ static int split_ctx(SplitCtx **out) {
 // Tied graph, batch of at most half the CUs, workspace with room for the second history: forward and backward
 // recursion side by side on two CUs per sequence, then the combining pass.
 static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t stream, SplitCtx *c) {
+  std::lock_guard<std::mutex> lock(c->enqueue);
   TC_HIP_CHECK(hipEventRecord(c->fork, stream));
   TC_HIP_CHECK(hipStreamWaitEvent(c->side, c->fork, 0));
   DenParams pf = p;
