@@ -120,6 +120,18 @@ int tc_chain_objf_and_deriv(tc_den_graph *graph, tc_supervision *supervision, co
                             float xent_regularize, void *workspace, int64_t workspace_bytes, int device,
                             void *stream);
 
+/* The same computation with the outputs in the form the reference's autograd backward returns them
+ * (torchain/functions.py:106-115: -mmi_grad for the input, -xent_regularize * xent_grad for xent_input):
+ *   grad      = -(w*gamma_num - w*gamma_den - w*l2*y)        xent_grad = -xent_regularize * w*gamma_num
+ * so that the wrapper needs no further pass over the matrices (the reference makes one to scale xent_grad and one
+ * each to negate).  grad is the exact negative of tc_chain_objf_and_deriv's deriv; results_dev3 is unchanged. */
+int tc_chain_objf_and_grad(tc_den_graph *graph, tc_supervision *supervision, const float *nnet_output,
+                           int64_t num_rows, int32_t num_cols, int64_t row_stride, float *results_dev3,
+                           float *nnet_output_grad, int64_t grad_stride, float *xent_output_grad,
+                           int64_t xent_stride, float l2_regularize, float leaky_hmm_coefficient,
+                           float xent_regularize, void *workspace, int64_t workspace_bytes, int device,
+                           void *stream);
+
 /* The benchmarked unit: [K] DenominatorComputation::Forward() + Backward(deriv_weight, deriv)
  * (direct use in the reference: src/chain-supervision-test.hpp:403-414).
  *   logprob_dev   : device double[1], sum over sequences of the denominator log-prob

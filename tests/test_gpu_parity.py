@@ -329,6 +329,41 @@ def test_two_cu_form_agrees_with_fused_kernel(oracle, kernel_family):
 
 
 @pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_gradient_form_is_the_exact_negative(oracle, kernel_family, form):
+    """tc_chain_objf_and_grad writes what the reference's backward returns (functions.py:106-115): -deriv and
+    -xent_regularize * xent_deriv, bit for bit what negating / scaling tc_chain_objf_and_deriv's outputs gives; the
+    three results are unchanged.  Also on the numerical-failure exit (deriv = -w*l2*y, xent_deriv = 0)."""
+    from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv
+    if form == "fused":
+        kernel_family("no_phase_split")
+    fst = synth.random_den_fst(300, 5, 120, seed=17)
+    S, T, xr = 4, 23, 0.1
+    g = oracle.DenGraph(fst)
+    sup = io.Supervision.from_synth(synth.random_supervision(fst, S, T, 2, seed=5, initial_probs=g.initial_probs()))
+    graph = io.DenominatorGraph(fst, fst.num_pdfs)
+    for bad in (False, True):
+        y = torch.from_numpy(synth.random_nnet_output(S, T, fst.num_pdfs, seed=6, scale=2.0)).cuda()
+        if bad:
+            y[5, 7] = float("nan")
+        outs = []
+        for as_grad in (False, True):
+            res = ChainResults()
+            d = torch.full_like(y, 9.0)
+            x = torch.full_like(y, 9.0)
+            compute_chain_objf_and_deriv(graph, sup, y, res.data, d, x, 1e-3, 0.05, xr, as_gradients=as_grad)
+            outs.append((res.data.clone(), d, x))
+        (r0, d0, x0), (r1, d1, x1) = outs
+        assert torch.allclose(r0, r1, rtol=0, atol=0, equal_nan=True)  # (l2_term is NaN on the failure exit, as [K]'s)
+        if bad:
+            assert float(r0[0]) == -10.0 * float(r0[2])
+            keep = ~torch.isnan(y)
+            assert torch.equal(d1[keep], -d0[keep]) and float(x0.abs().max()) == 0.0 and float(x1.abs().max()) == 0.0
+        else:
+            assert torch.equal(d1, -d0)
+            assert torch.equal(x1, torch.tensor(-xr, dtype=torch.float32) * x0)
+
+
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
 def test_hot_call_can_be_captured_in_a_hip_graph(kernel_family, form):
     """include/torchain_hip.h promises no allocation and no host synchronisation in the hot calls: then a training
     loop may capture them in a HIP graph (stream capture forbids both) and replay it on new data.  The two-CU form

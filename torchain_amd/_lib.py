@@ -84,6 +84,8 @@ def _load():
     L.tc_chain_objf_and_deriv.restype = C.c_int
     L.tc_chain_objf_and_deriv.argtypes = [vp, vp, vp, i64, i32, i64, vp, vp, i64, vp, i64, f32, f32, f32, vp, i64,
                                           C.c_int, vp]
+    L.tc_chain_objf_and_grad.restype = C.c_int
+    L.tc_chain_objf_and_grad.argtypes = L.tc_chain_objf_and_deriv.argtypes
     L.tc_den_forward_backward.restype = C.c_int
     L.tc_den_forward_backward.argtypes = [vp, i32, vp, i64, i32, i64, f32, f32, f32, C.c_int, vp, i64, vp, vp, vp,
                                           i64, C.c_int, vp]

@@ -227,11 +227,13 @@ int tc_num_forward_backward(tc_supervision *sup, const float *y, int64_t rows, i
   return supervision_mark_use(sup, device, stream);
 }
 
-int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
-                            int64_t y_stride, float *results_dev3, float *deriv, int64_t deriv_stride, float *xent,
-                            int64_t xent_stride, float l2_regularize, float leaky, float xent_regularize,
-                            void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
-  (void)xent_regularize;  // as in the reference it only decides whether the caller passes xent (my_lib_chain.cpp:127)
+}  // extern "C"
+
+// deriv_scale = 1: the reference's outputs.  deriv_scale = -1: what its backward returns (tc_chain_objf_and_grad).
+static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
+                      int64_t y_stride, float *results_dev3, float *deriv, int64_t deriv_stride, float *xent,
+                      int64_t xent_stride, float l2_regularize, float leaky, float deriv_scale, float xent_scale,
+                      void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
@@ -243,13 +245,16 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
 
   const float wgt = sup->weight;
   DenParams dp;
-  int rc = fill_den_params(g, device, sup->S, y, rows, cols, y_stride, leaky, -wgt, wgt * l2_regularize, deriv,
-                           deriv_stride, w, &dp);
+  // (deriv_scale is +-1: the products below are exact, so the scaled outputs are the exact negatives)
+  int rc = fill_den_params(g, device, sup->S, y, rows, cols, y_stride, leaky, deriv_scale * -wgt,
+                           deriv_scale * (wgt * l2_regularize), deriv, deriv_stride, w, &dp);
   if (rc != TC_OK) return rc;
   NumParams np;
   rc = fill_num_params(sup, device, stream, y, rows, cols, y_stride, deriv, deriv_stride, xent, xent_stride, w.num_lp,
                        &np);
   if (rc != TC_OK) return rc;
+  np.deriv_scale = deriv_scale;
+  np.xent_scale = xent_scale;
 
   if (xent) {
     if (xent_stride == cols)
@@ -268,8 +273,27 @@ int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y
   rc = launch_finalize(w.den_lp, w.num_lp, w.y2, w.ab, w.gs, sup->S, sup->T, wgt, l2_regularize, deriv != nullptr,
                        results_dev3, w.fail, stream);
   if (rc != TC_OK) return rc;
-  return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_stride, y, y_stride, wgt * l2_regularize, rows,
-                             cols, stream);
+  return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_stride, y, y_stride,
+                             deriv_scale * (wgt * l2_regularize), rows, cols, stream);
+}
+
+extern "C" {
+
+int tc_chain_objf_and_deriv(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
+                            int64_t y_stride, float *results_dev3, float *deriv, int64_t deriv_stride, float *xent,
+                            int64_t xent_stride, float l2_regularize, float leaky, float xent_regularize,
+                            void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
+  (void)xent_regularize;  // as in the reference it only decides whether the caller passes xent (my_lib_chain.cpp:127)
+  return chain_objf(g, sup, y, rows, cols, y_stride, results_dev3, deriv, deriv_stride, xent, xent_stride, l2_regularize,
+                    leaky, 1.0f, 1.0f, workspace, workspace_bytes, device, stream_v);
+}
+
+int tc_chain_objf_and_grad(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
+                           int64_t y_stride, float *results_dev3, float *grad, int64_t grad_stride, float *xent_grad,
+                           int64_t xent_stride, float l2_regularize, float leaky, float xent_regularize,
+                           void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
+  return chain_objf(g, sup, y, rows, cols, y_stride, results_dev3, grad, grad_stride, xent_grad, xent_stride,
+                    l2_regularize, leaky, -1.0f, -xent_regularize, workspace, workspace_bytes, device, stream_v);
 }
 
 int tc_xent_objf(const float *xent_output, int64_t rows, int32_t cols, int64_t output_stride, const float *xent_deriv,

@@ -252,6 +252,7 @@ struct NumParams {
   double *seq_logprob;  // [S]
   int S, T, P;
   float weight;
+  float deriv_scale = 1.f, xent_scale = 1.f;  // tc_chain_objf_and_grad: -1 and -xent_regularize (else 1, 1)
   int lds_states, lds_arcs, lds_uniq;
 };
 

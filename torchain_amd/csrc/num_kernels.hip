@@ -121,8 +121,10 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
     const float v = p.weight * sum;
     const int64_t row = (int64_t)p.t.uniq_t[ub + u] * S + q;
     const int pdf = p.t.uniq_pdf[ub + u];
-    if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += v;
-    if (p.xent) p.xent[row * p.xent_stride + pdf] = v;
+    // (scales other than 1 only through tc_chain_objf_and_grad: the reference's backward, -deriv and
+    // -xent_regularize * xent_deriv, formed here instead of in two more passes over the matrices)
+    if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
+    if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
   }
 }
 

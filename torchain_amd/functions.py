@@ -62,9 +62,12 @@ def _ptr(t):
 
 
 def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, nnet_output_deriv,
-                                 xent_output_deriv, l2_regularize, leaky_hmm_coefficient, xent_regularize):
+                                 xent_output_deriv, l2_regularize, leaky_hmm_coefficient, xent_regularize,
+                                 as_gradients=False):
     """The hot call: replaces ``my_lib.my_lib_ComputeChainObjfAndDeriv`` (``src/my_lib.h:33-42``).
-    ``results`` is the CPU float[3] tensor of ``ChainResults`` and is filled on return."""
+    ``results`` is the CPU float[3] tensor of ``ChainResults`` and is filled on return.  ``as_gradients``: the two
+    matrices come back as the reference's backward returns them (``functions.py:106-115``), ``-deriv`` and
+    ``-xent_regularize * xent_deriv`` (``tc_chain_objf_and_grad``)."""
     assert nnet_output.is_cuda, "Only the HIP (ROCm) implementation is available"
     if nnet_output.dim() != 2 or nnet_output.stride(1) != 1 or nnet_output.dtype != torch.float32:
         raise ValueError("nnet_output must be a 2-D float32 tensor with unit column stride")
@@ -84,13 +87,14 @@ def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, n
         for t in (nnet_output_deriv, xent_output_deriv):
             if t is not None and (t.dim() != 2 or t.stride(1) != 1 or t.shape != nnet_output.shape):
                 raise ValueError("derivative tensors must match nnet_output and have unit column stride")
-        rc = lib.tc_chain_objf_and_deriv(
+        entry = lib.tc_chain_objf_and_grad if as_gradients else lib.tc_chain_objf_and_deriv
+        rc = entry(
             den_ptr, sup_ptr, _ptr(nnet_output), rows, cols, nnet_output.stride(0), _ptr(res_dev),
             _ptr(nnet_output_deriv), nnet_output_deriv.stride(0) if nnet_output_deriv is not None else 0,
             _ptr(xent_output_deriv), xent_output_deriv.stride(0) if xent_output_deriv is not None else 0,
             float(l2_regularize), float(leaky_hmm_coefficient), float(xent_regularize), _ptr(ws), ws.numel(),
             device.index, C.c_void_p(stream))
-        check(rc, "tc_chain_objf_and_deriv")
+        check(rc, "tc_chain_objf_and_grad" if as_gradients else "tc_chain_objf_and_deriv")
         results.copy_(res_dev)  # 12-byte D2H, the one host sync of the step (reference: >= 4)
     return results
 
@@ -117,26 +121,27 @@ class _ChainLoss(Function):
     def forward(ctx, input, xent_input, results, den_graph, supervision,
                 l2_regularize, leaky_hmm_coefficient, xent_regularize=0.0, kaldi_way=False):
         assert input.is_cuda, "Only CUDA implementation is available"
+        # The kernels write the two matrices as backward() returns them (-deriv, -xent_regularize * xent_deriv):
+        # the reference scales one and negates both in three more passes over (T*B, C) tensors.
         mmi_grad = torch.empty_like(input, memory_format=torch.contiguous_format)
         use_xent = xent_input is not None and xent_regularize != 0.0
         xent_grad = torch.empty_like(xent_input, memory_format=torch.contiguous_format) if use_xent else None
         compute_chain_objf_and_deriv(den_graph, supervision, input.detach(), results.data, mmi_grad, xent_grad,
-                                     l2_regularize, leaky_hmm_coefficient, xent_regularize)
+                                     l2_regularize, leaky_hmm_coefficient, xent_regularize, as_gradients=True)
         ctx.mmi_grad = mmi_grad
         if use_xent:
-            results.xent_objf = xent_objective(xent_input.detach(), xent_grad)
-            if kaldi_way:
-                ctx.xent_grad = xent_regularize * xent_grad
-            else:
+            # sum(xent_output * xent_deriv) from the scaled matrix: the scale is one factor of every term
+            results.xent_objf = xent_objective(xent_input.detach(), xent_grad) / -float(xent_regularize)
+            if not kaldi_way:  # the reference's second call (functions.py:96-103)
                 compute_chain_objf_and_deriv(den_graph, supervision, xent_input.detach(), results.data, mmi_grad,
-                                             xent_grad, l2_regularize, leaky_hmm_coefficient, xent_regularize)
-                ctx.xent_grad = xent_regularize * xent_grad
+                                             xent_grad, l2_regularize, leaky_hmm_coefficient, xent_regularize,
+                                             as_gradients=True)
+            ctx.xent_grad = xent_grad
         return input.new_tensor([float(results.loss)])
 
     @staticmethod
     def backward(ctx, grad_output):
-        xent_grad = -ctx.xent_grad if hasattr(ctx, "xent_grad") else None
-        return (-ctx.mmi_grad, xent_grad, None, None, None, None, None, None, None)
+        return (ctx.mmi_grad, getattr(ctx, "xent_grad", None), None, None, None, None, None, None, None)
 
 
 def _stream(device):
