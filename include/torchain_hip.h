@@ -196,6 +196,8 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  * Read at launch (one relaxed atomic load):
  *   "no_phase_split" (1: batches of at most 128 sequences of tied on-chip graphs take the fused kernel instead of
  *                     running forward and backward recursion on two CUs at once)
+ *   "no_num_overlap" (1: the numerator always follows the denominator on the caller's stream; by default it runs
+ *                     beside it on a side stream when the denominator leaves CUs idle)
  * Returns TC_ERR_INVALID_ARGUMENT for an unknown key. */
 int tc_debug_set(const char *key, int value);
 /* Diagnostic counters: "pool_device_allocs" = device allocations made so far by the per-device supervision pool

@@ -328,6 +328,27 @@ def test_two_cu_form_agrees_with_fused_kernel(oracle, kernel_family):
         assert np.abs(outs["two_cu"]["deriv"] - outs["fused"]["deriv"]).max() <= 2e-6
 
 
+def test_numerator_beside_the_denominator_changes_nothing(oracle, kernel_family):
+    """Small batches leave CUs idle under the denominator: the numerator's recursion then runs on a side stream and
+    its posteriors are added once the denominator has written the derivative.  Same bits as one after the other."""
+    from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv
+    fst = synth.random_den_fst(700, 5, 300, seed=19)
+    S, T = 6, 31
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 3, seed=5, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=6)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+    outs = []
+    for serial in (0, 1):
+        kernel_family("no_num_overlap", serial)
+        outs.append(hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, xent=True))
+    a, b = outs
+    assert np.array_equal(a["results"], b["results"])
+    assert np.array_equal(a["deriv"], b["deriv"]) and np.array_equal(a["xent_deriv"], b["xent_deriv"])
+    assert abs(a["results"][0] - ref["objf"]) <= REL * abs(ref["objf"])
+    assert rel_err(a["deriv"], ref["deriv"], floor=1.0) <= REL and rel_err(a["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL
+
+
 @pytest.mark.parametrize("form", ["two_cu", "fused"])
 def test_gradient_form_is_the_exact_negative(oracle, kernel_family, form):
     """tc_chain_objf_and_grad writes what the reference's backward returns (functions.py:106-115): -deriv and

@@ -264,10 +264,30 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   }
   // denominator first: it writes every element of deriv (-w*gamma_den - w*l2*y); the numerator then
   // adds its sparse posteriors.  [K] runs the numerator first; the sum is the same.
-  rc = launch_den(dp, stream);
+  // When the denominator leaves CUs idle (small batches) the numerator's recursion runs beside it on a side
+  // stream, leaving its posteriors in the supervision's staging area; the scatter follows the denominator.
+  SideStreams *ss = nullptr;
+  rc = side_streams(&ss);
   if (rc != TC_OK) return rc;
-  rc = launch_num(np, stream);
-  if (rc != TC_OK) return rc;
+  if ((deriv || xent) && den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
+    std::lock_guard<std::recursive_mutex> lock(ss->enqueue);
+    np.staged = 1;
+    TC_HIP_CHECK(hipEventRecord(ss->num_fork, stream));
+    TC_HIP_CHECK(hipStreamWaitEvent(ss->num_side, ss->num_fork, 0));
+    rc = launch_num(np, ss->num_side);
+    if (rc != TC_OK) return rc;
+    TC_HIP_CHECK(hipEventRecord(ss->num_join, ss->num_side));
+    rc = launch_den(dp, stream);
+    if (rc != TC_OK) return rc;
+    TC_HIP_CHECK(hipStreamWaitEvent(stream, ss->num_join, 0));
+    rc = launch_num_scatter(np, stream);
+    if (rc != TC_OK) return rc;
+  } else {
+    rc = launch_den(dp, stream);
+    if (rc != TC_OK) return rc;
+    rc = launch_num(np, stream);
+    if (rc != TC_OK) return rc;
+  }
   rc = supervision_mark_use(sup, device, stream);
   if (rc != TC_OK) return rc;
   rc = launch_finalize(w.den_lp, w.num_lp, w.y2, w.ab, w.gs, sup->S, sup->T, wgt, l2_regularize, deriv != nullptr,

@@ -238,6 +238,7 @@ struct NumDev {
   const int32_t *seq_state_off, *seq_arc_off, *seq_uniq_off, *level_begin, *out_begin, *in_begin, *in_arc,
       *arc_src, *arc_dst, *arc_uniq, *uniq_t, *uniq_pdf, *uniq_begin, *uniq_arc;
   const float *arc_logw, *final_logw;
+  float *stage = nullptr;  // [unique (frame, pdf) entries of all sequences]: posteriors in transit (launch_num_scatter)
   PoolSlot *slot = nullptr;
 };
 
@@ -253,6 +254,9 @@ struct NumParams {
   int S, T, P;
   float weight;
   float deriv_scale = 1.f, xent_scale = 1.f;  // tc_chain_objf_and_grad: -1 and -xent_regularize (else 1, 1)
+  // non-zero: the kernel leaves weight * posterior in t.stage instead of adding it to deriv / writing xent, so that
+  // it can run beside the denominator (which writes every element of deriv); launch_num_scatter finishes the job
+  int staged = 0;
   int lds_states, lds_arcs, lds_uniq;
 };
 
@@ -294,6 +298,19 @@ bool split_bwd_fits(const DenLayout &L);  // the backward-only kernel's LDS layo
 constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most half the chip's CUs
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
+int launch_num_scatter(const NumParams &p, hipStream_t stream);
+// Per-device side streams and fork / join events (made on first use; the hot path only records and waits):
+// `den_side` carries the backward recursion of the two-CU form (den_tied_split.hip), `num_side` the numerator when
+// the denominator leaves CUs idle (api.cpp).
+struct SideStreams {
+  hipStream_t den_side = nullptr, num_side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, num_fork = nullptr, num_join = nullptr;
+  int num_cus = 0;
+  std::recursive_mutex enqueue;  // one caller at a time records / waits on the events (a wait binds to the latest record)
+};
+int side_streams(SideStreams **out);  // den_graph.cpp
+// CUs a denominator launch of S sequences occupies (two per sequence in the two-CU form, all for the streamed path)
+int den_cus_used(const DenParams &p, int num_cus);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
                     int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,
                     hipStream_t stream);
@@ -312,7 +329,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -33,6 +33,23 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes) {
   return e;
 }
 
+int side_streams(SideStreams **out) {
+  static std::mutex mu;
+  static std::map<int, SideStreams> ctx;
+  int device = 0;
+  TC_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mu);
+  SideStreams &c = ctx[device];
+  if (!c.den_side) {
+    TC_HIP_CHECK(hipDeviceGetAttribute(&c.num_cus, hipDeviceAttributeMultiprocessorCount, device));
+    for (hipEvent_t *e : {&c.fork, &c.join, &c.num_fork, &c.num_join}) TC_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    TC_HIP_CHECK(hipStreamCreateWithFlags(&c.num_side, hipStreamNonBlocking));
+    TC_HIP_CHECK(hipStreamCreateWithFlags(&c.den_side, hipStreamNonBlocking));
+  }
+  *out = &c;
+  return TC_OK;
+}
+
 static std::atomic<int> g_debug[kDbgCount];
 bool debug_flag(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed) != 0; }
 
@@ -146,7 +163,7 @@ extern "C" {
 
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
-                                               "no_bank_search", "sched_trace", "no_phase_split"};
+                                               "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {

@@ -433,47 +433,30 @@ static int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipSt
   return TC_OK;
 }
 
-// Per-device side stream and fork / join events of the two-CU form (den_tied_split.hip), made on first use; the
-// hot path then only records and waits.
-struct SplitCtx {
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  int num_cus = 0;
-  std::mutex enqueue;  // one caller at a time records / waits on the two events (a wait binds to the latest record)
-};
-
-static int split_ctx(SplitCtx **out) {
-  static std::mutex mu;
-  static std::map<int, SplitCtx> ctx;
-  int device = 0;
-  TC_HIP_CHECK(hipGetDevice(&device));
-  std::lock_guard<std::mutex> lock(mu);
-  SplitCtx &c = ctx[device];
-  if (!c.side) {
-    TC_HIP_CHECK(hipDeviceGetAttribute(&c.num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    TC_HIP_CHECK(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
-    TC_HIP_CHECK(hipEventCreateWithFlags(&c.join, hipEventDisableTiming));
-    TC_HIP_CHECK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
-  }
-  *out = &c;
-  return TC_OK;
-}
-
 // Tied graph, batch of at most half the CUs, workspace with room for the second history: forward and backward
 // recursion side by side on two CUs per sequence, then the combining pass.
-static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t stream, SplitCtx *c) {
-  std::lock_guard<std::mutex> lock(c->enqueue);
+static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t stream, SideStreams *c) {
   TC_HIP_CHECK(hipEventRecord(c->fork, stream));
-  TC_HIP_CHECK(hipStreamWaitEvent(c->side, c->fork, 0));
+  TC_HIP_CHECK(hipStreamWaitEvent(c->den_side, c->fork, 0));
   DenParams pf = p;
   pf.deriv = nullptr;  // forward only
   int rc = launch_den_tied(pf, 0, stream);
   if (rc != TC_OK) return rc;
-  rc = launch_den_tied_backward_only(p, c->side);
+  rc = launch_den_tied_backward_only(p, c->den_side);
   if (rc != TC_OK) return rc;
-  TC_HIP_CHECK(hipEventRecord(c->join, c->side));
+  TC_HIP_CHECK(hipEventRecord(c->join, c->den_side));
   TC_HIP_CHECK(hipStreamWaitEvent(stream, c->join, 0));
   return launch_den_tied_combine(p, accumulate, c->num_cus, stream);
+}
+
+static bool split_wanted(const DenParams &p) {
+  return p.tied_fs && !p.big.in_begin && p.deriv && p.beta_hist && split_bwd_fits(p.L) && !debug_flag(kDbgNoPhaseSplit);
+}
+
+int den_cus_used(const DenParams &p, int num_cus) {
+  if (p.big.in_begin) return num_cus;
+  if (split_wanted(p) && 2 * p.S <= num_cus) return 2 * p.S;
+  return p.S < num_cus ? p.S : num_cus;
 }
 
 // accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
@@ -483,11 +466,14 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
   if (p.tied_fs != nullptr) {
-    if (p.deriv && p.beta_hist && split_bwd_fits(p.L) && !debug_flag(kDbgNoPhaseSplit)) {
-      SplitCtx *c = nullptr;
-      const int rc = split_ctx(&c);
+    if (split_wanted(p)) {
+      SideStreams *c = nullptr;
+      const int rc = side_streams(&c);
       if (rc != TC_OK) return rc;
-      if (2 * p.S <= c->num_cus) return launch_den_tied_split(p, accumulate, stream, c);
+      if (2 * p.S <= c->num_cus) {
+        std::lock_guard<std::recursive_mutex> lock(c->enqueue);
+        return launch_den_tied_split(p, accumulate, stream, c);
+      }
     }
     DenParams pq = p;
     pq.fwd_norm = nullptr;

@@ -121,11 +121,36 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
     const float v = p.weight * sum;
     const int64_t row = (int64_t)p.t.uniq_t[ub + u] * S + q;
     const int pdf = p.t.uniq_pdf[ub + u];
+    if (p.staged) {
+      p.t.stage[ub + u] = v;  // beside the denominator: launch_num_scatter adds it once deriv is written
+      continue;
+    }
     // (scales other than 1 only through tc_chain_objf_and_grad: the reference's backward, -deriv and
     // -xent_regularize * xent_deriv, formed here instead of in two more passes over the matrices)
     if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
     if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
   }
+}
+
+// Second half of a staged numerator: deriv[row, pdf] += weight * posterior, xent_deriv[row, pdf] = it, one owner
+// per (row, pdf) as above.
+__global__ __launch_bounds__(128) void num_scatter_kernel(const NumParams p) {
+  const int q = blockIdx.x, S = p.S;
+  const int ub = p.t.seq_uniq_off[q], nu = p.t.seq_uniq_off[q + 1] - ub;
+  for (int u = threadIdx.x; u < nu; u += 128) {
+    const float v = p.t.stage[ub + u];
+    const int64_t row = (int64_t)p.t.uniq_t[ub + u] * S + q;
+    const int pdf = p.t.uniq_pdf[ub + u];
+    if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
+    if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
+  }
+}
+
+int launch_num_scatter(const NumParams &p, hipStream_t stream) {
+  if (!p.deriv && !p.xent) return TC_OK;
+  hipLaunchKernelGGL(num_scatter_kernel, dim3(p.S), dim3(128), 0, stream, p);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
 }
 
 int launch_num(const NumParams &p, hipStream_t stream) {

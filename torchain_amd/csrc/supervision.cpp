@@ -330,6 +330,10 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
     total += (parts[i].bytes + 255) & ~(size_t)255;
   }
   total += 256;
+  // behind the tables: one float per unique (frame, pdf), where the numerator kernel leaves its posteriors when it
+  // runs beside the denominator (api.cpp); not part of the upload
+  const size_t upload = total, stage_off = total;
+  total += (tb.uniq_t.size() * 4 + 255) & ~(size_t)255;
   // A new supervision arrives with every minibatch: its tables live in a slot of a per-device pool (device
   // blob + PINNED host staging + two events), so that after warm-up a step neither allocates nor frees
   // device memory and the upload is a true asynchronous copy.
@@ -338,7 +342,7 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   if (rc != TC_OK) return rc;
   for (int i = 0; i < nparts; ++i)
     if (parts[i].bytes) memcpy(slot->host + sup->blob_off[i], parts[i].src, parts[i].bytes);
-  hipError_t e = hipMemcpyAsync(slot->blob, slot->host, total, hipMemcpyHostToDevice, stream);
+  hipError_t e = hipMemcpyAsync(slot->blob, slot->host, upload, hipMemcpyHostToDevice, stream);
   if (e == hipSuccess) e = hipEventRecord(slot->ready, stream);
   if (e == hipSuccess) e = hipEventRecord(slot->done, stream);  // (moved forward by every launch that reads the slot)
   if (e != hipSuccess) {
@@ -355,6 +359,7 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   d.arc_uniq = P(9); d.uniq_t = P(10); d.uniq_pdf = P(11); d.uniq_begin = P(12); d.uniq_arc = P(13);
   d.arc_logw = (const float *)P(14);
   d.final_logw = (const float *)P(15);
+  d.stage = (float *)(blob + stage_off);
   sup->dev[device] = d;
   return TC_OK;
 }
