@@ -239,3 +239,21 @@ def test_supervision_with_final_weights_is_accepted_and_perturbation_is_not():
     with pytest.raises(TorchainHipError) as e:
         io.Supervision.from_fst(1.0, 4, 6, 20, sup.arc_begin, sup.ilabel, w, sup.nextstate, sup.final)
     assert e.value.code == -7
+
+
+def test_workspace_has_room_for_the_two_cu_form_and_switches_exist():
+    """Batches of at most 128 sequences of a tied on-chip graph may run forward and backward recursion on two CUs
+    (den_tied_split.hip): their workspace holds a second history.  Larger batches and other kernel families do not
+    pay for it.  The launch-time diagnostic switches are known keys."""
+    fst = synth.random_den_fst(500, 4, 200, seed=1)
+    g = io.DenominatorGraph(fst, fst.num_pdfs)
+    assert g.stats()["tied"] == 1
+    T = 40
+    small, large = lib.tc_chain_workspace_bytes(g.ptr, 64, T), lib.tc_chain_workspace_bytes(g.ptr, 256, T)
+    hist = 4 * (T + 1) * 4096  # bytes of one history per sequence: tied layouts hold whole planes of 4096 positions
+    assert small >= 2 * 64 * hist and small < 2 * 64 * hist + (1 << 20)
+    assert large >= 256 * hist and large < 256 * hist + (1 << 20)
+    assert lib.tc_chain_workspace_bytes(g.ptr, 128, T) > 2 * 128 * hist > lib.tc_chain_workspace_bytes(g.ptr, 129, T)
+    for key in (b"no_phase_split", b"no_num_overlap"):
+        assert lib.tc_debug_set(key, 1) == 0 and lib.tc_debug_set(key, 0) == 0
+    assert lib.tc_debug_set(b"no_such_switch", 1) != 0
