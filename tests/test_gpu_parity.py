@@ -328,6 +328,28 @@ def test_two_cu_form_agrees_with_fused_kernel(oracle, kernel_family):
         assert np.abs(outs["two_cu"]["deriv"] - outs["fused"]["deriv"]).max() <= 2e-6
 
 
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_phone_lm_structured_graphs(oracle, kernel_family, form):
+    """Graphs with the structure of Kaldi's chain den.fst (synth.phone_lm_den_fst: pruned phone LM x one-state
+    chain topology x biphone tree; in-degrees from 1 to hundreds, popular back-off states): a small one, and the
+    13800-state one whose secondary rows only fit the LDS once the home rows are allowed to grow (den_graph.cpp:
+    build_schedules) -- it must stay on the on-chip kernel."""
+    if form == "fused":
+        kernel_family("no_phase_split")
+    for fst, S, T in ((synth.phone_lm_den_fst(num_histories=90, branching=9, num_pdfs=400, seed=3), 4, 30),
+                      (synth.config_den_fst("R2"), 2, 8)):
+        graph = io.DenominatorGraph(fst, fst.num_pdfs)
+        assert graph.stats()["tied"] == 1
+        g = oracle.DenGraph(fst)
+        sup = synth.random_supervision(fst, S, T, 2, seed=4, initial_probs=g.initial_probs())
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=5, scale=2.0)
+        ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+        out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, xent=True, graph=graph)
+        assert abs(out["results"][0] - ref["objf"]) <= REL * max(abs(ref["objf"]), 0.05 * S * T)
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+        assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL
+
+
 def test_numerator_beside_the_denominator_changes_nothing(oracle, kernel_family):
     """Small batches leave CUs idle under the denominator: the numerator's recursion then runs on a side stream and
     its posteriors are added once the denominator has written the derivative.  Same bits as one after the other."""

@@ -83,3 +83,12 @@ def test_nearly_tied_graphs_are_split_not_demoted(kernel_family):
 def test_arbitrary_labelings_are_not_split():
     """Random arc labels are not a chain graph: splitting would multiply the states; general path."""
     check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 0)
+
+
+def test_phone_lm_graph_near_the_state_limit_stays_on_chip():
+    """13800 states with in-degrees up to 132: 888 secondary rows at the default row length would not fit the LDS next
+    to 16384 positions; the builder lets the home rows grow instead of giving the graph to the streamed kernels."""
+    fst = synth.config_den_fst("R2")
+    stats = io.DenominatorGraph(fst, fst.num_pdfs).stats()
+    assert stats["tied"] == 1 and 0 < stats["lds_bytes"] <= 160 * 1024 + 1024  # (lds_bytes is quoted for T = 256)
+    assert stats["fwd_rows"] >= fst.num_states and stats["bwd_rows"] == fst.num_states

@@ -277,7 +277,7 @@ int build_schedules(tc_den_graph *g);                                           
 void build_general(tc_den_graph *g);                                                   // schedule_general.cpp
 bool detect_tied(tc_den_graph *g, std::vector<char> *special);                         // schedule_owner.cpp
 bool make_work_graph(tc_den_graph *g);                                                 // schedule_owner.cpp
-bool build_owner(tc_den_graph *g, const std::vector<char> &special);                   // schedule_owner.cpp
+bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row);      // schedule_owner.cpp
 int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
                  const int32_t *pdf, std::vector<std::vector<int>> *pos_out);          // den_layout.cpp
 inline int round4(int x) { return (x + 3) & ~3; }

@@ -132,10 +132,15 @@ int build_schedules(tc_den_graph *g) {
     g->tied = tied;
   }
   if (!want_big && g->tied) {
-    if (build_owner(g, special)) {
-      g->layout_ok = true;
-      return TC_OK;
-    }
+    // Rows longer than kMaxRowLen spill into secondary rows, each with a private accumulator slot in LDS; a graph
+    // with many popular states (real phone-LM graphs: in-degrees of a hundred and more) and close to the 16384-state
+    // limit may have no room for them, so the home rows are allowed to grow before the graph is given up to the
+    // streamed kernels (8x slower per arc).
+    for (int max_row = kMaxRowLen; max_row <= 8 * kMaxRowLen; max_row *= 2)
+      if (build_owner(g, special, max_row)) {
+        g->layout_ok = true;
+        return TC_OK;
+      }
     want_big = true;  // tied but beyond the on-chip layouts: the streamed kernels keep the tied factorisation
   }
   if (!want_big) {

@@ -22,7 +22,7 @@ namespace tc {
 // both directions.  Everything per-state the kernel touches (pi, tied tables, alpha history) is stored
 // in position order; positions never leave the library.  Row ends are wave-uniform and known in
 // advance: one mask bit per pair of cells, eight pairs per mask word, read through the scalar cache.
-// Arc lists longer than kMaxRowLen keep their first kMaxRowLen arcs at home; the rest become secondary
+// Arc lists longer than max_row (kMaxRowLen, or more when the private slots would not fit) keep their first max_row arcs at home; the rest become secondary
 // rows (k >= K) of whichever waves have room, commit to private slots behind the accumulators and are
 // folded in by the owner after a barrier that only such graphs pay.
 struct OwnerTask {
@@ -126,7 +126,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
 
 // Returns false when the graph cannot use the owner-computes kernel (too many states for the 16-bit
 // offsets or the working set does not fit LDS); the caller then falls back to the general kernel.
-bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
+bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row) {
   const int H = g->work_H;  // states of the work graph (tc_den_graph::work_*)
   const int Npos = 4096 * ((H + 4095) / 4096);
   if (Npos > kMaxIndex) return false;
@@ -156,8 +156,8 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
   // ---- the permutation: sort by primary in-length into a few super-buckets, inside by primary out-length
   std::vector<int32_t> st(H);
   std::iota(st.begin(), st.end(), 0);
-  auto lin = [&](int h) { return std::min(deg(in_first, h), kMaxRowLen); };
-  auto lout = [&](int h) { return std::min(deg(out_first, h), kMaxRowLen); };
+  auto lin = [&](int h) { return std::min(deg(in_first, h), max_row); };
+  auto lout = [&](int h) { return std::min(deg(out_first, h), max_row); };
   std::stable_sort(st.begin(), st.end(), [&](int x, int y) { return lin(x) > lin(y); });
   const int ngroups = Npos / 64;
   const int nbucket = std::max(1, (int)std::lround(std::sqrt((double)std::max(1, (H + 63) / 64))));
@@ -356,9 +356,9 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special) {
           if (h >= 0) {
             const int d = deg(first, h);
             t.begin = first[h];
-            t.len = std::min(d, kMaxRowLen);
-            for (int done = t.len; done < d; done += kMaxRowLen)
-              secondary.push_back(OwnerTask{h, first[h] + done, std::min(kMaxRowLen, d - done)});
+            t.len = std::min(d, max_row);
+            for (int done = t.len; done < d; done += max_row)
+              secondary.push_back(OwnerTask{h, first[h] + done, std::min(max_row, d - done)});
           }
           slots[w][k][l] = t;
           steps = std::max(steps, t.len);

@@ -115,6 +115,60 @@ def skewed_tied_den_fst(num_states, num_arcs, num_pdfs, seed=5, hub_fraction=0.0
     return DenFst(H, src, dst, (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), final, 0, P)
 
 
+def phone_lm_den_fst(num_phones=42, num_histories=600, branching=12, num_pdfs=2928, seed=7, backoff_fraction=0.1):
+    """A den.fst with the STRUCTURE Kaldi's chain recipe produces (the real ones are private): a pruned n-gram phone
+    LM composed with the one-state-per-phone chain topology and a left-biphone tree.
+
+    LM histories h = 0..num_histories-1 each remember their last phone; from h a (Zipf-weighted) subset of
+    ``branching`` phones may follow, each leading to a history that ends in that phone -- or, for a
+    ``backoff_fraction`` of the LM arcs, to a shared low-order history (0..num_phones-1, one per phone), which is what
+    makes a few states very popular.  A graph state is one phone instance (h, p): entered by arcs that carry the
+    forward pdf of p in the context of the previous phone, it loops on its self-loop pdf and leaves to every phone
+    instance (h', p') of the history h' = next(h, p).  So: chain-structured by construction (every arc into a state
+    carries that state's forward pdf), out-degrees ~``branching``, in-degrees from 1 to hundreds, pdfs shared by all
+    instances of a biphone.  States: ~num_histories * branching; arcs: ~states * (branching + 1)."""
+    rng = np.random.default_rng(seed)
+    NP, NH, B, P = int(num_phones), int(num_histories), int(branching), int(num_pdfs)
+    assert NH >= NP and B <= NP
+    last = np.concatenate([np.arange(NP), rng.integers(0, NP, size=NH - NP)])  # last phone of every history
+    by_phone = [np.nonzero(last == p)[0] for p in range(NP)]
+    zipf = 1.0 / np.arange(1, NP + 1) ** 0.8
+    zipf /= zipf.sum()
+    # biphone tree: (left phone, phone) -> forward pdf, self-loop pdf; leaves shared between similar contexts
+    n_leaf = max(2, P // 2)
+    leaf = rng.integers(0, n_leaf, size=(NP, NP))
+    fwd_of = (2 * leaf) % P
+    self_of = (2 * leaf + 1) % P
+    inst = {}        # (h, p) -> state id
+    nxt = []         # per state: history reached after the phone
+    lm_prob = []     # per state: P_LM(p | h)
+    for h in range(NH):
+        phones = rng.choice(NP, size=B, replace=False, p=zipf)
+        pr = rng.dirichlet(np.ones(B) * 0.7)
+        for p, q in zip(phones, pr):
+            inst[(h, int(p))] = len(nxt)
+            cand = by_phone[int(p)]
+            tgt = int(p) if rng.uniform() < backoff_fraction else int(cand[rng.integers(0, len(cand))])
+            nxt.append(tgt)
+            lm_prob.append(float(q))
+    H = len(nxt)
+    members = [[] for _ in range(NH)]  # phone instances of every history
+    for (h, p), g in inst.items():
+        members[h].append((p, g))
+    src, dst, pdf, prob = [], [], [], []
+    for (h, p), g in sorted(inst.items(), key=lambda kv: kv[1]):
+        stay = float(rng.uniform(0.3, 0.7))
+        src.append(g), dst.append(g), pdf.append(int(self_of[last[h], p])), prob.append(stay)
+        for p2, g2 in members[nxt[g]]:
+            src.append(g), dst.append(g2), pdf.append(int(fwd_of[p, p2])), prob.append((1.0 - stay) * lm_prob[g2])
+    src, dst, pdf = np.array(src, np.int32), np.array(dst, np.int32), np.array(pdf, np.int32)
+    prob = np.array(prob)
+    tot = np.zeros(H)
+    np.add.at(tot, src, prob)
+    prob /= tot[src]
+    return DenFst(H, src, dst, (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), np.zeros(H, np.float32), 0, P)
+
+
 def nearly_tied_den_fst(num_states, out_degree, num_pdfs, seed=42, fraction=0.03):
     """A chain-structured graph (``random_den_fst``) in which a few states are entered through arcs of two
     or three different pdfs and a few carry a second self-loop -- what minimisation produces in a real
@@ -262,6 +316,9 @@ CONFIGS = {
     "C5": dict(S=128, T=150, P=10240, H=8192, degree=7.5, leaky=0.1, l2=5e-5),
     # not in BASELINE.json: a den graph of the size Kaldi recipes produce for a few-thousand-leaf tree
     # (robustness / timing of the <JV=4> instantiation only)
+    # phone-LM-structured graphs (phone_lm_den_fst): 42 phones, 2928 pdfs as the CHiME-5 tree of test/test.py:54
+    "R1": dict(S=256, T=150, P=2928, H=None, leaky=0.1, l2=5e-5, phone_lm=dict(num_histories=640, branching=12)),
+    "R2": dict(S=256, T=150, P=2928, H=None, leaky=0.1, l2=5e-5, phone_lm=dict(num_histories=1150, branching=12)),
     "X1": dict(S=256, T=150, P=2928, H=14000, degree=15, leaky=0.1, l2=5e-5),
     # beyond the on-chip layouts: the streamed (sequence-minor) kernels
     "X2": dict(S=256, T=150, P=4096, H=40000, degree=10, leaky=0.1, l2=5e-5),
@@ -272,6 +329,8 @@ def config_den_fst(name):
     c = CONFIGS[name]
     if name == "C1":
         return left_to_right_den_fst(c["P"], seed=42)
+    if "phone_lm" in c:
+        return phone_lm_den_fst(num_pdfs=c["P"], seed=42, **c["phone_lm"])
     if name == "C5":
         # 61440 arcs over 8192 states: half the states have 8 out-arcs, half 7
         fa = random_den_fst(c["H"], 8, c["P"], seed=42)
