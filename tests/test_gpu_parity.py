@@ -337,6 +337,9 @@ def test_phone_lm_structured_graphs(oracle, kernel_family, form):
     if form == "fused":
         kernel_family("no_phase_split")
     for fst, S, T in ((synth.phone_lm_den_fst(num_histories=90, branching=9, num_pdfs=400, seed=3), 4, 30),
+                      # with the LM's empty history: its phone instances are entered through arcs of up to 42 pdfs and
+                      # are split into as many copies (schedule_owner.cpp: make_work_graph)
+                      (synth.phone_lm_den_fst(num_histories=600, branching=8, num_pdfs=900, seed=3, unigram_fraction=0.05), 2, 10),
                       (synth.config_den_fst("R2"), 2, 8)):
         graph = io.DenominatorGraph(fst, fst.num_pdfs)
         assert graph.stats()["tied"] == 1

@@ -115,7 +115,8 @@ def skewed_tied_den_fst(num_states, num_arcs, num_pdfs, seed=5, hub_fraction=0.0
     return DenFst(H, src, dst, (pdf + 1).astype(np.int32), (-np.log(prob)).astype(np.float32), final, 0, P)
 
 
-def phone_lm_den_fst(num_phones=42, num_histories=600, branching=12, num_pdfs=2928, seed=7, backoff_fraction=0.1):
+def phone_lm_den_fst(num_phones=42, num_histories=600, branching=12, num_pdfs=2928, seed=7, backoff_fraction=0.1,
+                     unigram_fraction=0.0):
     """A den.fst with the STRUCTURE Kaldi's chain recipe produces (the real ones are private): a pruned n-gram phone
     LM composed with the one-state-per-phone chain topology and a left-biphone tree.
 
@@ -126,11 +127,16 @@ def phone_lm_den_fst(num_phones=42, num_histories=600, branching=12, num_pdfs=29
     forward pdf of p in the context of the previous phone, it loops on its self-loop pdf and leaves to every phone
     instance (h', p') of the history h' = next(h, p).  So: chain-structured by construction (every arc into a state
     carries that state's forward pdf), out-degrees ~``branching``, in-degrees from 1 to hundreds, pdfs shared by all
-    instances of a biphone.  States: ~num_histories * branching; arcs: ~states * (branching + 1)."""
+    instances of a biphone.  States: ~num_histories * branching; arcs: ~states * (branching + 1).
+
+    ``unigram_fraction`` > 0 adds the LM's empty history: a fraction of the LM arcs of every history lead to it, it
+    remembers no phone, so its phone instances are entered through arcs of as many different forward pdfs as there
+    are left contexts -- the graph is then only NEARLY chain-structured (the library splits such states)."""
     rng = np.random.default_rng(seed)
     NP, NH, B, P = int(num_phones), int(num_histories), int(branching), int(num_pdfs)
     assert NH >= NP and B <= NP
     last = np.concatenate([np.arange(NP), rng.integers(0, NP, size=NH - NP)])  # last phone of every history
+    empty = NH if unigram_fraction > 0 else -1  # index of the empty history (appended below)
     by_phone = [np.nonzero(last == p)[0] for p in range(NP)]
     zipf = 1.0 / np.arange(1, NP + 1) ** 0.8
     zipf /= zipf.sum()
@@ -142,23 +148,31 @@ def phone_lm_den_fst(num_phones=42, num_histories=600, branching=12, num_pdfs=29
     inst = {}        # (h, p) -> state id
     nxt = []         # per state: history reached after the phone
     lm_prob = []     # per state: P_LM(p | h)
-    for h in range(NH):
-        phones = rng.choice(NP, size=B, replace=False, p=zipf)
-        pr = rng.dirichlet(np.ones(B) * 0.7)
+    for h in range(NH + (1 if empty >= 0 else 0)):
+        nb = NP if h == empty else B  # the empty history allows every phone
+        phones = rng.choice(NP, size=nb, replace=False, p=zipf)
+        pr = rng.dirichlet(np.ones(nb) * 0.7)
         for p, q in zip(phones, pr):
             inst[(h, int(p))] = len(nxt)
             cand = by_phone[int(p)]
-            tgt = int(p) if rng.uniform() < backoff_fraction else int(cand[rng.integers(0, len(cand))])
+            u = rng.uniform()
+            if empty >= 0 and u < unigram_fraction:
+                tgt = empty
+            elif u < unigram_fraction + backoff_fraction:
+                tgt = int(p)
+            else:
+                tgt = int(cand[rng.integers(0, len(cand))])
             nxt.append(tgt)
             lm_prob.append(float(q))
     H = len(nxt)
-    members = [[] for _ in range(NH)]  # phone instances of every history
+    members = [[] for _ in range(NH + (1 if empty >= 0 else 0))]  # phone instances of every history
     for (h, p), g in inst.items():
         members[h].append((p, g))
     src, dst, pdf, prob = [], [], [], []
     for (h, p), g in sorted(inst.items(), key=lambda kv: kv[1]):
         stay = float(rng.uniform(0.3, 0.7))
-        src.append(g), dst.append(g), pdf.append(int(self_of[last[h], p])), prob.append(stay)
+        left = p if h == empty else int(last[h])  # (the empty history has no left context of its own)
+        src.append(g), dst.append(g), pdf.append(int(self_of[left, p])), prob.append(stay)
         for p2, g2 in members[nxt[g]]:
             src.append(g), dst.append(g2), pdf.append(int(fwd_of[p, p2])), prob.append((1.0 - stay) * lm_prob[g2])
     src, dst, pdf = np.array(src, np.int32), np.array(dst, np.int32), np.array(pdf, np.int32)
