@@ -24,8 +24,10 @@ nbytes = lib.tc_chain_workspace_bytes(graph.ptr, S, T)
 ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
 stream = torch.cuda.current_stream()
 a256 = lambda x: (x + 255) & ~255
-Hs = 4096 * ((H + 4095) // 4096)  # tied layout: whole planes of positions
-off = a256((T + 1) * S * Hs * 4) + 3 * a256(S * 8) + 2 * a256(S * 4) + 256
+# the stamp area is the 4 KB "scalar" block of the workspace (api.cpp: carve): the last block for batches
+# beyond 128 sequences of on-chip graphs
+assert S > 128, "batches of at most 128 sequences carry the second history behind the stamp area"
+off = nbytes - 4096
 names = ["tail", "barrier1", "walk", "barrier2", "pass1+reduce"]
 for _ in range(2):
     rc = lib.tc_den_forward_backward(

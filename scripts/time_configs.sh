@@ -1,8 +1,8 @@
 #!/bin/bash
 # Development aid (runs on the GPU box): one line per workload and kernel family -> profiles/rNN_configs.txt
-for c in C2 C3 C5 R1 R2 X1 X2; do echo "== $c"; python scripts/time_den.py $c 2>&1 | grep -v amdgpu.ids; done
+for c in C2 C3 C5 R1 R2 R3 X1 X2; do echo "== $c"; python scripts/time_den.py $c 2>&1 | grep -v amdgpu.ids; done
 echo "== small batches: forward and backward recursion on two CUs (default) vs the fused kernel (no_phase_split)"
-for c in "C2 1" "C2 16" C2 "C2 128" C5 "R1 64" "R2 64" "X1 64" "X1 128"; do
+for c in "C2 1" "C2 16" C2 "C2 128" C5 "R1 64" "R2 64" "R3 64" "X1 64" "X1 128"; do
   echo -n "$c two-CU: "; python scripts/time_den.py $c 2>&1 | tail -1
   echo -n "$c fused:  "; TC_DEBUG=no_phase_split python scripts/time_den.py $c 2>&1 | tail -1
 done

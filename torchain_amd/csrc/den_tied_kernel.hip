@@ -358,17 +358,34 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f;
     const float asum_up = ldsf(aAsum + 4u * (t + 1));
+    // With 16 states per thread the tables of plane j + 1 are requested before plane j is worked on: left at the top
+    // of their own iteration the loads waited behind the LDS atomics of the plane before, one exposed L2 round trip
+    // per plane (17 k cycles per frame for this pass on a 9681-state graph: profiles/r02_phase_stamps_r3.txt).  The
+    // instantiations with resident stream chunks have no registers for that.
+    constexpr bool kAhead = RESB == 0;
+    u4 fs_n = u4{0u, 0u, 0u, 0u};
+    f4 ws_n = mk4(0.f), cp_n = mk4(0.f), aup_n = mk4(0.f);
+    auto request = [&](int j) {
+      fs_n = bld4u(r_fs, own16, j * kPlane);
+      ws_n = bld4(r_ws, own16, j * kPlane);
+      cp_n = bld4(r_pi, own16, j * kPlane);
+      // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
+      if (!ALPHA_LDS) aup_n = bld4(make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs), own16, j * kPlane);
+    };
+    if (kAhead) request(0);
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       b4[j] = mk4(0.f);
       if (j < planes) {
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f4 ws = bld4(r_ws, own16, j * kPlane);
-        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
+        if (!kAhead) request(j);
+        const u4 fs = fs_n;
+        const f4 ws = ws_n;
+        const f4 cp = leaky * cp_n;
+        const f4 aup_g = aup_n;
+        if (kAhead && j + 1 < planes) request(j + 1);
         f4 a = own_rows(vrow, j);
         const f4 al = areg[j];  // alpha'_t of the owned states
-        // alpha'_{t+1}: parked by this thread (roomy layout) or re-read from the history (tight layout)
-        const f4 aup = ALPHA_LDS ? lds4(aAL + own16 + j * kPlane) : bld4(make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs), own16, j * kPlane);
+        const f4 aup = ALPHA_LDS ? lds4(aAL + own16 + j * kPlane) : aup_g;
         // Everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
         //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
         //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so

@@ -119,6 +119,9 @@ __global__ __launch_bounds__(kThreads) void den_tied_bwd_kernel(const DenParams 
       }
   }
   const int store_slot = RESB >= 4 ? wave >> 2 : RESB >= 2 ? wave >> 3 : 0;
+#ifdef TC_PHASE_STAMPS
+  long long wst_unused[3] = {0, 0, 0}, *wst = wst_unused;  // (the walk's sub-stamps: kept by the fused kernel only)
+#endif
   for (int t = T - 1; t >= 0; --t) {
     Chunk6 q0;
     load_chunk(q0, bbase, lane16, RESB);
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_bwd_kernel(const DenParams 
         for (int j = 0; j < JV; ++j)
           if (j < planes) bst4(hist_up, own16 + j * kPlane, bown[j]);
       }
-    });
+    } TC_WALK_PASS);
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {

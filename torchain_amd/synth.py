@@ -333,6 +333,9 @@ CONFIGS = {
     # phone-LM-structured graphs (phone_lm_den_fst): 42 phones, 2928 pdfs as the CHiME-5 tree of test/test.py:54
     "R1": dict(S=256, T=150, P=2928, H=None, leaky=0.1, l2=5e-5, phone_lm=dict(num_histories=640, branching=12)),
     "R2": dict(S=256, T=150, P=2928, H=None, leaky=0.1, l2=5e-5, phone_lm=dict(num_histories=1150, branching=12)),
+    # R1 plus the LM's empty history: 7722 states, split by the library into 9681 chain-structured ones
+    "R3": dict(S=256, T=150, P=2928, H=None, leaky=0.1, l2=5e-5,
+               phone_lm=dict(num_histories=640, branching=12, unigram_fraction=0.03)),
     "X1": dict(S=256, T=150, P=2928, H=14000, degree=15, leaky=0.1, l2=5e-5),
     # beyond the on-chip layouts: the streamed (sequence-minor) kernels
     "X2": dict(S=256, T=150, P=4096, H=40000, degree=10, leaky=0.1, l2=5e-5),
