@@ -11,7 +11,8 @@ from torchain_amd._lib import check, lib  # noqa: E402
 
 for key in os.environ.get("TC_DEBUG", "").split(","):  # e.g. TC_DEBUG=force_general,force_streamed (this script only)
     if key:
-        check(lib.tc_debug_set(key.encode(), 1), "tc_debug_set")
+        name, _, value = key.partition("=")
+        check(lib.tc_debug_set(name.encode(), int(value or 1)), "tc_debug_set")
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cfg = synth.CONFIGS[cfgname]
 S, T, P = cfg["S"], cfg["T"], cfg["P"]
