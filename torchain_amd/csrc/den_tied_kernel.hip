@@ -155,10 +155,9 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       } TC_WALK_PASS);
       __builtin_amdgcn_s_setprio(0);
       TC_STAMP(2)
-      if (p.fwd.nfix) {
-        __syncthreads();  // secondary rows committed (graphs with hub states only)
-        for (int e = ffx0; e < ffx1; ++e) fold_row(p.fwd.fix[e], vrow, aACC, Hs, K);
-      }
+      // graphs with hub states: the secondary rows of a state are walked by lanes of the wave that owns it
+      // (schedule_owner.cpp), and a wave's LDS operations execute in order: no barrier
+      for (int e = ffx0; e < ffx1; ++e) fold_row(p.fwd.fix[e], vrow, aACC, Hs, K);
       TC_STAMP(3)
       f4 v4[JV];
       part = 0.f;
@@ -348,10 +347,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       }
     }
     TC_STAMP(2)
-    if (p.bwd.nfix) {
-      __syncthreads();  // secondary rows committed (graphs with hub states only)
-      for (int e = bfx0; e < bfx1; ++e) fold_row(p.bwd.fix[e], vrow, aACC, Hs, K);
-    }
+    for (int e = bfx0; e < bfx1; ++e) fold_row(p.bwd.fix[e], vrow, aACC, Hs, K);  // (no barrier: as in the forward pass)
     TC_STAMP(3)
     f4 b4[JV];
     uint32_t fpk[JV][2];  // forward-pdf offsets of the owned states, kept for the Y update below

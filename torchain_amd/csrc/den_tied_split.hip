@@ -149,10 +149,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_bwd_kernel(const DenParams 
       const int i0 = 4 * ((int)tid + kThreads * v);
       if (i0 < Ps) lds4_st(pb_next + 4u * i0, exp4(ynext[v]));
     }
-    if (p.bwd.nfix) {
-      __syncthreads();
-      for (int e = bfx0; e < bfx1; ++e) fold_row(p.bwd.fix[e], vrow, aACC, Hs, K);
-    }
+    for (int e = bfx0; e < bfx1; ++e) fold_row(p.bwd.fix[e], vrow, aACC, Hs, K);  // (secondary rows: same wave, no barrier)
     f4 u4v[JV];
     uint32_t fpk[JV][2];
     float part_n = 0.f, part_b = 0.f;

@@ -209,6 +209,16 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
       mo = std::max(mo, lout(h));
     }
     groups[gi] = Group{gi, mi, mo};
+    // its states' arcs beyond max_row become secondary rows of the same wave, 64 to a slot
+    int64_t over_in = 0, over_out = 0;
+    for (int l = 0; l < 64; ++l) {
+      const int h = st[(size_t)gi * 64 + l];
+      if (h < 0) continue;
+      over_in += std::max(0, deg(in_first, h) - max_row);
+      over_out += std::max(0, deg(out_first, h) - max_row);
+    }
+    groups[gi].cin += (int)((over_in + 63) / 64);
+    groups[gi].cout += (int)((over_out + 63) / 64);
   }
   // longest-processing-time deal of the groups to the waves, K per wave, balancing both directions
   std::vector<Group> by_cost(groups);
@@ -344,7 +354,12 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     std::vector<int32_t> opos(A2);
     for (int64_t a = 0; a < A2; ++a) opos[a] = g->pos[other[a]];
     std::vector<std::vector<std::vector<OwnerTask>>> slots(kWaves, std::vector<std::vector<OwnerTask>>(K, std::vector<OwnerTask>(64)));
-    std::vector<OwnerTask> secondary;
+    // Secondary rows stay on the wave that owns their state: its lanes commit them to private slots and the owner
+    // lane reads them back after the WAVE's walk -- LDS operations of one wave execute in order, so the fold needs
+    // no workgroup barrier and a wave that has finished its walk goes on to its per-state pass while others still
+    // walk (dealt to the least-loaded wave instead, every frame of a graph with popular states paid a barrier at
+    // which the fast waves idled for 1-5 k cycles: profiles/r02_phase_stamps_r3.txt).
+    std::vector<std::vector<OwnerTask>> secondary(kWaves);
     std::vector<int64_t> load(kWaves, 0);
     for (int w = 0; w < kWaves; ++w)
       for (int k = 0; k < K; ++k) {
@@ -358,23 +373,25 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
             t.begin = first[h];
             t.len = std::min(d, max_row);
             for (int done = t.len; done < d; done += max_row)
-              secondary.push_back(OwnerTask{h, first[h] + done, std::min(max_row, d - done)});
+              secondary[w].push_back(OwnerTask{h, first[h] + done, std::min(max_row, d - done)});
           }
           slots[w][k][l] = t;
           steps = std::max(steps, t.len);
         }
         load[w] += steps;
       }
-    std::stable_sort(secondary.begin(), secondary.end(), [](const OwnerTask &x, const OwnerTask &y) { return x.len > y.len; });
     std::vector<std::vector<int2>> fix_of_thread(kThreads);
     std::vector<int> extra_first(kWaves + 1, 0);
     std::vector<std::vector<std::vector<OwnerTask>>> sec_slots(kWaves);
-    for (size_t b = 0; b < secondary.size(); b += 64) {
-      const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-      std::vector<OwnerTask> tasks(64, OwnerTask{-1, 0, 0});
-      for (size_t i = b; i < std::min(secondary.size(), b + 64); ++i) tasks[i - b] = secondary[i];
-      load[w] += secondary[b].len;
-      sec_slots[w].push_back(tasks);
+    for (int w = 0; w < kWaves; ++w) {
+      std::vector<OwnerTask> &sec = secondary[w];
+      std::stable_sort(sec.begin(), sec.end(), [](const OwnerTask &x, const OwnerTask &y) { return x.len > y.len; });
+      for (size_t b = 0; b < sec.size(); b += 64) {
+        std::vector<OwnerTask> tasks(64, OwnerTask{-1, 0, 0});
+        for (size_t i = b; i < std::min(sec.size(), b + 64); ++i) tasks[i - b] = sec[i];
+        load[w] += sec[b].len;
+        sec_slots[w].push_back(tasks);
+      }
     }
     // private slots: wave w's j-th secondary row, lane l -> accumulator index Npos + 4 + 64 * (extra_first[w] + j) + l
     for (int w = 0; w < kWaves; ++w) extra_first[w + 1] = extra_first[w] + (int)sec_slots[w].size();
