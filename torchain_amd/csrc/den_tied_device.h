@@ -197,8 +197,11 @@ __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc
 // One walk of a wave's stream: RES resident chunks, then the rest through two register buffers in
 // ping-pong (qa arrives preloaded with chunk RES when there is one; the stream is followed by readable
 // padding, so the look-ahead loads need no guard).  The mask words come through the scalar cache.
-// `after_chunk(i)` runs after resident chunk i (once, with i = -1, when nothing is resident): the hook through
-// which the frame's global STORES are spread over the walk (see the kernel).
+// `after_chunk(i)` runs after resident chunk i; when nothing is resident, with i = -1 - n after the n-th pair of
+// streamed chunks and finally with kWalkEnd: the hook through which the frame's global STORES are spread over the
+// walk (see the kernels).
+constexpr int kWalkEnd = -1000;  // last call of a walk's hook when nothing is resident: whatever is still pending
+
 template <uint32_t SRC, int RES, class AfterChunk>
 __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chunk6 &qa, rsrc_t sbase,
                                      uint32_t lane16, int nchunks, const uint32_t *masks, RowCommit rc,
@@ -218,7 +221,6 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
     do_chunk<SRC, 1>(res[2 * i + 1], m, acc, rc);
     after_chunk(2 * i + 1);
   }
-  if (RES == 0) after_chunk(-1);
 #ifdef TC_PHASE_STAMPS
   {
     __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */
@@ -238,6 +240,7 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
     do_chunk<SRC, 0>(qa, m, acc, rc);
     load_chunk(qa, sbase, lane16, c + 2);
     do_chunk<SRC, 1>(qb, m, acc, rc);
+    if (RES == 0) after_chunk(-1 - (c >> 1));
   }
   if (c + 1 < nchunks) {
     const uint32_t m = mk[c >> 1];
@@ -247,6 +250,7 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
   } else if (c < nchunks) {
     do_chunk<SRC, 0>(qa, mk[c >> 1], acc, rc);
   }
+  if (RES == 0) after_chunk(kWalkEnd);
 #ifdef TC_PHASE_STAMPS
   __builtin_amdgcn_s_waitcnt(0xC07F);
   wst[1] += clock64() - wst[2];  // streamed part

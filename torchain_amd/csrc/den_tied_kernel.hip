@@ -143,8 +143,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       // held the frame's tail for ~1.9k cycles (profiles/r02_phase_stamps_before_spread.txt).  Under the walk
       // the store path is idle: the four wave generations issue theirs after resident chunk 0, 1, 2, 3.
       age_prio_on(wave);
+      bool stored = false;  // (nothing resident: the four wave generations store after streamed pair 0, 1, 2, 3)
       walk<kA0, RESF>(fres, q0, fbase, lane16, fnch, fmask, frc, [&](int i) {
-        if (t > 1 && (i < 0 || i == store_slot)) {
+        if (t > 1 && !stored && (RESF > 0 ? i == store_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
+          stored = true;
           const rsrc_t hist_prev = make_rsrc(hist + (int64_t)(t - 1) * hist_step, 4u * Hs);
 #ifndef TC_ABL_NOHIST
 #pragma unroll
@@ -329,8 +331,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     // It waits, thread-private, in the exp(y) buffer that went dead with frame t+1's per-state pass and that
     // this thread overwrites only after its walk.
     age_prio_on(wave);
+    bool dstored = false;
     walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
-      if (kDeferDeriv && t < T - 1 && (i < 0 || i == bstore_slot)) {
+      if (kDeferDeriv && t < T - 1 && !dstored && (RESB > 0 ? i == bstore_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
+        dstored = true;
         const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)(t + 1) * S + s) * p.deriv_stride, row_bytes);
 #pragma unroll
         for (int v = 0; v < PV; ++v)

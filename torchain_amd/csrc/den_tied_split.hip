@@ -135,8 +135,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_bwd_kernel(const DenParams 
     age_prio_on(wave);
     // (the history row of B_{t+1}, still in this thread's registers, leaves under the walk like the forward
     // phase's alpha' rows do: a CU takes a 1 KB store only every ~60 cycles)
+    bool stored = false;
     walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
-      if (t < T - 1 && (i < 0 || i == store_slot)) {
+      if (t < T - 1 && !stored && (RESB > 0 ? i == store_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
+        stored = true;
         const rsrc_t hist_up = make_rsrc(bhist + (int64_t)(t + 1) * hist_step, 4u * Hs);
 #pragma unroll
         for (int j = 0; j < JV; ++j)
