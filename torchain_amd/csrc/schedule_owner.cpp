@@ -22,9 +22,10 @@ namespace tc {
 // both directions.  Everything per-state the kernel touches (pi, tied tables, alpha history) is stored
 // in position order; positions never leave the library.  Row ends are wave-uniform and known in
 // advance: one mask bit per pair of cells, eight pairs per mask word, read through the scalar cache.
-// Arc lists longer than max_row (kMaxRowLen, or more when the private slots would not fit) keep their first max_row arcs at home; the rest become secondary
-// rows (k >= K) of whichever waves have room, commit to private slots behind the accumulators and are
-// folded in by the owner after a barrier that only such graphs pay.
+// Arc lists longer than max_row (kMaxRowLen, or more when the private slots would not fit) keep their first max_row
+// arcs at home; the rest become secondary rows (k >= K) of the SAME wave, commit to private slots behind the
+// accumulators and are folded in by the owner lane after the wave's walk -- no barrier: one wave's LDS operations
+// execute in order.
 struct OwnerTask {
   int32_t state;   // original state id (or -1: empty)
   int64_t begin;   // range into the direction's arc order

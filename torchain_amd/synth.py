@@ -84,7 +84,7 @@ def skewed_tied_den_fst(num_states, num_arcs, num_pdfs, seed=5, hub_fraction=0.0
     """Chain-structured ("tied") graph with heavily skewed degrees: every non-self-loop arc carries the
     forward pdf of its destination, most states have one self-loop with their own self-loop pdf, a few
     hub states have hundreds of in- and out-arcs (longer than one schedule row), some states are
-    non-final.  Exercises the secondary rows and the fold barrier of the owner-computes schedules."""
+    non-final.  Exercises the secondary rows (and their fold) of the owner-computes schedules."""
     rng = np.random.default_rng(seed)
     H, A, P = int(num_states), int(num_arcs), int(num_pdfs)
     hubs = max(1, int(H * hub_fraction))
