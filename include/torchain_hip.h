@@ -112,7 +112,10 @@ int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequence
  *   xent_deriv = w*gamma_num                        (written when non-NULL)
  * and on NaN/inf or a failed alpha.beta check: deriv = xent_deriv = 0, objf = -10*weight.
  * results_dev3 is DEVICE memory for {objf, l2_term, weight} (the reference writes a CPU
- * THFloatTensor, src/my_lib_chain.cpp:126,130; the host wrapper copies the 12 bytes). */
+ * THFloatTensor, src/my_lib_chain.cpp:126,130; the host wrapper copies the 12 bytes).
+ * Stream capture: tc_den_forward_backward may be captured in a HIP graph (tested); this call may not -- it orders
+ * itself behind the supervision's upload with an event from outside the capture, and a supervision is new with
+ * every minibatch anyway. */
 int tc_chain_objf_and_deriv(tc_den_graph *graph, tc_supervision *supervision, const float *nnet_output,
                             int64_t num_rows, int32_t num_cols, int64_t row_stride, float *results_dev3,
                             float *nnet_output_deriv, int64_t deriv_stride, float *xent_output_deriv,
