@@ -192,6 +192,10 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            # the banner is written through C stdio, which buffers when stdout is a pipe: without this flush it
+            # would sit in libc's buffer and come out on the restored fd 1 at exit, behind the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     else:
