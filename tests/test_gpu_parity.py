@@ -353,6 +353,23 @@ def test_phone_lm_structured_graphs(oracle, kernel_family, form):
         assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL
 
 
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_long_sequences(oracle, kernel_family, form):
+    """1000 frames per sequence (the per-frame normalisers live in LDS; the two-CU form chains 1000 of them in
+    double): objective and derivatives against the oracle."""
+    if form == "fused":
+        kernel_family("no_phase_split")
+    fst = synth.random_den_fst(300, 5, 120, seed=29)
+    S, T = 2, 1000
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 2, seed=2, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=3, scale=2.0)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.05, want_xent=False)
+    out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.05)
+    assert abs(out["results"][0] - ref["objf"]) <= REL * abs(ref["objf"])
+    assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+
+
 def test_numerator_beside_the_denominator_changes_nothing(oracle, kernel_family):
     """Small batches leave CUs idle under the denominator: the numerator's recursion then runs on a side stream and
     its posteriors are added once the denominator has written the derivative.  Same bits as one after the other."""

@@ -294,7 +294,7 @@ int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  //
 // that forms gamma / the derivative from the two histories
 int launch_den_tied_backward_only(const DenParams &p, hipStream_t stream);
 int launch_den_tied_combine(const DenParams &p, int accumulate, int num_cus, hipStream_t stream);
-bool split_bwd_fits(const DenLayout &L);  // the backward-only kernel's LDS layout fits one CU
+bool split_bwd_fits(const DenLayout &L, int T);  // the backward-only kernel's and the combining pass's LDS fit one CU
 constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most half the chip's CUs
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);

@@ -450,7 +450,7 @@ static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t
 }
 
 static bool split_wanted(const DenParams &p) {
-  return p.tied_fs && !p.big.in_begin && p.deriv && p.beta_hist && split_bwd_fits(p.L) && !debug_flag(kDbgNoPhaseSplit);
+  return p.tied_fs && !p.big.in_begin && p.deriv && p.beta_hist && split_bwd_fits(p.L, p.T) && !debug_flag(kDbgNoPhaseSplit);
 }
 
 int den_cus_used(const DenParams &p, int num_cus) {

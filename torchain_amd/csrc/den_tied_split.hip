@@ -348,10 +348,15 @@ int launch_bwd_jp(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
   return TC_OK;
 }
 
+// LDS of the combining pass: exp(y_t), gamma_t, c_0..c_T (float), the log ratios (double), reduction scratch
+size_t combine_lds_bytes(int PV, int Ps, int T) {
+  return (size_t)PV * 16 * kThreads + 4 * (size_t)((Ps + 3) & ~3) + 4 * (size_t)(T + 2) + 8 + 8 * (size_t)(T + 1) +
+         4 * 3 * kWaves + 64;
+}
+
 template <int JV, int PV>
 int launch_combine_jp(const DenParams &p, int accumulate, int groups, hipStream_t stream) {
-  const size_t lds = (size_t)PV * 16 * kThreads + 4 * (size_t)((p.L.Ps + 3) & ~3) + 4 * (size_t)(p.T + 2) + 8 +
-                     8 * (size_t)(p.T + 1) + 4 * 3 * kWaves + 64;
+  const size_t lds = combine_lds_bytes(PV, p.L.Ps, p.T);
   void (*k)(const DenParams, int) = accumulate ? den_tied_combine_kernel<JV, PV, true> : den_tied_combine_kernel<JV, PV, false>;
   TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds));
   hipLaunchKernelGGL(k, dim3(p.S, groups), dim3(kThreads), lds, stream, p, groups);
@@ -379,9 +384,10 @@ size_t split_bwd_layout(DenLayout *L) {
   return bytes <= (size_t)kLdsLimitBytes ? bytes : 0;
 }
 
-bool split_bwd_fits(const DenLayout &L0) {
+bool split_bwd_fits(const DenLayout &L0, int T) {
   DenLayout L = L0;
-  return split_bwd_layout(&L) != 0;
+  // (the combining pass keeps 12 bytes per frame in LDS: only sequences of many thousand frames fail this)
+  return split_bwd_layout(&L) != 0 && combine_lds_bytes(L.PV, L.Ps, T) <= (size_t)kLdsLimitBytes;
 }
 
 int launch_den_tied_backward_only(const DenParams &p0, hipStream_t stream) {
