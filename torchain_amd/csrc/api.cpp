@@ -20,6 +20,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
   float *big_expy, *big_beta, *big_small, *big_y;  // streamed path only
+  int big_exp_frames = 1;
   float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU form of small batches only (den_tied_split.hip)
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
@@ -58,7 +59,10 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.gs = (float *)take((size_t)S * 4);
   w.fail = (int32_t *)take(256);
   w.scalar = (double *)take(4096);  // also the stamp area of diagnostic builds
-  w.big_expy = big_P ? (float *)take((size_t)Sp * big_P * sizeof(float)) : nullptr;
+  // streamed path: exp(y) of every frame, transposed once and used by both passes, when that is at most 4 GB
+  // (else one frame at a time, recomputed by the backward pass)
+  w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)4 << 30) ? T : 1;
+  w.big_expy = big_P ? (float *)take((size_t)w.big_exp_frames * Sp * big_P * sizeof(float)) : nullptr;
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
   w.big_y = big_P ? (float *)take((size_t)Sp * big_H * sizeof(float)) : nullptr;
@@ -112,6 +116,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   }
   p->big = d.big;
   p->big_expy = w.big_expy;
+  p->big_exp_stride = w.big_exp_frames > 1 ? (int64_t)((S + 63) & ~63) * g->P : 0;
   p->big_beta = w.big_beta;
   p->big_small = w.big_small;
   p->big_y = w.big_y;

@@ -153,7 +153,8 @@ struct DenParams {
   const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
   const float *tied_w;
   BigDev big;           // streamed path only
-  float *big_expy;      // [P][Sp]  exp(y_t) of the current frame, transposed
+  float *big_expy;      // [P][Sp]  exp(y_t) of the current frame, transposed; or [T][P][Sp], every frame (big_exp_stride)
+  int64_t big_exp_stride = 0;  // floats between consecutive frames of big_expy (0: one frame at a time)
   float *big_beta;      // [2][H][Sp]
   float *big_y;         // [H][Sp]  tied graphs: Y = beta_{t+1} * p_t(f), the backward gather source
   float *big_small;     // per-sequence sums and per-block partials (den_big_kernel.hip: BigSmall)

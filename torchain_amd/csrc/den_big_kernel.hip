@@ -109,6 +109,46 @@ __global__ __launch_bounds__(kBT) void big_exp_kernel(const DenParams p, int t) 
   }
 }
 
+// The same for ALL frames in one launch (when the workspace has room for T transposed frames: api.cpp): one block
+// per (pdf tile, sequence group) loops over the frames, so sum(y^2) is accumulated in the same order as by the
+// per-frame launches, and the forward and the backward pass share the result -- 2 T launches and T redundant
+// exp-transposes fewer.
+__global__ __launch_bounds__(kBT) void big_exp_all_kernel(const DenParams p) {
+  __shared__ float tile[64][65];
+  __shared__ float sq[64][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int p0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
+  float y2 = 0.f;
+  for (int t = 0; t < p.T; ++t) {
+    float yv[16];
+    const int pdf = p0 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int s = s0 + wave + 4 * i;
+      yv[i] = (s < p.S && pdf < p.P) ? p.y[((int64_t)t * p.S + s) * p.y_stride + pdf] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int sl = wave + 4 * i;
+      tile[sl][lane] = big_exp(yv[i]);
+      sq[sl][lane] = yv[i] * yv[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float acc = 0.f;
+      for (int i = 0; i < 64; ++i) acc += sq[lane][i];
+      y2 = y2 + acc;  // (the per-frame kernels add frame by frame in this order)
+    }
+    float *const out = p.big_expy + p.big_exp_stride * t;
+    for (int pl = wave; pl < 64; pl += 4) {
+      const int pd = p0 + pl;
+      if (pd < p.P) out[(int64_t)pd * p.big_Sp + s0 + lane] = tile[lane][pl];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) big_small(p).part_y2[(int64_t)blockIdx.x * p.big_Sp + s0 + lane] = y2;
+}
+
 // alpha_0 = pi for every sequence; asum_0 = sum(pi)   ([K] AlphaFirstFrame)
 __global__ __launch_bounds__(kBT) void big_alpha0_kernel(const DenParams p) {
   const int64_t n = (int64_t)p.H * p.big_Sp;
@@ -173,7 +213,7 @@ __global__ __launch_bounds__(kBT) void big_fwd_kernel(const DenParams p, int t) 
   const BigSmall sm = big_small(p);
   const float *prev = p.alpha_hist + (int64_t)(t - 1) * p.H * Sp + s;
   float *cur = p.alpha_hist + (int64_t)t * p.H * Sp + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t - 1) + s;  // (all frames resident: big_exp_all_kernel)
   const float asum_prev = sm.asum[(int64_t)(t - 1) * Sp + s];
   const float inv = 1.0f / asum_prev, cl_as = p.leaky * asum_prev;
   float part = 0.f;
@@ -246,7 +286,7 @@ __global__ __launch_bounds__(kBT) void big_bwd_kernel(const DenParams p, int t) 
   const BigSmall sm = big_small(p);
   const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
   float *Bcur = p.big_beta + (int64_t)(t & 1) * p.H * Sp + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t) + s;  // (all frames resident: big_exp_all_kernel)
   const float asum_t = sm.asum[(int64_t)t * Sp + s];
   const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s];
   const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
@@ -286,7 +326,7 @@ __global__ __launch_bounds__(kRT) void big_gamma_kernel(const DenParams p, int t
   const BigSmall sm = big_small(p);
   const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
   const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t) + s;  // (all frames resident: big_exp_all_kernel)
   const float asum_t = sm.asum[(int64_t)t * Sp + s];
   const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s], cl_as = p.leaky * asum_t;
   const int p0 = blockIdx.x * kPdfsPerBlock;
@@ -342,7 +382,7 @@ __global__ __launch_bounds__(kBT) void big_fwd_tied_kernel(const DenParams p, in
   const BigSmall sm = big_small(p);
   const float *prev = p.alpha_hist + (int64_t)(t - 1) * p.H * Sp + s;
   float *cur = p.alpha_hist + (int64_t)t * p.H * Sp + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t - 1) + s;  // (all frames resident: big_exp_all_kernel)
   const float asum_prev = sm.asum[(int64_t)(t - 1) * Sp + s];
   const float inv = 1.0f / asum_prev, cl_as = p.leaky * asum_prev;
   float part = 0.f;
@@ -382,7 +422,7 @@ __global__ __launch_bounds__(kBT) void big_y_kernel(const DenParams p, int t) {
   const int Sp = p.big_Sp, s = blockIdx.y * 64 + lane;
   const BigSmall sm = big_small(p);
   const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t) + s;  // (all frames resident: big_exp_all_kernel)
   const float bs = sm.bsum[((t + 1) & 1) * Sp + s];
   const int h0 = blockIdx.x * kStatesPerBlock + wave * (kStatesPerBlock / 4);
   for (int k = 0; k < kStatesPerBlock / 4; ++k) {
@@ -400,7 +440,7 @@ __global__ __launch_bounds__(kBT) void big_bwd_tied_kernel(const DenParams p, in
   const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
   float *Bcur = p.big_beta + (int64_t)(t & 1) * p.H * Sp + s;
   const float *Y = p.big_y + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t) + s;  // (all frames resident: big_exp_all_kernel)
   const float asum_t = sm.asum[(int64_t)t * Sp + s];
   const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s];
   const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
@@ -448,7 +488,7 @@ __global__ __launch_bounds__(kRT) void big_gamma_tied_kernel(const DenParams p, 
   const float *alpha = p.alpha_hist + (int64_t)t * p.H * Sp + s;
   const float *alpha_up = p.alpha_hist + (int64_t)(t + 1) * p.H * Sp + s;  // un-dashed alpha_{t+1}
   const float *Bprev = p.big_beta + (int64_t)((t + 1) & 1) * p.H * Sp + s;
-  const float *E = p.big_expy + s;
+  const float *E = p.big_expy + p.big_exp_stride * (t) + s;  // (all frames resident: big_exp_all_kernel)
   const float asum_t = sm.asum[(int64_t)t * Sp + s];
   const float inv_as = 1.0f / asum_t, bs = sm.bsum[((t + 1) & 1) * Sp + s], cl_as = p.leaky * asum_t;
   const int p0 = blockIdx.x * kPdfsPerBlock;
@@ -540,8 +580,10 @@ int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream) {
   const int fill_blocks = (int)std::min<int64_t>(4096, ((int64_t)p.H * Sp + kBT - 1) / kBT);
   hipLaunchKernelGGL(big_alpha0_kernel, dim3(fill_blocks), blk, 0, stream, p);
   const bool tied = p.big.tied != 0;
+  const bool exp_all = p.big_exp_stride != 0;
+  if (exp_all) hipLaunchKernelGGL(big_exp_all_kernel, g_exp, blk, 0, stream, p);
   for (int t = 1; t <= p.T; ++t) {
-    hipLaunchKernelGGL(big_exp_kernel<true>, g_exp, blk, 0, stream, p, t - 1);
+    if (!exp_all) hipLaunchKernelGGL(big_exp_kernel<true>, g_exp, blk, 0, stream, p, t - 1);
     if (tied)
       hipLaunchKernelGGL(big_fwd_tied_kernel, g_states, blk, 0, stream, p, t);
     else
@@ -552,7 +594,7 @@ int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream) {
   if (p.deriv) {
     hipLaunchKernelGGL(big_beta_init_kernel, dim3(fill_blocks), blk, 0, stream, p);
     for (int t = p.T - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(big_exp_kernel<false>, g_exp, blk, 0, stream, p, t);
+      if (!exp_all) hipLaunchKernelGGL(big_exp_kernel<false>, g_exp, blk, 0, stream, p, t);
       if (tied) {
         hipLaunchKernelGGL(big_y_kernel, g_states, blk, 0, stream, p, t);
         hipLaunchKernelGGL(big_bwd_tied_kernel, g_states, blk, 0, stream, p, t);
