@@ -483,7 +483,7 @@ bool detect_tied(tc_den_graph *g, std::vector<char> *special) {
 // exact: the copies share g's out-arcs (and its special self-loop), so their futures are identical,
 // beta(copy) = beta(g), alpha(g) = sum of the copies' alphas, and pi(g) may sit on any one of them.
 // Every arc h -> g is replicated from every copy of h.  Returns false (graph left untouched) when the
-// split graph would be more than 1.5x the states or 2x the arcs: arbitrary labelings are not chain graphs.
+// split graph would not pay (cost model below): arbitrary labelings are not chain graphs.
 bool make_work_graph(tc_den_graph *g) {
   const int H = g->H;
   const int64_t A = g->A;
@@ -512,7 +512,13 @@ bool make_work_graph(tc_den_graph *g) {
   for (int h = 0; h < H; ++h) first[h + 1] = first[h] + std::max<int>(1, (int)cls[h].size());
   const int WH = first[H];
   if (WH == H) return false;  // nothing to split: the graph failed the tied test for another reason
-  if (WH > H + H / 2 + 64) return false;
+  // Worth it?  Every arc is replicated from every copy of its source, and beyond 8192 states the tied kernel runs
+  // with 16 states per thread; the general kernel pays two gathers and an atomic per arc instead.  Measured on
+  // nearly tied graphs of 3000 / 6000 states with 60-90 % of the states entered through 2-3 pdfs (one MI355X,
+  // 256 x 150, tied vs general): 1.77 vs 2.04 ms at 1.9x the states, 1.54 vs 2.04 at 2.3x; across the 8192-state
+  // step 2.63 vs 3.26 at 1.9x but 3.56 vs 3.24 at 2.3x.
+  if (WH > kMaxIndex) return false;
+  if (WH <= 8192 ? WH > (int64_t)H * 5 / 2 + 64 : WH > 2 * (int64_t)H + 64) return false;
   std::vector<int32_t> ws, wd, wp;
   std::vector<float> ww;
   for (int64_t a = 0; a < A; ++a) {
@@ -534,7 +540,7 @@ bool make_work_graph(tc_den_graph *g) {
       wp.push_back(p);
       ww.push_back(g->arc_prob[a]);
     }
-    if ((int64_t)ws.size() > 2 * A + 1024) return false;
+    if ((int64_t)ws.size() > 4 * A + 1024) return false;
   }
   g->work_H = WH;
   g->work_src.swap(ws);
