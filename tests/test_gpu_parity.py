@@ -370,6 +370,26 @@ def test_long_sequences(oracle, kernel_family, form):
     assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
 
 
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_heavily_split_graphs(oracle, kernel_family, form):
+    """Graphs in which most states are entered through two or three pdfs are still run on the tied kernel, with up to
+    2.5x the states after splitting (schedule_owner.cpp: make_work_graph); beyond that they take the general kernel."""
+    if form == "fused":
+        kernel_family("no_phase_split")
+    for frac, want_tied in ((0.6, 1), (0.9, 1)):
+        fst = synth.nearly_tied_den_fst(1200, 6, 500, seed=31, fraction=frac)
+        graph = io.DenominatorGraph(fst, fst.num_pdfs)
+        assert graph.stats()["tied"] == want_tied and graph.stats()["bwd_rows"] > 1.5 * fst.num_states
+        S, T = 3, 25
+        g = oracle.DenGraph(fst)
+        sup = synth.random_supervision(fst, S, T, 2, seed=4, initial_probs=g.initial_probs())
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=5, scale=2.0)
+        ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=False)
+        out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, graph=graph)
+        assert abs(out["results"][0] - ref["objf"]) <= REL * max(abs(ref["objf"]), 0.05 * S * T)
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+
+
 def test_numerator_beside_the_denominator_changes_nothing(oracle, kernel_family):
     """Small batches leave CUs idle under the denominator: the numerator's recursion then runs on a side stream and
     its posteriors are added once the denominator has written the derivative.  Same bits as one after the other."""
