@@ -22,6 +22,8 @@ struct Workspace {
   float *big_expy, *big_beta, *big_small, *big_y;  // streamed path only
   int big_exp_frames = 1;
   float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU form of small batches only (den_tied_split.hip)
+  float *pair_norm = nullptr;                      // two-sequence form (den_tied_pair.hip)
+  uint32_t *pair_sync = nullptr;
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
   float *ab, *gs;
@@ -40,9 +42,12 @@ int big_h(const tc_den_graph *g) { return g->big ? (g->tied ? g->work_H : g->H) 
 // Batches the tied on-chip kernel may run as two CUs per sequence get room for the second history.  (Whether
 // they do is decided at launch: device size, layout for this T, diagnostic switch.)
 bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq; }
+// Tied on-chip graphs of at most 8192 positions may run two sequences per workgroup (den_tied_pair.hip): two more
+// history rows, the two roles' normalisers and the pairing words.
+bool pair_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.JV == kJvSmall; }
 
 // big_P != 0 selects the streamed path's layout: sequences padded to 64 lanes, [state][sequence] matrices
-Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, bool split = false) {
+Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, bool split = false, bool pair = false) {
   Workspace w;
   const int Sp = (S + 63) & ~63;
   size_t off = 0;
@@ -51,7 +56,8 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
     off += align256(bytes);
     return p;
   };
-  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + 1) * S * Hs * sizeof(float));
+  // (pair form: row T + 1 holds the backward role's B_M)
+  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair ? 2 : 1)) * S * Hs * sizeof(float));
   w.den_lp = (double *)take((size_t)S * 8);
   w.num_lp = (double *)take((size_t)S * 8);
   w.y2 = (double *)take((size_t)S * 8);
@@ -69,6 +75,8 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.beta_hist = split ? (float *)take((size_t)(T + 1) * S * Hs * sizeof(float)) : nullptr;
   w.fwd_norm = split ? (float *)take((size_t)S * (T + 2) * sizeof(float)) : nullptr;
   w.bwd_norm = split ? (float *)take((size_t)S * (T + 1) * sizeof(float)) : nullptr;
+  w.pair_sync = pair ? (uint32_t *)take(pair_sync_bytes(S)) : nullptr;
+  w.pair_norm = pair ? (float *)take((size_t)2 * S * pair_norm_stride(T) * sizeof(float)) : nullptr;
   w.total = off;
   return w;
 }
@@ -123,6 +131,9 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->beta_hist = w.beta_hist;
   p->fwd_norm = w.fwd_norm;
   p->bwd_norm = w.bwd_norm;
+  p->pair_norm = w.pair_norm;
+  p->pair_sync = w.pair_sync;
+  p->pair_extra_slots = std::max(g->fwd.extra_slots, g->bwd.extra_slots);
   p->big_Sp = (S + 63) & ~63;
   p->big_sum_pi = g->big_sum_pi;
   p->tied_fs = tied ? d.tied_fs : nullptr;
@@ -187,7 +198,7 @@ extern "C" {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S)).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S), pair_room(g)).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -196,7 +207,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S));
+  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S), pair_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -242,7 +253,7 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), split_room(g, sup->S));
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), split_room(g, sup->S), pair_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;

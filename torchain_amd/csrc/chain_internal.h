@@ -88,6 +88,7 @@ struct ScheduleDev {
   const uint32_t *masks = nullptr;      // owner-computes schedules only
   const int32_t *extra_first = nullptr;
   int32_t mask_stride = 0, nfix = 0;
+  const void *cells_pair = nullptr;     // tied graphs of at most 8192 positions: the stream with offsets = position * 8
 };
 
 // ---- graphs too large for the on-chip layout ("streamed" path, den_big_kernel.hip) ------------------
@@ -167,6 +168,10 @@ struct DenParams {
   float *beta_hist = nullptr;   // [(T+1)][S][Hs]  B_t (row 0: B'_0), see den_tied_split.hip
   float *fwd_norm = nullptr;    // [S][T+2]        asum_0 .. asum_T, tot
   float *bwd_norm = nullptr;    // [S][T+1]        n_0 .. n_{T-1}
+  // Two-sequence form (den_tied_pair.hip): normalisers of both roles [2][S][pair_norm_stride(T)], ticket + flags
+  float *pair_norm = nullptr;
+  uint32_t *pair_sync = nullptr;
+  int pair_extra_slots = 0;     // secondary-row slots of the graph's schedules (LDS layout of the pair kernel)
 };
 
 }  // namespace tc
@@ -297,6 +302,11 @@ int launch_den_tied_backward_only(const DenParams &p, hipStream_t stream);
 int launch_den_tied_combine(const DenParams &p, int accumulate, int num_cus, hipStream_t stream);
 bool split_bwd_fits(const DenLayout &L, int T);  // the backward-only kernel's and the combining pass's LDS fit one CU
 constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most half the chip's CUs
+// den_tied_pair.hip: two sequences per workgroup, the two recursions of a pair on two CUs meeting in the middle
+int launch_den_tied_pair(const DenParams &p, int extra_slots, int accumulate, hipStream_t stream);
+bool pair_fits(const DenLayout &L, int extra_slots, int T);
+int pair_norm_stride(int T);
+size_t pair_sync_bytes(int S);
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_num_scatter(const NumParams &p, hipStream_t stream);
@@ -330,7 +340,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

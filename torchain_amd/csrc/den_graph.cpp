@@ -168,7 +168,8 @@ extern "C" {
 
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
-                                               "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap"};
+                                               "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
+                                               "force_pair"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -606,6 +607,21 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   if (g->tied) pi_pad = g->pi_pos;  // position order (build_owner)
   const std::vector<uint32_t> no_mask(1, 0u);
   const std::vector<int32_t> no_extra(kWaves, 0);
+  // den_tied_pair.hip gathers from a [position][2 sequences] array: the same streams with offsets = position * 8,
+  // which fit 16 bits up to 8192 positions
+  std::vector<uint32_t> pair_cells[2];
+  const bool want_pair = g->tied && g->layout.Hs <= 8192 && !g->fwd.cells6.empty();
+  if (want_pair)
+    for (int dir = 0; dir < 2; ++dir) {
+      const std::vector<uint32_t> &src = dir == 0 ? g->fwd.cells6 : g->bwd.cells6;
+      pair_cells[dir] = src;
+      for (size_t chunk = 0; chunk + 1 <= src.size() / (3 * 64 * 4); ++chunk)
+        for (size_t i = 0; i < 64 * 4; ++i) {
+          uint32_t &x = pair_cells[dir][chunk * 3 * 64 * 4 + 2 * 64 * 4 + i];
+          x = ((x & 0xffffu) << 1) | ((x >> 16) << 17);
+        }
+    }
+  const std::vector<uint32_t> no_pair(4, 0u);
   Part parts[] = {
       {g->fwd.cells6.empty() ? (const void *)g->fwd.cells.data() : (const void *)g->fwd.cells6.data(),
        g->fwd.cells6.empty() ? g->fwd.cells.size() * sizeof(ArcRec) : g->fwd.cells6.size() * 4, 0},
@@ -624,6 +640,8 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
       {g->bwd.masks.empty() ? no_mask.data() : g->bwd.masks.data(), std::max<size_t>(1, g->bwd.masks.size()) * 4, 0},
       {g->fwd.extra_first.empty() ? no_extra.data() : g->fwd.extra_first.data(), kWaves * 4, 0},
       {g->bwd.extra_first.empty() ? no_extra.data() : g->bwd.extra_first.data(), kWaves * 4, 0},
+      {want_pair ? pair_cells[0].data() : no_pair.data(), (want_pair ? pair_cells[0].size() : no_pair.size()) * 4, 0},
+      {want_pair ? pair_cells[1].data() : no_pair.data(), (want_pair ? pair_cells[1].size() : no_pair.size()) * 4, 0},
   };
   size_t total = 0;
   for (auto &p : parts) {
@@ -657,6 +675,10 @@ int tc_den_graph_prepare(tc_den_graph *g, int device) {
   if (g->tied) {
     d.tied_fs = (const uint32_t *)(blob + parts[9].off);
     d.tied_w = (const float *)(blob + parts[10].off);
+  }
+  if (want_pair) {
+    d.fwd.cells_pair = blob + parts[15].off;
+    d.bwd.cells_pair = blob + parts[16].off;
   }
   g->dev[device] = d;
   return TC_OK;

@@ -453,8 +453,18 @@ static bool split_wanted(const DenParams &p) {
   return p.tied_fs && !p.big.in_begin && p.deriv && p.beta_hist && split_bwd_fits(p.L, p.T) && !debug_flag(kDbgNoPhaseSplit);
 }
 
+// Two sequences per workgroup, the pair's two recursions on two CUs (den_tied_pair.hip): batches the two-CU form of one
+// sequence does not cover.
+static bool pair_wanted(const DenParams &p, int num_cus) {
+  if (!p.tied_fs || p.big.in_begin || !p.deriv || !p.pair_norm || !p.pair_sync || !p.fwd.cells_pair) return false;
+  if (debug_flag(kDbgNoPair) || !pair_fits(p.L, p.pair_extra_slots, p.T)) return false;
+  if (debug_flag(kDbgForcePair)) return true;
+  return !(split_wanted(p) && 2 * p.S <= num_cus);
+}
+
 int den_cus_used(const DenParams &p, int num_cus) {
   if (p.big.in_begin) return num_cus;
+  if (pair_wanted(p, num_cus)) return std::min(num_cus, 2 * ((p.S + 1) / 2));
   if (split_wanted(p) && 2 * p.S <= num_cus) return 2 * p.S;
   return p.S < num_cus ? p.S : num_cus;
 }
@@ -466,10 +476,11 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
   if (p.tied_fs != nullptr) {
+    SideStreams *c = nullptr;
+    const int src = side_streams(&c);
+    if (src != TC_OK) return src;
+    if (pair_wanted(p, c->num_cus)) return launch_den_tied_pair(p, p.pair_extra_slots, accumulate, stream);
     if (split_wanted(p)) {
-      SideStreams *c = nullptr;
-      const int rc = side_streams(&c);
-      if (rc != TC_OK) return rc;
       if (2 * p.S <= c->num_cus) {
         std::lock_guard<std::recursive_mutex> lock(c->enqueue);
         return launch_den_tied_split(p, accumulate, stream, c);
