@@ -24,6 +24,7 @@ struct Workspace {
   float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU form of small batches only (den_tied_split.hip)
   float *pair_norm = nullptr;                      // two-sequence form (den_tied_pair.hip)
   uint32_t *pair_sync = nullptr;
+  long long *pair_stamps = nullptr;                // ... its diagnostic builds (-DTC_PAIR_STAMPS): raw cycle stamps
   float *alpha_hist;
   double *den_lp, *num_lp, *y2;
   float *ab, *gs;
@@ -77,6 +78,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.bwd_norm = split ? (float *)take((size_t)S * (T + 1) * sizeof(float)) : nullptr;
   w.pair_sync = pair ? (uint32_t *)take(pair_sync_bytes(S)) : nullptr;
   w.pair_norm = pair ? (float *)take((size_t)2 * S * pair_norm_stride(T) * sizeof(float)) : nullptr;
+  w.pair_stamps = pair ? (long long *)take(pair_stamp_bytes(T)) : nullptr;  // (the workspace's last block)
   w.total = off;
   return w;
 }
@@ -133,6 +135,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->bwd_norm = w.bwd_norm;
   p->pair_norm = w.pair_norm;
   p->pair_sync = w.pair_sync;
+  p->pair_stamps = w.pair_stamps;
   p->pair_extra_slots = std::max(g->fwd.extra_slots, g->bwd.extra_slots);
   p->big_Sp = (S + 63) & ~63;
   p->big_sum_pi = g->big_sum_pi;

@@ -171,6 +171,7 @@ struct DenParams {
   // Two-sequence form (den_tied_pair.hip): normalisers of both roles [2][S][pair_norm_stride(T)], ticket + flags
   float *pair_norm = nullptr;
   uint32_t *pair_sync = nullptr;
+  long long *pair_stamps = nullptr;  // diagnostic builds (-DTC_PAIR_STAMPS): [role][wave][T + 2][8] raw cycle stamps of pair 0
   int pair_extra_slots = 0;     // secondary-row slots of the graph's schedules (LDS layout of the pair kernel)
 };
 
@@ -307,6 +308,7 @@ int launch_den_tied_pair(const DenParams &p, int extra_slots, int accumulate, hi
 bool pair_fits(const DenLayout &L, int extra_slots, int T);
 int pair_norm_stride(int T);
 size_t pair_sync_bytes(int S);
+inline size_t pair_stamp_bytes(int T) { return ((size_t)2 * kWaves * (T + 2) * 8 * 8 + 255) & ~(size_t)255; }
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_num_scatter(const NumParams &p, hipStream_t stream);

@@ -458,8 +458,10 @@ static bool split_wanted(const DenParams &p) {
 static bool pair_wanted(const DenParams &p, int num_cus) {
   if (!p.tied_fs || p.big.in_begin || !p.deriv || !p.pair_norm || !p.pair_sync || !p.fwd.cells_pair) return false;
   if (debug_flag(kDbgNoPair) || !pair_fits(p.L, p.pair_extra_slots, p.T)) return false;
-  if (debug_flag(kDbgForcePair)) return true;
-  return !(split_wanted(p) && 2 * p.S <= num_cus);
+  // (round 3: correct everywhere it is tested, but at C3 still a few per cent behind the fused kernel -- see DESIGN.md;
+  // until it wins it runs only on request)
+  (void)num_cus;
+  return debug_flag(kDbgForcePair);
 }
 
 int den_cus_used(const DenParams &p, int num_cus) {

@@ -42,11 +42,12 @@ typedef __attribute__((address_space(3))) f2 lds_f2;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 __device__ __forceinline__ f2 lds2(uint32_t a) { return *reinterpret_cast<lds_f2 *>(a); }
 
-// row sums of a lane's own rows, sequences 0 / 1: in registers (the LDS has no room for them: at C3 the gather
-// source of two sequences alone is 64 KB)
-struct Rows {
-  float a[8], b[8];
-};
+// Row sums of a lane's own rows in registers (the LDS has no room for them: at C3 the gather source of two sequences
+// alone is 64 KB): one 16-element vector, row k of sequence q at element 2 k + q.  All 64 lanes of a wave are at the
+// same row index, so a commit is a register write at a scalar index -- LLVM lowers the dynamic insert into a
+// 16-element vector to s_set_gpr_idx_on / v_mov_b32 / s_set_gpr_idx_off (an 8-element vector would be expanded into
+// eight compares and eight v_cndmask).
+typedef float Rows __attribute__((ext_vector_type(16)));
 
 struct PairCommit {
   int k;             // next row of the wave's stream (uniform)
@@ -58,18 +59,17 @@ __device__ __forceinline__ void addtid_st(uint32_t row, float v) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(v), "s"(row) : "memory", "m0");
 }
 
-// A row ends: all 64 lanes are at the same row index, so k is a scalar and the switch a scalar branch tree.
+// ADD: the row registers arrive preloaded (backward role: the self-loop arc's term of every owned state) and a
+// commit adds to them -- what the thread would otherwise hold in 16 more registers across the walk.
+template <bool ADD>
 __device__ __forceinline__ void commit2(PairCommit &rc, Rows &r, float v0, float v1) {
   if (rc.k < rc.K) {
-    switch (rc.k) {
-      case 0: r.a[0] = v0; r.b[0] = v1; break;
-      case 1: r.a[1] = v0; r.b[1] = v1; break;
-      case 2: r.a[2] = v0; r.b[2] = v1; break;
-      case 3: r.a[3] = v0; r.b[3] = v1; break;
-      case 4: r.a[4] = v0; r.b[4] = v1; break;
-      case 5: r.a[5] = v0; r.b[5] = v1; break;
-      case 6: r.a[6] = v0; r.b[6] = v1; break;
-      default: r.a[7] = v0; r.b[7] = v1; break;
+    if (ADD) {
+      r[2 * rc.k] += v0;
+      r[2 * rc.k + 1] += v1;
+    } else {
+      r[2 * rc.k] = v0;
+      r[2 * rc.k + 1] = v1;
     }
   } else {
     addtid_st(rc.sec_row, v0);
@@ -81,40 +81,47 @@ __device__ __forceinline__ void commit2(PairCommit &rc, Rows &r, float v0, float
 
 // acc(row) += w * SRC[off] for both sequences over one chunk (den_tied_device.h: do_chunk); the stream's 16-bit
 // offsets are position * 8 here (cells_pair).
-template <uint32_t SRC, int HALF>
+template <uint32_t SRC, int HALF, bool ADD>
 __device__ __forceinline__ void do_chunk2(const Chunk6 &q, uint32_t m, float &acc0, float &acc1, PairCommit &rc, Rows &r) {
-  uint32_t o[8];
-  o[0] = lo16(q.oc.x);
-  o[1] = hi16(q.oc.x);
-  o[2] = lo16(q.oc.y);
-  o[3] = hi16(q.oc.y);
-  o[4] = lo16(q.oc.z);
-  o[5] = hi16(q.oc.z);
-  o[6] = lo16(q.oc.w);
-  o[7] = hi16(q.oc.w);
-  f2 a[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = lds2(SRC + o[i]);
+  // four cells at a time: a gathered cell is two registers here, and 16 waves x 4 gathers in flight keep the LDS busy
+  const uint32_t oc[4] = {q.oc.x, q.oc.y, q.oc.z, q.oc.w};
   const uint32_t w[8] = {q.wa.x, q.wa.y, q.wa.z, q.wa.w, q.wb.x, q.wb.y, q.wb.z, q.wb.w};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    // (asm: left to the compiler the two FMAs become one v_pk_fma_f32 with the weight duplicated into a register
-    // pair, and for resident chunks that duplication is hoisted out of the frame loop: +1 register per cell)
-    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc0) : "v"(a[i].x), "v"(w[i]));
-    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc1) : "v"(a[i].y), "v"(w[i]));
-    const int bit = (i & 1) ? 4 * HALF + i / 2 : 8 + 4 * HALF + i / 2;
-    if (__builtin_expect((m >> bit) & 1u, 0)) {
-      commit2(rc, r, acc0, acc1);
-      acc0 = 0.f;
-      acc1 = 0.f;
+  for (int h = 0; h < 2; ++h) {
+    uint32_t o[4];
+    o[0] = lo16(oc[2 * h]);
+    o[1] = hi16(oc[2 * h]);
+    o[2] = lo16(oc[2 * h + 1]);
+    o[3] = hi16(oc[2 * h + 1]);
+    f2 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = lds2(SRC + o[i]);
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      const int i = 4 * h + i4;
+      // (asm: left to the compiler the two FMAs become one v_pk_fma_f32 with the weight duplicated into a register
+      // pair, and for resident chunks that duplication is hoisted out of the frame loop: +1 register per cell)
+      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc0) : "v"(a[i4].x), "v"(w[i]));
+      asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc1) : "v"(a[i4].y), "v"(w[i]));
+      const int bit = (i & 1) ? 4 * HALF + i / 2 : 8 + 4 * HALF + i / 2;
+      if (__builtin_expect((m >> bit) & 1u, 0)) {
+        commit2<ADD>(rc, r, acc0, acc1);
+        acc0 = 0.f;
+        acc1 = 0.f;
+      }
     }
   }
 }
 
-// One walk of a wave's stream for two sequences (den_tied_device.h: walk).
-template <uint32_t SRC, int RES, class AfterChunk>
-__device__ __forceinline__ void walk2(const Chunk6 *res, Chunk6 &qa, rsrc_t sbase, uint32_t lane16,
-                                      int nchunks, const uint32_t *masks, PairCommit rc, Rows &r, AfterChunk after_chunk) {
+// One walk of a wave's stream for two sequences (den_tied_device.h: walk): RES resident chunks, the rest through the
+// two register buffers qa / qb, which arrive PRELOADED with chunks RES and RES + 1 -- requested before the frame's
+// barrier, i.e. before the frame's HBM loads (y and history rows).  A wave's vector-memory operations complete in
+// order, so a chunk requested behind those loads waits for them (~2-3 k cycles under load); with the two
+// preloaded chunks and the resident ones in front, that wait is over before the first such chunk is needed.  Every
+// look-ahead load is unconditional (the streams end with four chunks of readable padding).
+template <uint32_t SRC, int RES, bool ADD>
+__device__ __forceinline__ void walk2(const Chunk6 *res, Chunk6 &qa, Chunk6 &qb, rsrc_t sbase, uint32_t lane16, int nchunks,
+                                      const uint32_t *masks, PairCommit rc, Rows &r) {
   static_assert(RES % 2 == 0, "a mask word covers two chunks");
   typedef __attribute__((address_space(4))) const uint32_t const_u32;
   const_u32 *mk = (const_u32 *)masks;
@@ -122,30 +129,18 @@ __device__ __forceinline__ void walk2(const Chunk6 *res, Chunk6 &qa, rsrc_t sbas
 #pragma unroll
   for (int i = 0; i < RES / 2; ++i) {
     const uint32_t m = mk[i];
-    do_chunk2<SRC, 0>(res[2 * i], m, acc0, acc1, rc, r);
-    after_chunk(2 * i);
-    do_chunk2<SRC, 1>(res[2 * i + 1], m, acc0, acc1, rc, r);
-    after_chunk(2 * i + 1);
+    do_chunk2<SRC, 0, ADD>(res[2 * i], m, acc0, acc1, rc, r);
+    do_chunk2<SRC, 1, ADD>(res[2 * i + 1], m, acc0, acc1, rc, r);
   }
-  Chunk6 qb;
   int c = RES;
-  for (; c + 2 < nchunks; c += 2) {
+  for (; c + 1 < nchunks; c += 2) {
     const uint32_t m = mk[c >> 1];
-    load_chunk(qb, sbase, lane16, c + 1);
-    do_chunk2<SRC, 0>(qa, m, acc0, acc1, rc, r);
+    do_chunk2<SRC, 0, ADD>(qa, m, acc0, acc1, rc, r);
     load_chunk(qa, sbase, lane16, c + 2);
-    do_chunk2<SRC, 1>(qb, m, acc0, acc1, rc, r);
-    if (RES == 0) after_chunk(-1 - (c >> 1));
+    do_chunk2<SRC, 1, ADD>(qb, m, acc0, acc1, rc, r);
+    load_chunk(qb, sbase, lane16, c + 3);
   }
-  if (c + 1 < nchunks) {
-    const uint32_t m = mk[c >> 1];
-    load_chunk(qb, sbase, lane16, c + 1);
-    do_chunk2<SRC, 0>(qa, m, acc0, acc1, rc, r);
-    do_chunk2<SRC, 1>(qb, m, acc0, acc1, rc, r);
-  } else if (c < nchunks) {
-    do_chunk2<SRC, 0>(qa, mk[c >> 1], acc0, acc1, rc, r);
-  }
-  if (RES == 0) after_chunk(kWalkEnd);
+  if (c < nchunks) do_chunk2<SRC, 0, ADD>(qa, mk[c >> 1], acc0, acc1, rc, r);
 }
 
 // N block sums behind one barrier; `red` holds N x kWaves floats and is not written again before the next barrier
@@ -187,6 +182,14 @@ __device__ __forceinline__ float vload_f32(const float *ptr) {
   const rsrc_t r = make_rsrc(ptr, 4u);
   return __uint_as_float(__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(r, 0, 0, 0)));
 }
+
+// Diagnostic build (-DTC_PAIR_STAMPS; never timed): lane 0 of every wave of pair 0 writes raw cycle stamps.
+#ifdef TC_PAIR_STAMPS
+#define TC_PSTAMP(role, t, i)                                                                                   \
+  if (pair == 0 && lane == 0) p.pair_stamps[(((role) * kWaves + wave) * (int64_t)(T + 2) + (t)) * 8 + (i)] = clock64();
+#else
+#define TC_PSTAMP(role, t, i)
+#endif
 
 struct PairParams {
   uint32_t *sync;     // [0]: ticket counter, [4 + 2 * pair + role]: "my first phase is stored" flags; zeroed before the launch
@@ -267,15 +270,15 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   float *const hist0 = p.alpha_hist + (int64_t)s0 * Hs, *const hist1 = p.alpha_hist + (int64_t)s1 * Hs;
   float *const fn0 = p.fwd_norm + (int64_t)s0 * q.norm_stride, *const fn1 = p.fwd_norm + (int64_t)s1 * q.norm_stride;
   const float *const bn0 = p.bwd_norm + (int64_t)s0 * q.norm_stride, *const bn1 = p.bwd_norm + (int64_t)s1 * q.norm_stride;
-  auto yrow = [&](int t, int s, uint32_t bytes) { return make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, bytes); };
-  auto drow = [&](int t, int s, uint32_t bytes) { return make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, bytes); };
+  auto yrow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, bytes); };
+  auto drow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, bytes); };
 
   // ---- t = 0: alpha_0 = pi, alpha'_0 = pi + leaky * pi * sum(pi) for both sequences
   f4 v0[2], v1[2];  // alpha_t (un-dashed) of the owned states, sequence 0 / 1
   float part = 0.f;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    v0[j] = j < planes ? bld4(r_pi, own16, j * kPlane) : mk4(0.f);
+    v0[j] = bld4(r_pi, own16, j * kPlane);
     part += hsum(v0[j]);
   }
   float asum_a = block_sum_a(part, aRed, wave, lane), asum_b = asum_a;
@@ -288,19 +291,15 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
       bst4(make_rsrc(hist1, hb1), own16 + j * kPlane, a);
     }
   float y2a = 0.f, y2b = 0.f;
-  f4 yp0[PV], yp1[PV];  // y_{t-1} of the thread's pdfs (the derivative row's l2 term)
   {
     const rsrc_t ya = yrow(0, s0, rb0), yb = yrow(0, s1, rb1);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
-      yp0[v] = mk4(0.f);
-      yp1[v] = mk4(0.f);
       if (4 * ((int)tid + kThreads * v) < Ps) {
-        yp0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-        yp1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
-        y2a += hsum(yp0[v] * yp0[v]);
-        y2b += hsum(yp1[v] * yp1[v]);
-        put_exp2(kPB, own32, v, yp0[v], yp1[v]);
+        const f4 yp0 = row_ld(ya, own16 + v * kPlane, p.y_vec), yp1 = row_ld(yb, own16 + v * kPlane, p.y_vec);
+        y2a += hsum(yp0 * yp0);
+        y2b += hsum(yp1 * yp1);
+        put_exp2(kPB, own32, v, yp0, yp1);
         lds4_st(aGM0 + own16 + v * kPlane, mk4(0.f));
         lds4_st(aGM1 + own16 + v * kPlane, mk4(0.f));
       }
@@ -316,7 +315,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   const int fnch = __builtin_amdgcn_readfirstlane(frange.y) / kChunk;
   const rsrc_t fbase = make_rsrc(reinterpret_cast<const char *>(q.fwd_cells) +
                                      (int64_t)(__builtin_amdgcn_readfirstlane(frange.x) / kChunk) * (3 * 64 * 16),
-                                 (uint32_t)(fnch + 2) * (3 * 64 * 16));
+                                 (uint32_t)(fnch + 4) * (3 * 64 * 16));
   const uint32_t *const fmask = p.fwd.masks + wave * p.fwd.mask_stride;
   const int ffx0 = p.fwd.nfix ? p.fwd.fix_begin[tid] : 0, ffx1 = p.fwd.nfix ? p.fwd.fix_begin[tid + 1] : 0;
   const PairCommit frc{0, K, q.aSEC + 512u * (uint32_t)p.fwd.extra_first[wave]};
@@ -329,7 +328,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   float chat_a = 0.f, chat_b = 0.f;  // c^_t used by the fixed-point adds of the running frame
 
   // secondary rows of hub states: add the slots other lanes of this wave filled to the owner's row sums
-  auto fold = [&](Rows &r, const ScheduleDev &sd, int e0, int e1) {
+  auto fold = [&](Rows &r, const ScheduleDev &sd, int e0, int e1) __attribute__((always_inline)) {
     for (int e = e0; e < e1; ++e) {
       const int2 f = sd.fix[e];
       const int k = 4 * (f.x / (4 * kThreads)) + (f.x & 3);
@@ -337,79 +336,84 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
       const float x0 = ldsf(src), x1 = ldsf(src + 256u);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        r.a[kk] += k == kk ? x0 : 0.f;
-        r.b[kk] += k == kk ? x1 : 0.f;
+        r[2 * kk] += k == kk ? x0 : 0.f;
+        r[2 * kk + 1] += k == kk ? x1 : 0.f;
       }
     }
   };
 
+  Chunk6 q0, q1;  // the stream's first two non-resident chunks
+  // HBM rows a frame needs (y_t; second phase: B_t) are requested in the frame BEFORE, behind its per-state pass: a
+  // wave's memory operations complete in order, so a request under the walk would hold up every streamed chunk
+  // behind it for an HBM round trip; requested there, the rows arrive during the reduction and the tail.
+  f4 yr0[PV], yr1[PV];  // y_t of the thread's pdfs
+  f4 bt0[2] = {mk4(0.f), mk4(0.f)}, bt1[2] = {mk4(0.f), mk4(0.f)};  // B_t of the owned states
+  auto request_y = [&](int t) __attribute__((always_inline)) {
+    const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      yr0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
+      yr1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+    }
+  };
+  auto request_b = [&](int t) __attribute__((always_inline)) {
+    const rsrc_t ba = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), bb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bt0[j] = bld4(ba, own16, j * kPlane);
+      bt1[j] = bld4(bb, own16, j * kPlane);
+    }
+  };
   // One frame t: alpha_t from alpha'_{t-1}; GAMMA: also gamma_{t-1} and its derivative row from B_t.
-  auto frame = [&](int t, auto res_tag, auto gamma_tag) {
+  auto frame = [&](int t, auto res_tag, auto gamma_tag) __attribute__((always_inline)) {
     constexpr int RES = decltype(res_tag)::value;
     constexpr bool GAMMA = decltype(gamma_tag)::value;
-    Chunk6 q0;
-    load_chunk(q0, fbase, lane16, RES);
+    TC_PSTAMP(0, t, 0)
     __syncthreads();  // alpha'_{t-1}, exp(y_{t-1}) ready; gamma zero
-    f4 yr0[PV], yr1[PV];
-    if (t < T) {
-      const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) {
-        yr0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-        yr1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
-      }
-    }
-    f4 bt0[2] = {mk4(0.f), mk4(0.f)}, bt1[2] = {mk4(0.f), mk4(0.f)};  // B_t of the owned states
+    TC_PSTAMP(0, t, 1)
     float n_a = 1.f, n_b = 1.f;
-    if (GAMMA) {
-      const rsrc_t ba = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), bb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bt0[j] = j < planes ? bld4(ba, own16, j * kPlane) : mk4(0.f);
-        bt1[j] = j < planes ? bld4(bb, own16, j * kPlane) : mk4(0.f);
-      }
-      if (t < T) {  // n_t: c^_{t+1} = c_t asum_t / n_t, for the next frame
-        n_a = vload_f32(bn0 + t);
-        n_b = vload_f32(bn1 + t);
-      }
+    if (GAMMA && t < T) {  // n_t: c^_{t+1} = c_t asum_t / n_t, for the next frame
+      n_a = vload_f32(bn0 + t);
+      n_b = vload_f32(bn1 + t);
     }
     Rows r;
     age_prio_on(wave);
-    bool stored = false;
-    const int store_slot = RES >= 4 ? wave >> 2 : RES >= 2 ? wave >> 3 : 0;
-    walk2<kA0, RES>(fres, q0, fbase, lane16, fnch, fmask, frc, r, [&](int i) {
-      // the history row of frame t-1 leaves under the walk (den_tied_kernel.hip), from the gather buffer
-      if (!GAMMA && t > 1 && !stored && (RES > 0 ? i == store_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
-        stored = true;
-        const rsrc_t ha = make_rsrc(hist0 + (int64_t)(t - 1) * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)(t - 1) * hist_step, hb1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (j < planes) {
-            const Own8 o = own_ld(kA0 + own32 + j * kPlane2);
-            bst4(ha, own16 + j * kPlane, seq0(o));
-            bst4(hb, own16 + j * kPlane, seq1(o));
-          }
-      }
-    });
+    walk2<kA0, RES, false>(fres, q0, q1, fbase, lane16, fnch, fmask, frc, r);
     __builtin_amdgcn_s_setprio(0);
+    TC_PSTAMP(0, t, 2)
+    // Behind the walk: the per-state tables (L2), then y_{t-1}.
+    u4 fs[2];
+    f4 ws[2], cpi[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fs[j] = bld4u(r_fs, own16, j * kPlane);
+      ws[j] = bld4(r_ws, own16, j * kPlane);
+    }
+    f4 yp0[PV], yp1[PV];
+    if (GAMMA) {
+      // y_{t-1} (the derivative row's l2 term) is read again rather than held in registers across the walk: the row
+      // was this CU's a frame ago (L2), and its first use is behind the pass and the reduction
+      const rsrc_t ya = yrow(t - 1, s0, rb0), yb = yrow(t - 1, s1, rb1);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        yp0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
+        yp1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+      }
+    }
     fold(r, p.fwd, ffx0, ffx1);
     float sums[GAMMA ? 4 : 2];
 #pragma unroll
     for (int i = 0; i < (GAMMA ? 4 : 2); ++i) sums[i] = 0.f;
-    f4 cpi[2];
     const float gsa = kGammaScale * chat_a, gsb = kGammaScale * chat_b;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      v0[j] = v1[j] = cpi[j] = mk4(0.f);
+      v0[j] = v1[j] = mk4(0.f);
       if (j < planes) {
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f4 ws = bld4(r_ws, own16, j * kPlane);
-        cpi[j] = bld4(r_pi, own16, j * kPlane);
         const Own8 al = own_ld(kA0 + own32 + j * kPlane2);  // alpha'_{t-1} of the owned states
         const f4 al0 = seq0(al), al1 = seq1(al);
         // alpha_t(g) asum_{t-1} = p(f(g)) F(g) + p(s(g)) w_s alpha'_{t-1}(g); with B_t(g): the two parts are the
         // occupations of the forward-class arcs into g and of its self-loop in frame t-1
-        auto one = [&](uint32_t fsx, float wsx, float F0, float F1, float a0, float a1, float b0, float b1, float &o0, float &o1) {
+        auto one = [&](uint32_t fsx, float wsx, float F0, float F1, float a0, float a1, float b0, float b1, float &o0, float &o1) __attribute__((always_inline)) {
           const f2 pf = lds2(kPB + 2u * (fsx & 0xffffu)), ps = lds2(kPB + 2u * (fsx >> 16));
           const float fp0 = pf.x * F0 * inv_a, fp1 = pf.y * F1 * inv_b;
           const float sp0 = ps.x * (wsx * a0) * inv_a, sp1 = ps.y * (wsx * a1) * inv_b;
@@ -426,17 +430,40 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
           }
         };
         float oa[4], ob[4];
-        one(fs.x, ws.x, r.a[4 * j + 0], r.b[4 * j + 0], al0.x, al1.x, bt0[j].x, bt1[j].x, oa[0], ob[0]);
-        one(fs.y, ws.y, r.a[4 * j + 1], r.b[4 * j + 1], al0.y, al1.y, bt0[j].y, bt1[j].y, oa[1], ob[1]);
-        one(fs.z, ws.z, r.a[4 * j + 2], r.b[4 * j + 2], al0.z, al1.z, bt0[j].z, bt1[j].z, oa[2], ob[2]);
-        one(fs.w, ws.w, r.a[4 * j + 3], r.b[4 * j + 3], al0.w, al1.w, bt0[j].w, bt1[j].w, oa[3], ob[3]);
+        one(fs[j].x, ws[j].x, r[8 * j + 2 * 0], r[8 * j + 2 * 0 + 1], al0.x, al1.x, bt0[j].x, bt1[j].x, oa[0], ob[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        one(fs[j].y, ws[j].y, r[8 * j + 2 * 1], r[8 * j + 2 * 1 + 1], al0.y, al1.y, bt0[j].y, bt1[j].y, oa[1], ob[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        one(fs[j].z, ws[j].z, r[8 * j + 2 * 2], r[8 * j + 2 * 2 + 1], al0.z, al1.z, bt0[j].z, bt1[j].z, oa[2], ob[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        one(fs[j].w, ws[j].w, r[8 * j + 2 * 3], r[8 * j + 2 * 3 + 1], al0.w, al1.w, bt0[j].w, bt1[j].w, oa[3], ob[3]);
+        __builtin_amdgcn_sched_barrier(0);
         v0[j] = f4{oa[0], oa[1], oa[2], oa[3]};
         v1[j] = f4{ob[0], ob[1], ob[2], ob[3]};
         sums[0] += hsum(v0[j]);
         sums[1] += hsum(v1[j]);
       }
     }
+    // pi: first touched behind the reduction, which hides its L2 trip
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cpi[j] = bld4(r_pi, own16, j * kPlane);
+    // the next frame's B row (unconditional, index clamped: a conditional assignment would keep the old values alive
+    // through the whole frame)
+    if (GAMMA) request_b(t + 1 <= T ? t + 1 : T);
+    // the history row of frame t-1 (first phase), behind everything this frame still loads
+    if (!GAMMA && t > 1) {
+      const rsrc_t ha = make_rsrc(hist0 + (int64_t)(t - 1) * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)(t - 1) * hist_step, hb1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (j < planes) {
+          const Own8 o = own_ld(kA0 + own32 + j * kPlane2);  // alpha'_{t-1} of the owned states: still in the gather buffer
+          bst4(ha, own16 + j * kPlane, seq0(o));
+          bst4(hb, own16 + j * kPlane, seq1(o));
+        }
+    }
+    TC_PSTAMP(0, t, 3)
     block_sums(sums, aRed, wave, lane);  // its barrier also ends every wave's gathers and completes gamma_{t-1}
+    TC_PSTAMP(0, t, 4)
     asum_a = sums[0];
     asum_b = sums[1];
     part_tot_a = part_tot_b = 0.f;
@@ -448,6 +475,9 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
         part_tot_a += hsum(a0);
         part_tot_b += hsum(a1);
       }
+    // the next frame's first chunks: requested ahead of the stores and of the HBM request below (in-order completion)
+    load_chunk(q0, fbase, lane16, RES);
+    load_chunk(q1, fbase, lane16, RES + 1);
     if (GAMMA) {
       // the derivative row of frame t-1: gamma_{t-1} * (c_t / c^_t)
       const float ca = __builtin_amdgcn_rcpf(sums[2]), cb = __builtin_amdgcn_rcpf(sums[3]);
@@ -481,8 +511,6 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
           y2a += hsum(yr0[v] * yr0[v]);
           y2b += hsum(yr1[v] * yr1[v]);
           put_exp2(kPB, own32, v, yr0[v], yr1[v]);
-          yp0[v] = yr0[v];
-          yp1[v] = yr1[v];
         }
     }
     if (tid == 0) {
@@ -491,10 +519,17 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     }
     inv_a = __builtin_amdgcn_rcpf(asum_a);
     inv_b = __builtin_amdgcn_rcpf(asum_b);
+    request_y(t + 1 < T ? t + 1 : T - 1);  // the next frame's y row (HBM): its first use is that frame's tail
+    TC_PSTAMP(0, t, 5)
   };
 
   // ---- first phase: frames 1 .. M, pure recursion, rows 0 .. M-1 stored under the walks
+  load_chunk(q0, fbase, lane16, RES1);
+  load_chunk(q1, fbase, lane16, RES1 + 1);
+  request_y(1);  // (T >= 2)
+#ifndef TC_PAIR_NO_PURE
   for (int t = 1; t <= M; ++t) frame(t, std::integral_constant<int, RES1>(), std::false_type());
+#endif
   {
     // row M (still in the gather buffer), then the hand-off
     const rsrc_t ha = make_rsrc(hist0 + (int64_t)M * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)M * hist_step, hb1);
@@ -506,8 +541,10 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
         bst4(hb, own16 + j * kPlane, seq1(o));
       }
   }
+  TC_PSTAMP(0, T + 1, 0)
   publish(q.sync + 4 + 2 * pair, tid);
   const bool partner_ok = await(q.sync + 4 + 2 * pair + 1, tid, aRed + kScrAwait);
+  TC_PSTAMP(0, T + 1, 1)
   {
     // c_M = 1 / sum_g alpha_M(g) B_M(g)  (B_M: row T + 1), c^_{M+1} = c_M asum_M / n_M
     const rsrc_t ba = make_rsrc(hist0 + (int64_t)(T + 1) * hist_step, hb0), bb = make_rsrc(hist1 + (int64_t)(T + 1) * hist_step, hb1);
@@ -525,7 +562,12 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     chat_b = c_b * asum_b * __builtin_amdgcn_rcpf(vload_f32(bn1 + M));
   }
   // ---- second phase: frames M+1 .. T with gamma_{t-1}
+  load_chunk(q0, fbase, lane16, RES2);
+  load_chunk(q1, fbase, lane16, RES2 + 1);
+  request_b(M + 1);
+#ifndef TC_PAIR_NO_GAMMA
   for (int t = M + 1; t <= T; ++t) frame(t, std::integral_constant<int, RES2>(), std::true_type());
+#endif
 
   // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h); log-prob = log tot + sum_{t<T} log asum_t
   float fin[4] = {part_tot_a, part_tot_b, y2a, y2b};
@@ -573,6 +615,12 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
 // n_t = sum_h U_t(h) / H, B'_t = U_t / n_t, B_t = B'_t + leaky sum_h pi(h) B'_t(h); in its second phase also gamma_t and
 // the derivative row with the fused kernel's per-state formulas (den_tied_kernel.hip) and beta_{t+1} = c_{t+1} B_{t+1}.
 // LDS: one exp(y) buffer (rewritten in place behind a barrier, the fused kernel's tight layout).
+//
+// Every frame is the same walk + per-state pass: the self-loop arc's term of U_t waits in the row registers the walk
+// adds to (form_y), so B_{t+1} is not held across the walk.  In the second phase the per-state gamma work of frame t
+// (fixed-point adds from B_{t+1}, alpha'_t, alpha'_{t+1} and exp(y_t)) is done at the END of frame t + 1, between
+// forming B_{t+1} and the next walk, where nothing of a walk or a pass is in registers; frame t then only converts
+// the finished gamma_t row behind its reduction.
 // ---------------------------------------------------------------------------------------------------------
 template <int PV, bool ACCUM, int RES1, int RES2>
 __device__ __forceinline__ void pair_backward(const DenParams &p, const PairParams &q, int pair) {
@@ -597,33 +645,34 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   float *const hist0 = p.alpha_hist + (int64_t)s0 * Hs, *const hist1 = p.alpha_hist + (int64_t)s1 * Hs;
   const float *const fn0 = p.fwd_norm + (int64_t)s0 * q.norm_stride, *const fn1 = p.fwd_norm + (int64_t)s1 * q.norm_stride;
   float *const bn0 = p.bwd_norm + (int64_t)s0 * q.norm_stride, *const bn1 = p.bwd_norm + (int64_t)s1 * q.norm_stride;
-  auto yrow = [&](int t, int s, uint32_t bytes) { return make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, bytes); };
-  auto drow = [&](int t, int s, uint32_t bytes) { return make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, bytes); };
+  auto yrow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, bytes); };
+  auto drow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, bytes); };
   const float inv_h = 1.0f / (float)H;
 
   const int2 brange = p.bwd.wave_range[wave];
   const int bnch = __builtin_amdgcn_readfirstlane(brange.y) / kChunk;
   const rsrc_t bbase = make_rsrc(reinterpret_cast<const char *>(q.bwd_cells) +
                                      (int64_t)(__builtin_amdgcn_readfirstlane(brange.x) / kChunk) * (3 * 64 * 16),
-                                 (uint32_t)(bnch + 2) * (3 * 64 * 16));
+                                 (uint32_t)(bnch + 4) * (3 * 64 * 16));
   const uint32_t *const bmask = p.bwd.masks + wave * p.bwd.mask_stride;
-  const int bfx0 = p.bwd.nfix ? p.bwd.fix_begin[tid] : 0, bfx1 = p.bwd.nfix ? p.bwd.fix_begin[tid + 1] : 0;
   const PairCommit brc{0, K, q.aSEC + 512u * (uint32_t)p.bwd.extra_first[wave]};
   constexpr int RESMAX = RES1 > RES2 ? RES1 : RES2;
   Chunk6 bres[RESMAX > 0 ? RESMAX : 1];
 #pragma unroll
   for (int i = 0; i < RESMAX; ++i) load_chunk(bres[i], bbase, lane16, i);
 
-  auto fold = [&](Rows &r, const ScheduleDev &sd, int e0, int e1) {
+  auto fold = [&](Rows &r) __attribute__((always_inline)) {
+    if (p.bwd.nfix == 0) return;
+    const int e0 = p.bwd.fix_begin[tid], e1 = p.bwd.fix_begin[tid + 1];
     for (int e = e0; e < e1; ++e) {
-      const int2 f = sd.fix[e];
+      const int2 f = p.bwd.fix[e];
       const int k = 4 * (f.x / (4 * kThreads)) + (f.x & 3);
       const uint32_t src = q.aSEC + 512u * (uint32_t)((f.y - Hs - 4) >> 6) + 4u * (uint32_t)((f.y - Hs - 4) & 63);
       const float x0 = ldsf(src), x1 = ldsf(src + 256u);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        r.a[kk] += k == kk ? x0 : 0.f;
-        r.b[kk] += k == kk ? x1 : 0.f;
+        r[2 * kk] += k == kk ? x0 : 0.f;
+        r[2 * kk + 1] += k == kk ? x1 : 0.f;
       }
     }
   };
@@ -635,7 +684,6 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     if (j < planes) part += hsum(leaky * bld4(r_pi, own16, j * kPlane));
   const float bsum_T = block_sum_a(part, aRed, wave, lane);
   f4 bo0[2], bo1[2];  // B_{t+1} of the owned states
-  f4 yc0[PV], yc1[PV];  // y_t of the thread's pdfs
   {
     const rsrc_t ha = make_rsrc(hist0 + (int64_t)T * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)T * hist_step, hb1);
 #pragma unroll
@@ -652,134 +700,180 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     const rsrc_t ya = yrow(T - 1, s0, rb0), yb = yrow(T - 1, s1, rb1);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
-      yc0[v] = yc1[v] = mk4(0.f);
       if (4 * ((int)tid + kThreads * v) < Ps) {
-        yc0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-        yc1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
-        put_exp2(kPB, own32, v, yc0[v], yc1[v]);
+        put_exp2(kPB, own32, v, row_ld(ya, own16 + v * kPlane, p.y_vec), row_ld(yb, own16 + v * kPlane, p.y_vec));
         lds4_st(aGM0 + own16 + v * kPlane, mk4(0.f));
         lds4_st(aGM1 + own16 + v * kPlane, mk4(0.f));
       }
     }
-    __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = B_T(g) p_{T-1}(f(g))
+    __syncthreads();  // exp(y_{T-1}) complete
+  }
+  // From B_{t+1} (bo) and exp(y_t) in LDS: the next walk's gather source Y_t(g) = B_{t+1}(g) p_t(f(g)) and the self-loop
+  // arc's term of U_t(g), p_t(s(g)) w_s(g) B_{t+1}(g), which waits in the row registers the walk adds to.
+  Rows rnext;
+  auto form_y = [&](const u4 (&fs)[2], const f4 (&ws)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rnext[8 * j + i] = 0.f;
+      if (j < planes) {
+        const f2 p0 = lds2(kPB + 2u * (fs[j].x & 0xffffu)), p1 = lds2(kPB + 2u * (fs[j].y & 0xffffu));
+        const f2 p2 = lds2(kPB + 2u * (fs[j].z & 0xffffu)), p3 = lds2(kPB + 2u * (fs[j].w & 0xffffu));
+        own_st(kA0 + own32 + j * kPlane2, bo0[j] * f4{p0.x, p1.x, p2.x, p3.x}, bo1[j] * f4{p0.y, p1.y, p2.y, p3.y});
+        const f2 q0 = lds2(kPB + 2u * (fs[j].x >> 16)), q1 = lds2(kPB + 2u * (fs[j].y >> 16));
+        const f2 q2 = lds2(kPB + 2u * (fs[j].z >> 16)), q3 = lds2(kPB + 2u * (fs[j].w >> 16));
+        const f4 sa = bo0[j] * ws[j] * f4{q0.x, q1.x, q2.x, q3.x}, sb = bo1[j] * ws[j] * f4{q0.y, q1.y, q2.y, q3.y};
+        rnext[8 * j + 0] = sa.x;
+        rnext[8 * j + 1] = sb.x;
+        rnext[8 * j + 2] = sa.y;
+        rnext[8 * j + 3] = sb.y;
+        rnext[8 * j + 4] = sa.z;
+        rnext[8 * j + 5] = sb.z;
+        rnext[8 * j + 6] = sa.w;
+        rnext[8 * j + 7] = sb.w;
+      }
+    }
+  };
+  {
+    u4 fs[2];
+    f4 ws[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fs[j] = bld4u(r_fs, own16, j * kPlane);
+      ws[j] = bld4(r_ws, own16, j * kPlane);
+    }
+    form_y(fs, ws);
+  }
+  Chunk6 q0, q1;  // the stream's first two non-resident chunks of the NEXT frame: requested before the frame's stores
+  // HBM rows a frame needs are requested a frame ahead or behind the frame's own pass (see the forward role).
+  f4 yn0[PV], yn1[PV];  // y_{t-1}
+  f4 al0[2] = {mk4(0.f), mk4(0.f)}, al1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_{t-1}: gamma_{t-1} is formed at the end of frame t
+  f4 au0[2] = {mk4(0.f), mk4(0.f)}, au1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_t
+  auto request_yn = [&](int t) __attribute__((always_inline)) {
+    const int tn = t > 0 ? t - 1 : 0;
+    const rsrc_t ya = yrow(tn, s0, rb0), yb = yrow(tn, s1, rb1);
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      yn0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
+      yn1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+    }
+  };
+  // alpha'_{tl} -> al, alpha'_{tl+1} -> au (the second one was this CU's a frame ago: L2; it goes first)
+  auto request_alpha = [&](int tl) __attribute__((always_inline)) {
+    const rsrc_t u0r = make_rsrc(hist0 + (int64_t)(tl + 1) * hist_step, hb0), u1r = make_rsrc(hist1 + (int64_t)(tl + 1) * hist_step, hb1);
+    const rsrc_t a0r = make_rsrc(hist0 + (int64_t)tl * hist_step, hb0), a1r = make_rsrc(hist1 + (int64_t)tl * hist_step, hb1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      au0[j] = bld4(u0r, own16, j * kPlane);
+      au1[j] = bld4(u1r, own16, j * kPlane);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      al0[j] = bld4(a0r, own16, j * kPlane);
+      al1[j] = bld4(a1r, own16, j * kPlane);
+    }
+  };
+  float chat_a = 0.f, chat_b = 0.f;  // c^_{t+1}: the scale of B_{t+1} the fixed-point adds of gamma_t used
+  float dpart_a = 0.f, dpart_b = 0.f;  // this thread's part of sum_g alpha_{t+1}(g) B_{t+1}(g) = 1 / c_{t+1}
+
+  // gamma_tl's fixed-point adds, from B_{tl+1} (bo), alpha'_tl (al), alpha'_{tl+1} (au) and exp(y_tl) (LDS) -- the fused
+  // kernel's per-state formulas (den_tied_kernel.hip):
+  //   self-loop     occ_s = beta_{tl+1}(g) selfpart,  selfpart = p_tl(s(g)) w_s(g) alpha'_tl(g) / asum_tl
+  //   forward class occ_f = beta_{tl+1}(g) (alpha_{tl+1}(g) - selfpart),  alpha_{tl+1} = alpha'_{tl+1} - leaky pi asum_{tl+1}
+  // with beta_{tl+1} = c^ B_{tl+1}.  Leaves this thread's part of sum_g alpha_{tl+1}(g) B_{tl+1}(g) in dpart.
+  auto gamma_block = [&](int tl, const u4 (&fs)[2], const f4 (&ws)[2], const f4 (&cp)[2]) {
+    const float as_a = vload_f32(fn0 + tl), as_b = vload_f32(fn1 + tl);
+    const float asu_a = vload_f32(fn0 + tl + 1), asu_b = vload_f32(fn1 + tl + 1);
+    const float inv_as_a = __builtin_amdgcn_rcpf(as_a), inv_as_b = __builtin_amdgcn_rcpf(as_b);
+    const float gsa = kGammaScale * chat_a, gsb = kGammaScale * chat_b;
+    dpart_a = dpart_b = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       if (j < planes) {
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f2 p0 = lds2(kPB + 2u * (fs.x & 0xffffu)), p1 = lds2(kPB + 2u * (fs.y & 0xffffu));
-        const f2 p2 = lds2(kPB + 2u * (fs.z & 0xffffu)), p3 = lds2(kPB + 2u * (fs.w & 0xffffu));
-        own_st(kA0 + own32 + j * kPlane2, bo0[j] * f4{p0.x, p1.x, p2.x, p3.x}, bo1[j] * f4{p0.y, p1.y, p2.y, p3.y});
+        auto one = [&](uint32_t fsx, float wsx, float cpx, float b0, float b1, float a0, float a1, float up0, float up1) __attribute__((always_inline)) {
+          const f2 ps = lds2(kPB + 2u * (fsx >> 16));
+          const float sp0 = ps.x * wsx * a0 * inv_as_a, sp1 = ps.y * wsx * a1 * inv_as_b;
+          const float an0 = up0 - cpx * asu_a, an1 = up1 - cpx * asu_b;
+          const float g0 = gsa * b0, g1 = gsb * b1;
+          gamma_add_a(aGM0 + (fsx >> 16), g0 * sp0);
+          gamma_add_a(aGM0 + (fsx & 0xffffu), g0 * fmaxf(an0 - sp0, 0.f));
+          gamma_add_a(aGM1 + (fsx >> 16), g1 * sp1);
+          gamma_add_a(aGM1 + (fsx & 0xffffu), g1 * fmaxf(an1 - sp1, 0.f));
+          dpart_a = fmaf(an0, b0, dpart_a);
+          dpart_b = fmaf(an1, b1, dpart_b);
+        };
+        one(fs[j].x, ws[j].x, cp[j].x, bo0[j].x, bo1[j].x, al0[j].x, al1[j].x, au0[j].x, au1[j].x);
+        __builtin_amdgcn_sched_barrier(0);
+        one(fs[j].y, ws[j].y, cp[j].y, bo0[j].y, bo1[j].y, al0[j].y, al1[j].y, au0[j].y, au1[j].y);
+        __builtin_amdgcn_sched_barrier(0);
+        one(fs[j].z, ws[j].z, cp[j].z, bo0[j].z, bo1[j].z, al0[j].z, al1[j].z, au0[j].z, au1[j].z);
+        __builtin_amdgcn_sched_barrier(0);
+        one(fs[j].w, ws[j].w, cp[j].w, bo0[j].w, bo1[j].w, al0[j].w, al1[j].w, au0[j].w, au1[j].w);
+        __builtin_amdgcn_sched_barrier(0);
       }
-  }
-  float chat_a = 0.f, chat_b = 0.f;  // c^_{t+1}: scale of B_{t+1} used by the fixed-point adds of frame t
+  };
 
-  // One frame t: B_t from B_{t+1}; GAMMA: also gamma_t and its derivative row from alpha'_t, alpha'_{t+1}.
-  auto frame = [&](int t, auto res_tag, auto gamma_tag) {
+  // One frame t: B_t from B_{t+1}; GAMMA: also the derivative row of frame t (its gamma was formed at the end of frame
+  // t + 1) and, at its end, gamma_{t-1}.
+  // (LAST: frame 0, instantiated on its own -- an early exit inside the loop's frame would make every assignment of
+  // the tail conditional and so keep last frame's values alive through the whole frame)
+  auto frame = [&](int t, auto res_tag, auto gamma_tag, auto last_tag) __attribute__((always_inline)) {
     constexpr int RES = decltype(res_tag)::value;
     constexpr bool GAMMA = decltype(gamma_tag)::value;
-    Chunk6 q0;
-    load_chunk(q0, bbase, lane16, RES);
-    __syncthreads();  // Y_t and exp(y_t) ready; gamma zero
-    f4 yn0[PV], yn1[PV];
-    {
-      const int tn = t > 0 ? t - 1 : 0;
-      const rsrc_t ya = yrow(tn, s0, rb0), yb = yrow(tn, s1, rb1);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) {
-        yn0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-        yn1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
-      }
-    }
-    f4 al0[2] = {mk4(0.f), mk4(0.f)}, al1[2] = {mk4(0.f), mk4(0.f)}, au0[2] = {mk4(0.f), mk4(0.f)}, au1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_t, alpha'_{t+1}
-    float as_a = 1.f, as_b = 1.f, asu_a = 1.f, asu_b = 1.f;
-    if (GAMMA) {
-      const rsrc_t a0r = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), a1r = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
-      const rsrc_t u0r = make_rsrc(hist0 + (int64_t)(t + 1) * hist_step, hb0), u1r = make_rsrc(hist1 + (int64_t)(t + 1) * hist_step, hb1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        al0[j] = j < planes ? bld4(a0r, own16, j * kPlane) : mk4(0.f);
-        al1[j] = j < planes ? bld4(a1r, own16, j * kPlane) : mk4(0.f);
-        au0[j] = j < planes ? bld4(u0r, own16, j * kPlane) : mk4(0.f);
-        au1[j] = j < planes ? bld4(u1r, own16, j * kPlane) : mk4(0.f);
-      }
-      as_a = vload_f32(fn0 + t);
-      as_b = vload_f32(fn1 + t);
-      asu_a = vload_f32(fn0 + t + 1);
-      asu_b = vload_f32(fn1 + t + 1);
-    }
-    Rows r;
+    constexpr bool LAST = decltype(last_tag)::value;
+    TC_PSTAMP(1, t, 0)
+    __syncthreads();  // Y_t and exp(y_t) ready; gamma_t complete
+    TC_PSTAMP(1, t, 1)
+    Rows r = rnext;
     age_prio_on(wave);
-    bool stored = false;
-    const int store_slot = RES >= 4 ? wave >> 2 : RES >= 2 ? wave >> 3 : 0;
-    walk2<kA0, RES>(bres, q0, bbase, lane16, bnch, bmask, brc, r, [&](int i) {
-      // the row of B_{t+1}, still in registers, leaves under the walk (row T was stored at the start)
-      if (!GAMMA && t < T - 1 && !stored && (RES > 0 ? i == store_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
-        stored = true;
-        const rsrc_t ha = make_rsrc(hist0 + (int64_t)(t + 1) * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)(t + 1) * hist_step, hb1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (j < planes) {
-            bst4(ha, own16 + j * kPlane, bo0[j]);
-            bst4(hb, own16 + j * kPlane, bo1[j]);
-          }
-      }
-    });
+    walk2<kA0, RES, true>(bres, q0, q1, bbase, lane16, bnch, bmask, brc, r);
     __builtin_amdgcn_s_setprio(0);
-    fold(r, p.bwd, bfx0, bfx1);
-    constexpr int NS = GAMMA ? 8 : 4;
+    TC_PSTAMP(1, t, 2)
+    // Behind the walk: the per-state tables (L2)
+    u4 fs[2];
+    f4 ws[2], cp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fs[j] = bld4u(r_fs, own16, j * kPlane);
+      ws[j] = bld4(r_ws, own16, j * kPlane);
+      cp[j] = leaky * bld4(r_pi, own16, j * kPlane);
+    }
+    fold(r);
+    constexpr int NS = GAMMA ? 6 : 4;
     float sums[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) sums[i] = 0.f;
     f4 u0[2], u1[2];
-    uint32_t fpk[2][2];
-    const float inv_as_a = __builtin_amdgcn_rcpf(as_a), inv_as_b = __builtin_amdgcn_rcpf(as_b);
-    const float gsa = kGammaScale * chat_a, gsb = kGammaScale * chat_b;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      u0[j] = u1[j] = mk4(0.f);
-      fpk[j][0] = fpk[j][1] = 0u;
+      // U_t(h): the self-loop arc's term was preloaded into the row registers (form_y)
+      u0[j] = f4{r[8 * j + 0], r[8 * j + 2], r[8 * j + 4], r[8 * j + 6]};
+      u1[j] = f4{r[8 * j + 1], r[8 * j + 3], r[8 * j + 5], r[8 * j + 7]};
       if (j < planes) {
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f4 ws = bld4(r_ws, own16, j * kPlane);
-        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
-        auto one = [&](uint32_t fsx, float wsx, float cpx, float R0, float R1, float b0, float b1, float a0, float a1, float up0,
-                       float up1, float &o0, float &o1) {
-          const f2 ps = lds2(kPB + 2u * (fsx >> 16));
-          const float pw0 = ps.x * wsx, pw1 = ps.y * wsx;
-          o0 = fmaf(pw0, b0, R0);  // U_t(h): the self-loop arc joins the row sum
-          o1 = fmaf(pw1, b1, R1);
-          sums[0] += o0;
-          sums[1] += o1;
-          sums[2] = fmaf(cpx, o0, sums[2]);
-          sums[3] = fmaf(cpx, o1, sums[3]);
-          if constexpr (GAMMA) {
-            // (den_tied_kernel.hip) self-loop: occ_s = beta_{t+1}(g) selfpart, selfpart = p_t(s) w_s alpha'_t(g) / asum_t;
-            // forward class: occ_f = beta_{t+1}(g) (alpha_{t+1}(g) - selfpart), alpha_{t+1} = alpha'_{t+1} - leaky pi asum_{t+1}
-            const float sp0 = pw0 * a0 * inv_as_a, sp1 = pw1 * a1 * inv_as_b;
-            const float an0 = up0 - cpx * asu_a, an1 = up1 - cpx * asu_b;
-            const float g0 = gsa * b0, g1 = gsb * b1;
-            gamma_add_a(aGM0 + (fsx >> 16), g0 * sp0);
-            gamma_add_a(aGM0 + (fsx & 0xffffu), g0 * fmaxf(an0 - sp0, 0.f));
-            gamma_add_a(aGM1 + (fsx >> 16), g1 * sp1);
-            gamma_add_a(aGM1 + (fsx & 0xffffu), g1 * fmaxf(an1 - sp1, 0.f));
-            sums[4] = fmaf(an0, b0, sums[4]);  // sum_g alpha_{t+1}(g) B_{t+1}(g) = 1 / c_{t+1}
-            sums[5] = fmaf(an1, b1, sums[5]);
-            sums[6] = fmaf(a0, o0, sums[6]);   // (t == 0: alpha'_0 . beta'_0)
-            sums[7] = fmaf(a1, o1, sums[7]);
-          }
-        };
-        float oa[4], ob[4];
-        one(fs.x, ws.x, cp.x, r.a[4 * j + 0], r.b[4 * j + 0], bo0[j].x, bo1[j].x, al0[j].x, al1[j].x, au0[j].x, au1[j].x, oa[0], ob[0]);
-        one(fs.y, ws.y, cp.y, r.a[4 * j + 1], r.b[4 * j + 1], bo0[j].y, bo1[j].y, al0[j].y, al1[j].y, au0[j].y, au1[j].y, oa[1], ob[1]);
-        one(fs.z, ws.z, cp.z, r.a[4 * j + 2], r.b[4 * j + 2], bo0[j].z, bo1[j].z, al0[j].z, al1[j].z, au0[j].z, au1[j].z, oa[2], ob[2]);
-        one(fs.w, ws.w, cp.w, r.a[4 * j + 3], r.b[4 * j + 3], bo0[j].w, bo1[j].w, al0[j].w, al1[j].w, au0[j].w, au1[j].w, oa[3], ob[3]);
-        u0[j] = f4{oa[0], oa[1], oa[2], oa[3]};
-        u1[j] = f4{ob[0], ob[1], ob[2], ob[3]};
-        fpk[j][0] = (fs.x & 0xffffu) | (fs.y << 16);
-        fpk[j][1] = (fs.z & 0xffffu) | (fs.w << 16);
+        sums[0] += hsum(u0[j]);
+        sums[1] += hsum(u1[j]);
+        sums[2] += hsum(cp[j] * u0[j]);
+        sums[3] += hsum(cp[j] * u1[j]);
       }
     }
-    block_sums(sums, aRed, wave, lane);  // its barrier also ends every wave's gathers of Y_t and completes gamma_t
+    f4 yc0[PV], yc1[PV];
+    if (GAMMA) {
+      sums[4] = dpart_a;
+      sums[5] = dpart_b;
+      // Behind the pass, first used behind the reduction: y_t (the l2 term of the derivative row; this CU read it a
+      // frame ago: L2), alpha'_t (likewise) and, from HBM, alpha'_{t-1} and y_{t-1}
+      const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        yc0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
+        yc1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+      }
+      request_alpha(LAST ? 0 : t - 1);
+      request_yn(t);
+    }
+    TC_PSTAMP(1, t, 3)
+    block_sums(sums, aRed, wave, lane);  // its barrier also ends every wave's gathers of Y_t
+    TC_PSTAMP(1, t, 4)
     const float n_a = sums[0] * inv_h, n_b = sums[1] * inv_h;
     const float inv_n_a = __builtin_amdgcn_rcpf(n_a), inv_n_b = __builtin_amdgcn_rcpf(n_b);
     const float bsum_a = sums[2] * inv_n_a, bsum_b = sums[3] * inv_n_b;
@@ -800,7 +894,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
           lds4_st(aGM1 + own16 + v * kPlane, mk4(0.f));
           const f4 g0 = sa * f4{(float)ga.x, (float)ga.y, (float)ga.z, (float)ga.w};
           const f4 g1 = sb * f4{(float)gb.x, (float)gb.y, (float)gb.z, (float)gb.w};
-          if (t == 0) {
+          if (LAST) {
             gs[0] += hsum(g0);
             gs[1] += hsum(g1);
           }
@@ -812,50 +906,88 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
           row_st(da, own16 + v * kPlane, p.d_vec, oa);
           row_st(db, own16 + v * kPlane, p.d_vec, ob);
         }
-      if (t == 0) {
+      const float as_a = vload_f32(fn0 + t), as_b = vload_f32(fn1 + t);
+      const float inv_as_a = __builtin_amdgcn_rcpf(as_a), inv_as_b = __builtin_amdgcn_rcpf(as_b);
+      if (LAST) {
         // [K] BetaGeneralFrameDebug(0): alpha'_0 . beta'_0 and sum(gamma_0) must both be ~1 per sequence;
-        // beta'_0 = c_0 U_0 / n_0 = c_1 U_0 / asum_0
-        block_sums(gs, aRed + kScrFinal, wave, lane);
+        // beta'_0 = c_0 U_0 / n_0 = c_1 U_0 / asum_0  (request_alpha(0) above left alpha'_0 in al)
+        float fin[4] = {gs[0], gs[1], 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < planes) {
+            fin[2] += hsum(al0[j] * u0[j]);
+            fin[3] += hsum(al1[j] * u1[j]);
+          }
+        block_sums(fin, aRed + kScrFinal, wave, lane);
         if (tid == 0) {
-          p.seq_ab[s0] = sums[6] * ca * inv_as_a;
-          p.seq_gsum[s0] = gs[0];
+          p.seq_ab[s0] = fin[2] * ca * inv_as_a;
+          p.seq_gsum[s0] = fin[0];
           if (valid1) {
-            p.seq_ab[s1] = sums[7] * cb * inv_as_b;
-            p.seq_gsum[s1] = gs[1];
+            p.seq_ab[s1] = fin[3] * cb * inv_as_b;
+            p.seq_gsum[s1] = fin[1];
           }
         }
         return;
       }
-      // c_t = c_{t+1} n_t / asum_t: the scale of the next frame's adds
+      // c_t = c_{t+1} n_t / asum_t: the scale of B_t in gamma_{t-1}'s adds below
       chat_a = ca * n_a * inv_as_a;
       chat_b = cb * n_b * inv_as_b;
     }
     // exp(y_{t-1}) overwrites exp(y_t) in place -- its readers (the per-state pass) are behind the reduction's
     // barrier -- and one more barrier publishes it to the Y update below
 #pragma unroll
-    for (int v = 0; v < PV; ++v)
-      if (4 * ((int)tid + kThreads * v) < Ps) {
-        put_exp2(kPB, own32, v, yn0[v], yn1[v]);
-        yc0[v] = yn0[v];
-        yc1[v] = yn1[v];
-      }
+    for (int v = 0; v < PV; ++v) {
+      if (4 * ((int)tid + kThreads * v) < Ps) put_exp2(kPB, own32, v, yn0[v], yn1[v]);
+    }
+    TC_PSTAMP(1, t, 5)
     __syncthreads();
-    // B_t = B'_t + leaky-sum; next frame's gather source Y_{t-1} = B_t * p_{t-1}(f)
+    TC_PSTAMP(1, t, 6)
+    // B_t = B'_t + leaky-sum, the next frame's gather source Y_{t-1} and self-loop terms; second phase: gamma_{t-1};
+    // then the next frame's first chunk requests and, behind them, B_t's history row (first phase: rows T-1 .. M+1)
+    // (unconditional for both planes: a conditional assignment would keep the old B alive through the whole frame)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (j < planes) {
-        bo0[j] = u0[j] * inv_n_a + bsum_a;
-        bo1[j] = u1[j] * inv_n_b + bsum_b;
-        const f2 p0 = lds2(kPB + 2u * (fpk[j][0] & 0xffffu)), p1 = lds2(kPB + 2u * (fpk[j][0] >> 16));
-        const f2 p2 = lds2(kPB + 2u * (fpk[j][1] & 0xffffu)), p3 = lds2(kPB + 2u * (fpk[j][1] >> 16));
-        own_st(kA0 + own32 + j * kPlane2, bo0[j] * f4{p0.x, p1.x, p2.x, p3.x}, bo1[j] * f4{p0.y, p1.y, p2.y, p3.y});
+    for (int j = 0; j < 2; ++j) {
+      bo0[j] = u0[j] * inv_n_a + bsum_a;
+      bo1[j] = u1[j] * inv_n_b + bsum_b;
+    }
+    // (first phase: the chunk requests first, so that the memory pipe works on them while the LDS does form_y's gathers;
+    // the gamma frames have no registers for that)
+    if (!GAMMA) {
+      load_chunk(q0, bbase, lane16, RES);
+      load_chunk(q1, bbase, lane16, RES + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    form_y(fs, ws);
+    if (GAMMA) {
+      gamma_block(t - 1, fs, ws, cp);
+      __builtin_amdgcn_sched_barrier(0);
+      load_chunk(q0, bbase, lane16, RES);
+      load_chunk(q1, bbase, lane16, RES + 1);
+    }
+    if (!GAMMA) {
+      if (t > M) {
+        const rsrc_t ha = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (j < planes) {
+            bst4(ha, own16 + j * kPlane, bo0[j]);
+            bst4(hb, own16 + j * kPlane, bo1[j]);
+          }
       }
+      request_yn(t - 1);  // the next frame's y row (HBM, unconditional: see the forward role): first used behind its pass
+    }
+    TC_PSTAMP(1, t, 7)
   };
 
   // ---- first phase: frames T-1 .. M, pure recursion; rows T .. M+1 stored
-  for (int t = T - 1; t >= M; --t) frame(t, std::integral_constant<int, RES1>(), std::false_type());
+  load_chunk(q0, bbase, lane16, RES1);
+  load_chunk(q1, bbase, lane16, RES1 + 1);
+  request_yn(T - 1);
+#ifndef TC_PAIR_NO_PURE
+  for (int t = T - 1; t >= M; --t) frame(t, std::integral_constant<int, RES1>(), std::false_type(), std::false_type());
+#endif
   {
-    // B_{M+1} left under frame M's walk unless M == T - 1 (row T); B_M goes to row T + 1; then the hand-off
+    // B_M goes to row T + 1; then the hand-off
     const rsrc_t ha = make_rsrc(hist0 + (int64_t)(T + 1) * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)(T + 1) * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -864,26 +996,42 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
         bst4(hb, own16 + j * kPlane, bo1[j]);
       }
   }
+  TC_PSTAMP(1, T + 1, 0)
   publish(q.sync + 4 + 2 * pair + 1, tid);
   const bool partner_ok = await(q.sync + 4 + 2 * pair, tid, aRed + kScrAwait);
+  TC_PSTAMP(1, T + 1, 1)
   {
-    // c_M = 1 / sum_g alpha_M(g) B_M(g), alpha_M = alpha'_M - leaky pi asum_M
-    const rsrc_t a0r = make_rsrc(hist0 + (int64_t)M * hist_step, hb0), a1r = make_rsrc(hist1 + (int64_t)M * hist_step, hb1);
+    // c_M = 1 / sum_g alpha_M(g) B_M(g), alpha_M = alpha'_M - leaky pi asum_M; then gamma_{M-1} (exp(y_{M-1}) is in LDS,
+    // B_M in bo)
+    request_alpha(M - 1);
+    u4 fs[2];
+    f4 ws[2], cp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fs[j] = bld4u(r_fs, own16, j * kPlane);
+      ws[j] = bld4(r_ws, own16, j * kPlane);
+      cp[j] = leaky * bld4(r_pi, own16, j * kPlane);
+    }
     const float asm_a = vload_f32(fn0 + M), asm_b = vload_f32(fn1 + M);
     float d[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       if (j < planes) {
-        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
-        d[0] += hsum((bld4(a0r, own16, j * kPlane) - cp * asm_a) * bo0[j]);
-        d[1] += hsum((bld4(a1r, own16, j * kPlane) - cp * asm_b) * bo1[j]);
+        d[0] += hsum((au0[j] - cp[j] * asm_a) * bo0[j]);
+        d[1] += hsum((au1[j] - cp[j] * asm_b) * bo1[j]);
       }
     block_sums(d, aRed + kScrDot, wave, lane);
     chat_a = __builtin_amdgcn_rcpf(d[0]);
     chat_b = __builtin_amdgcn_rcpf(d[1]);
+    gamma_block(M - 1, fs, ws, cp);
   }
-  // ---- second phase: frames M-1 .. 0 with gamma_t
-  for (int t = M - 1; t >= 0; --t) frame(t, std::integral_constant<int, RES2>(), std::true_type());
+  // ---- second phase: frames M-1 .. 0: the derivative row of frame t, gamma_{t-1}
+  load_chunk(q0, bbase, lane16, RES2);
+  load_chunk(q1, bbase, lane16, RES2 + 1);
+#ifndef TC_PAIR_NO_GAMMA
+  for (int t = M - 1; t >= 1; --t) frame(t, std::integral_constant<int, RES2>(), std::true_type(), std::false_type());
+  frame(0, std::integral_constant<int, RES2>(), std::true_type(), std::true_type());
+#endif
   if (!partner_ok && tid == 0) {
     p.seq_ab[s0] = __builtin_nanf("");
     if (valid1) p.seq_ab[s1] = __builtin_nanf("");
@@ -891,13 +1039,13 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
 }
 
 #ifndef TC_PAIR_RF1
-#define TC_PAIR_RF1 4
+#define TC_PAIR_RF1 2
 #endif
 #ifndef TC_PAIR_RF2
 #define TC_PAIR_RF2 2
 #endif
 #ifndef TC_PAIR_RB1
-#define TC_PAIR_RB1 4
+#define TC_PAIR_RB1 2
 #endif
 #ifndef TC_PAIR_RB2
 #define TC_PAIR_RB2 0
@@ -913,10 +1061,12 @@ __global__ __launch_bounds__(kThreads) void den_tied_pair_kernel(const DenParams
   const uint32_t ticket = __builtin_amdgcn_readfirstlane(*reinterpret_cast<lds_u *>(q.aRed + kScrTicket));
   const int pair = (int)(ticket >> 1);
   if (pair >= q.npairs) return;
-  if ((ticket & 1u) == 0u)
-    pair_forward<PV, ACCUM, TC_PAIR_RF1, TC_PAIR_RF2>(p, q, pair);
-  else
-    pair_backward<PV, ACCUM, TC_PAIR_RB1, TC_PAIR_RB2>(p, q, pair);
+#ifndef TC_PAIR_ONLY_BWD
+  if ((ticket & 1u) == 0u) pair_forward<PV, ACCUM, TC_PAIR_RF1, TC_PAIR_RF2>(p, q, pair);
+#endif
+#ifndef TC_PAIR_ONLY_FWD
+  if ((ticket & 1u) != 0u) pair_backward<PV, ACCUM, TC_PAIR_RB1, TC_PAIR_RB2>(p, q, pair);
+#endif
 }
 
 struct PairLds {
