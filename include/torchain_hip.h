@@ -82,6 +82,23 @@ int tc_supervision_create(tc_supervision **out, float weight, int32_t num_sequen
                           const int32_t *arc_begin, const int32_t *arc_ilabel, const float *arc_weight,
                           const int32_t *arc_nextstate, const float *final_weight);
 
+/* Merges the supervision FSTs of a minibatch's examples into the one acceptor tc_supervision_create takes: what the
+ * reference reaches natively through kaldi::nnet3::MergeChainExamples -> [K] chain::AppendSupervision
+ * (src/my_lib_example_rand.cpp:160).  Host memory only, no GPU needed.  The pieces arrive concatenated: piece k has
+ * piece_num_states[k] states and spans piece_num_frames[k] = num_sequences * frames_per_sequence frames; its CSR
+ * offsets (num_states + 1 entries, starting at 0) follow those of the pieces before it in `arc_begin`, its arcs and
+ * final weights likewise (nextstate local to the piece; +inf = not final).  fst::Concat + RmEpsilon + breadth-first
+ * renumbering: a final state f of piece k-1 receives copies of piece k's start arcs with weight w_f + arc weight and
+ * stops being final, piece k's start state disappears, states are numbered in time order.  The caller provides the
+ * output arrays (cap_states + 1 / cap_arcs entries; TC_ERR_WORKSPACE if too small: sum of the pieces' states, and
+ * sum of the arcs + for every boundary (final states before it) x (start arcs behind it), always suffice).
+ * TC_ERR_BAD_FST: a piece is not a connected acceptor whose paths all have piece_num_frames[k] arcs. */
+int tc_supervision_append(int32_t num_pieces, const int32_t *piece_num_states, const int32_t *piece_num_frames,
+                          const int32_t *arc_begin, const int32_t *arc_ilabel, const float *arc_weight,
+                          const int32_t *arc_nextstate, const float *final_weight, int64_t cap_states,
+                          int64_t cap_arcs, int32_t *out_num_states, int64_t *out_num_arcs, int32_t *out_arc_begin,
+                          int32_t *out_ilabel, float *out_weight, int32_t *out_nextstate, float *out_final);
+
 /* Replaces my_lib_supervision_free (src/my_lib.h:22). */
 void tc_supervision_free(tc_supervision *supervision);
 /* Replace my_lib_supervision_num_pdf / _num_sequence / _num_frame (src/my_lib.h:23-25). */

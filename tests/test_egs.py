@@ -57,6 +57,28 @@ def test_example_round_trip(kind, tol, dw):
     assert same_fst(s, r)
 
 
+def test_end2end_flag_across_a_read_buffer_boundary(tmp_path):
+    """``BufferedReader.peek(n)`` may return a single byte: with the '<' of the newer-Kaldi ``<End2End>`` token as the
+    last byte of an 8192-byte buffer block a two-byte look-ahead saw only '<', left the token unread and failed with
+    "bad FST magic" -- about one new-format example in 8192, ending the epoch of a sequential archive.  The key is
+    padded so that the token straddles the block boundary for every alignment in turn."""
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    eg = make_example(fst, 9, seed=3, n_seq=2)
+    blob = kw.chain_example(eg, e2e_flag=True)
+    at = blob.index(b"<End2End>")
+    path = str(tmp_path / "e2e.ark")
+    for shift in (0, 1, 2):  # '<' at offsets 8191, 8190 and 8189 of the file
+        pad = 8191 - shift - at - 2  # "key SPACE \0 B" precede the object
+        key = "k" * (pad - 1)
+        with open(path, "wb") as f:
+            f.write(key.encode() + b" " + b"\0B" + blob)
+        with open(path, "rb") as f:
+            assert f.read(8192)[8191 - shift:8192 - shift] == b"<"
+        got = list(egs.iter_rspecifier("ark:" + path))
+        assert len(got) == 1 and got[0][0] == key
+        assert same_fst(got[0][1]["outputs"][0]["supervision"], eg["outputs"][0]["supervision"])
+
+
 def test_malformed_examples_are_refused():
     fst = synth.random_den_fst(20, 3, 10, seed=2)
     blob = kw.chain_example(make_example(fst, 4, seed=1))
@@ -147,6 +169,82 @@ def test_rand_reader_batches_by_length(tmp_path):
     rd.reset()
     assert sum(1 for _ in rd) == 6
     assert [tuple(b) for b in rd._key_batch] != first  # reshuffled
+
+
+def test_rand_reader_prefetches_one_batch_ahead(tmp_path):
+    """RandExample prepares the next minibatch on a background thread while the current one is in use; the batches it
+    delivers are those of the synchronous reader, in the same order, also across reset()."""
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    lengths = [5] * 7 + [8] * 4 + [11]
+    keyed, ark, scp = _write_set(tmp_path, fst, lengths)
+    io.print_key_length("scp:" + scp, scp + ".len")
+    a, b = io.RandExample(scp, seed=3, batchsize=3), io.RandExample(scp, seed=3, batchsize=3, prefetch=False)
+    for epoch in range(2):
+        n = 0
+        while a.next():
+            assert b.next()
+            if n + 1 < a.n_batch:
+                assert a._pending is not None and a._pending[0] == n + 1  # the look-ahead is under way (or done)
+            else:
+                assert a._pending is None
+            sa, sb = a._cur["outputs"][0]["supervision"], b._cur["outputs"][0]["supervision"]
+            assert same_fst(sa, sb) and sa.num_sequences == sb.num_sequences
+            np.testing.assert_array_equal(a._cur["inputs"][0]["features"], b._cur["inputs"][0]["features"])
+            n += 1
+        assert not b.next() and n == a.n_batch
+        a.reset()
+        b.reset()
+
+
+def test_native_merge_equals_the_numpy_statement_and_meets_its_time_bound():
+    """``tc_supervision_append`` (the library's host-side AppendSupervision; the reference merges natively,
+    src/my_lib_example_rand.cpp:160) against the numpy statement of the same algorithm: identical arrays on random
+    merges (several sequences per piece, final weights, pieces whose states are NOT numbered in time order); and a
+    64 x 150 minibatch with ~10 arcs per frame merges in <= 5 ms (round 2's Python loops: ~1 s; the loss it feeds: ~1 ms)."""
+    import time
+
+    fst = synth.random_den_fst(400, 8, 200, seed=1)
+
+    def identical(x, y):
+        return (x.num_states == y.num_states and np.array_equal(x.arc_begin, y.arc_begin) and np.array_equal(x.ilabel, y.ilabel)
+                and np.array_equal(x.nextstate, y.nextstate) and np.array_equal(x.arc_weight, y.arc_weight)
+                and np.array_equal(x.final, y.final) and (x.weight, x.num_sequences, x.frames_per_sequence, x.label_dim)
+                == (y.weight, y.num_sequences, y.frames_per_sequence, y.label_dim))
+
+    def scrambled(sup, seed):
+        """the same acceptor with its non-start states renumbered at random"""
+        rng = np.random.default_rng(seed)
+        perm = np.concatenate([[0], 1 + rng.permutation(sup.num_states - 1)])  # old -> new
+        inv = np.argsort(perm)
+        deg = np.diff(sup.arc_begin)[inv]
+        ab = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        idx = np.concatenate([np.arange(sup.arc_begin[o], sup.arc_begin[o + 1]) for o in inv]).astype(np.int64)
+        return synth.SupFst(sup.weight, sup.num_sequences, sup.frames_per_sequence, sup.label_dim, sup.num_states, ab,
+                            sup.ilabel[idx], sup.arc_weight[idx], perm[sup.nextstate[idx]].astype(np.int32), sup.final[inv])
+
+    for seed in range(8):
+        pieces = [synth.random_supervision(fst, 1 + (i % 2), 12, 3, seed=seed * 10 + i, final_weights=(seed % 2 == 0))
+                  for i in range(5)]
+        if seed >= 4:
+            pieces = [scrambled(p, seed * 7 + i) for i, p in enumerate(pieces)]
+        assert identical(egs.append_supervisions(pieces), egs.append_supervisions_numpy(pieces)), seed
+    # refused, not mis-merged: a piece with paths of unequal lengths
+    bad = synth.random_supervision(fst, 1, 12, 3, seed=99)
+    nx = bad.nextstate.copy()
+    nx[0] = int(bad.nextstate[bad.arc_begin[nx[0]]])  # skip a frame
+    broken = synth.SupFst(bad.weight, 1, 12, bad.label_dim, bad.num_states, bad.arc_begin, bad.ilabel, bad.arc_weight, nx, bad.final)
+    with pytest.raises(egs.EgsFormatError):
+        egs.append_supervisions([bad, broken])
+    big = [synth.random_supervision(fst, 1, 150, 10, seed=100 + i) for i in range(64)]
+    assert 9.0 <= np.mean([len(p.ilabel) / 150.0 for p in big]) <= 11.0
+    egs.append_supervisions(big)
+    best = 1e9
+    for _ in range(7):
+        t0 = time.perf_counter()
+        merged = egs.append_supervisions(big)
+        best = min(best, time.perf_counter() - t0)
+    assert merged.num_sequences == 64 and merged.frames_per_sequence == 150
+    assert best <= 5e-3, "64 x 150 merge took %.2f ms" % (best * 1e3)
 
 
 def test_committed_fixture(oracle):

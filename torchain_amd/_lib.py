@@ -54,6 +54,8 @@ def _load():
     L.tc_den_graph_num_pdfs.argtypes = [vp]
     L.tc_den_graph_initial_probs.restype = C.c_int
     L.tc_den_graph_initial_probs.argtypes = [vp, vp]
+    L.tc_supervision_append.restype = C.c_int
+    L.tc_supervision_append.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.tc_den_graph_prepare.restype = C.c_int
     L.tc_den_graph_prepare.argtypes = [vp, C.c_int]
     L.tc_den_graph_stats.restype = C.c_int

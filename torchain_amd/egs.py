@@ -49,8 +49,11 @@ class _Reader:
         return b
 
     def peek(self, n=1):
-        b = self.f.peek(n)[:n] if hasattr(self.f, "peek") else None
-        if b is None:
+        """The next ``n`` bytes without consuming them.  ``BufferedReader.peek`` returns only what is left in its
+        buffer -- possibly ONE byte at a block boundary -- so a short answer is completed by read + seek where the
+        stream can seek; callers on pipes must not ask for more than one byte."""
+        b = self.f.peek(n)[:n] if hasattr(self.f, "peek") else b""
+        if len(b) < n and (not hasattr(self.f, "seekable") or self.f.seekable()):
             pos = self.f.tell()
             b = self.f.read(n)
             self.f.seek(pos)
@@ -196,7 +199,9 @@ def _read_supervision(r):
     T = r.int32()
     r.expect("<LabelDim>")
     P = r.int32()
-    if r.peek(2) == b"<E":  # later Kaldi: <End2End> flag
+    # later Kaldi: <End2End> flag.  One byte decides: the FST that follows otherwise starts with its magic number
+    # 2125659606 = d6 fd b2 7e, never '<' (and a buffered reader's peek may hold a single byte at a block boundary).
+    if r.peek(1) == b"<":
         r.expect("<End2End>")
         if r.boolean():
             raise EgsFormatError("end-to-end (e2e) supervisions are outside this path (SURVEY.md section 8a caveat 3)")
@@ -338,25 +343,41 @@ def iter_rspecifier(rspec):
 
 
 # ---- merging ([K] MergeChainExamples / AppendSupervision) ----------------------------------------------------
+def _state_times(n_states, src, dst, start_ids, max_time):
+    """Time (distance from its piece's start state) of every state of a set of time-sorted acceptors held in common
+    arrays: one predecessor per state (any: all paths into a state are equally long), then pointer doubling --
+    log2(max_time) numpy passes instead of a Python loop over states.  ``src`` / ``dst`` are the arcs' end points."""
+    pred = np.full(n_states, n_states, np.int32)
+    pred[dst] = src  # (whichever of a state's predecessors is written last: all are equally far from the start)
+    is_start = np.zeros(n_states, bool)
+    is_start[start_ids] = True
+    if np.any(is_start & (pred < n_states)):
+        raise EgsFormatError("supervision start state has incoming arcs")
+    if np.any(~is_start & (pred == n_states)):
+        raise EgsFormatError("supervision FST is not connected / not time-sorted")
+    anc = np.where(is_start, np.arange(n_states, dtype=np.int32), pred)   # roots point at themselves
+    depth = (~is_start).astype(np.int32)
+    for _ in range(max(1, int(max_time)).bit_length()):  # after k rounds a state has jumped 2^k levels
+        depth += depth[anc]
+        anc = anc[anc]
+    if not np.all(is_start[anc]) or np.any(depth[dst] != depth[src] + 1):
+        raise EgsFormatError("supervision FST paths have unequal lengths")
+    return depth.astype(np.int64)
+
+
 def _fst_state_times(sup):
-    times = np.full(sup.num_states, -1, np.int64)
-    times[0] = 0
-    for s in range(sup.num_states):
-        if times[s] < 0:
-            raise EgsFormatError("supervision FST is not connected / not time-sorted")
-        a0, a1 = sup.arc_begin[s], sup.arc_begin[s + 1]
-        nt = times[sup.nextstate[a0:a1]]
-        if np.any((nt >= 0) & (nt != times[s] + 1)):
-            raise EgsFormatError("supervision FST paths have unequal lengths")
-        times[sup.nextstate[a0:a1]] = times[s] + 1
-    return times
+    src = np.repeat(np.arange(sup.num_states, dtype=np.int64), np.diff(sup.arc_begin))
+    return _state_times(sup.num_states, src, sup.nextstate.astype(np.int64), np.array([0]), sup.num_states)
 
 
-def append_supervisions(sups):
+def append_supervisions_numpy(sups):
     """[K] AppendSupervision for examples of equal weight, frames-per-sequence and label-dim: the FSTs are
     concatenated (``fst::Concat``), epsilons removed -- every final state f of piece k-1 (final weight w_f) receives
     copies of piece k's start arcs with weight w_f + arc weight and stops being final; piece k's start state
-    disappears -- and states are renumbered breadth-first, i.e. in time order.  Returns one merged ``SupFst``."""
+    disappears -- and states are renumbered breadth-first, i.e. in time order.  Returns one merged ``SupFst``.
+
+    The numpy statement of ``append_supervisions`` (which runs natively in the library): all pieces live in common
+    arrays, the only Python loop runs over the pieces.  Kept as the independent check of the native merge in the tests."""
     if not sups:
         raise ValueError("nothing to merge")
     w, T, P = sups[0].weight, sups[0].frames_per_sequence, sups[0].label_dim
@@ -365,56 +386,105 @@ def append_supervisions(sups):
             raise EgsFormatError("cannot merge supervisions with different weight / frames / label-dim")
     if len(sups) == 1:
         return sups[0]
-    # global ids: piece 0 keeps all its states; later pieces drop their start state (id 0)
-    pieces = []
-    base = 0
-    for k, s in enumerate(sups):
-        times = _fst_state_times(s)
-        total = s.num_sequences * T
-        finals = np.flatnonzero(~np.isinf(s.final))
-        if np.any(times[finals] != total) or np.any(np.diff(s.arc_begin)[finals] != 0):
-            raise EgsFormatError("final states of a supervision must sit at the last frame and have no arcs")
-        if k > 0 and np.any(s.nextstate == 0):
-            raise EgsFormatError("supervision start state has incoming arcs")
-        gid = np.arange(s.num_states, dtype=np.int64) + base - (1 if k > 0 else 0)
-        pieces.append((s, times, finals, gid))
-        base += s.num_states - (1 if k > 0 else 0)
-    n_total = base
-    out_il, out_w, out_next, counts = [], [], [], np.zeros(n_total, np.int64)
+    K = len(sups)
+    nst = np.array([s.num_states for s in sups], np.int64)
+    narc = np.array([len(s.ilabel) for s in sups], np.int64)
+    soff = np.concatenate([[0], np.cumsum(nst)])            # raw global id of piece k's state 0
+    aoff = np.concatenate([[0], np.cumsum(narc)])
+    n_raw = int(soff[-1])
+    piece_of_state = np.repeat(np.arange(K), nst)
+    deg = np.concatenate([np.diff(s.arc_begin) for s in sups]).astype(np.int64)
+    src = np.repeat(np.arange(n_raw, dtype=np.int64), deg)
+    piece_of_arc = np.repeat(np.arange(K), narc)
+    dst = np.concatenate([s.nextstate for s in sups]).astype(np.int64) + soff[piece_of_arc]
+    il = np.concatenate([s.ilabel for s in sups]).astype(np.int32)
+    aw = np.concatenate([s.arc_weight for s in sups]).astype(np.float32)
+    fin = np.concatenate([s.final for s in sups]).astype(np.float32)
+    total = np.array([s.num_sequences * T for s in sups], np.int64)
+    times = _state_times(n_raw, src, dst, soff[:-1], int(total.max()) + 1)
+    is_final = ~np.isinf(fin)
+    if np.any(times[is_final] != total[piece_of_state[is_final]]) or np.any(deg[is_final] != 0):
+        raise EgsFormatError("final states of a supervision must sit at the last frame and have no arcs")
+    toff = np.concatenate([[0], np.cumsum(total)])[:-1]
+    gtime = times + toff[piece_of_state]
+    # states that survive: everything but the start states of pieces 1 .. K-1; new ids in (time, raw id) order
+    keep = np.ones(n_raw, bool)
+    keep[soff[1:-1]] = False
+    kept = np.flatnonzero(keep)
+    order = kept[np.argsort(gtime[kept], kind="stable")]
+    newid = np.full(n_raw, -1, np.int64)
+    newid[order] = np.arange(len(order))
+    n_total = len(order)
+    # arcs that stay: all but the start arcs of pieces 1 .. K-1
+    stay = keep[src]
+    m_src, m_il, m_w, m_dst = [newid[src[stay]]], [il[stay]], [aw[stay]], [newid[dst[stay]]]
+    # bridges: every final state of piece k-1 gets piece k's start arcs
+    for k in range(1, K):
+        f = np.flatnonzero(is_final[soff[k - 1]:soff[k]]) + soff[k - 1]
+        a0, a1 = aoff[k], aoff[k] + deg[soff[k]]
+        na = int(a1 - a0)
+        if len(f) == 0 or na == 0:
+            continue
+        nf = len(f)
+        m_src.append(np.broadcast_to(newid[f][:, None], (nf, na)).reshape(-1))
+        m_il.append(np.broadcast_to(il[a0:a1][None, :], (nf, na)).reshape(-1))
+        m_w.append((fin[f][:, None] + aw[a0:a1][None, :]).astype(np.float32).reshape(-1))
+        m_dst.append(np.broadcast_to(newid[dst[a0:a1]][None, :], (nf, na)).reshape(-1))
+    m_src = np.concatenate(m_src)
+    perm = np.argsort(m_src, kind="stable")  # by state; inside a state the order the pieces gave
+    arc_begin = np.zeros(n_total + 1, np.int64)
+    np.cumsum(np.bincount(m_src, minlength=n_total), out=arc_begin[1:])
     final = np.full(n_total, np.inf, np.float32)
-    order_time = np.zeros(n_total, np.int64)
-    rows = [[] for _ in range(n_total)]
-    toff = 0
-    for k, (s, times, finals, gid) in enumerate(pieces):
-        for st in range(1 if k > 0 else 0, s.num_states):
-            g = int(gid[st])
-            order_time[g] = toff + times[st]
-            for a in range(s.arc_begin[st], s.arc_begin[st + 1]):
-                rows[g].append((int(s.ilabel[a]), float(s.arc_weight[a]), int(gid[s.nextstate[a]])))
-        if k + 1 < len(pieces):
-            nxt, _, _, ngid = pieces[k + 1]
-            for f in finals:
-                g = int(gid[f])
-                for a in range(nxt.arc_begin[0], nxt.arc_begin[1]):
-                    rows[g].append((int(nxt.ilabel[a]), float(s.final[f]) + float(nxt.arc_weight[a]),
-                                    int(ngid[nxt.nextstate[a]])))
-        else:
-            final[gid[finals]] = s.final[finals]
-        toff += s.num_sequences * T
-    # breadth-first (time) order, stable inside a time
-    perm = np.argsort(order_time, kind="stable")
-    newid = np.empty(n_total, np.int64)
-    newid[perm] = np.arange(n_total)
-    arc_begin = [0]
-    for g in perm:
-        for (il, aw, nx) in rows[g]:
-            out_il.append(il)
-            out_w.append(aw)
-            out_next.append(int(newid[nx]))
-        arc_begin.append(len(out_il))
-    return SupFst(float(w), sum(s.num_sequences for s in sups), T, P, n_total, np.asarray(arc_begin, np.int32),
-                  np.asarray(out_il, np.int32), np.asarray(out_w, np.float32), np.asarray(out_next, np.int32),
-                  final[perm])
+    last = np.flatnonzero(is_final[soff[K - 1]:]) + soff[K - 1]
+    final[newid[last]] = fin[last]
+    return SupFst(float(w), int(sum(s.num_sequences for s in sups)), T, P, n_total, arc_begin.astype(np.int32),
+                  np.concatenate(m_il)[perm].astype(np.int32), np.concatenate(m_w)[perm].astype(np.float32),
+                  np.concatenate(m_dst)[perm].astype(np.int32), final)
+
+
+def append_supervisions(sups):
+    """[K] AppendSupervision (see ``append_supervisions_numpy``) through the library's ``tc_supervision_append``: the
+    reference merges natively too (``src/my_lib_example_rand.cpp:160``).  Host memory only."""
+    import ctypes as C
+
+    from ._lib import lib
+
+    if not sups:
+        raise ValueError("nothing to merge")
+    w, T, P = sups[0].weight, sups[0].frames_per_sequence, sups[0].label_dim
+    for s in sups:
+        if (s.weight, s.frames_per_sequence, s.label_dim) != (w, T, P):
+            raise EgsFormatError("cannot merge supervisions with different weight / frames / label-dim")
+    if len(sups) == 1:
+        return sups[0]
+    K = len(sups)
+    nst = np.array([s.num_states for s in sups], np.int32)
+    frames = np.array([s.num_sequences * T for s in sups], np.int32)
+    ab = np.ascontiguousarray(np.concatenate([s.arc_begin for s in sups]), np.int32)
+    il = np.ascontiguousarray(np.concatenate([s.ilabel for s in sups]), np.int32)
+    aw = np.ascontiguousarray(np.concatenate([s.arc_weight for s in sups]), np.float32)
+    nx = np.ascontiguousarray(np.concatenate([s.nextstate for s in sups]), np.int32)
+    fin = np.ascontiguousarray(np.concatenate([s.final for s in sups]), np.float32)
+    # bound of the merged arcs: all arcs + (final states before a boundary) x (start arcs behind it)
+    n_fin = np.array([int(np.count_nonzero(~np.isinf(s.final))) for s in sups[:-1]], np.int64)
+    n_start = np.array([int(s.arc_begin[1]) if s.num_states > 0 else 0 for s in sups[1:]], np.int64)
+    cap_states, cap_arcs = int(nst.sum()), int(len(il) + int((n_fin * n_start).sum()))
+    o_ab = np.empty(cap_states + 1, np.int32)
+    o_il, o_w, o_nx = np.empty(cap_arcs, np.int32), np.empty(cap_arcs, np.float32), np.empty(cap_arcs, np.int32)
+    o_fin = np.empty(cap_states, np.float32)
+    n_states, n_arcs = C.c_int32(0), C.c_int64(0)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = lib.tc_supervision_append(K, p(nst), p(frames), p(ab), p(il), p(aw), p(nx), p(fin), cap_states, cap_arcs,
+                                   C.cast(C.byref(n_states), C.c_void_p), C.cast(C.byref(n_arcs), C.c_void_p),
+                                   p(o_ab), p(o_il), p(o_w), p(o_nx), p(o_fin))
+    if rc == -2:
+        raise EgsFormatError("a supervision FST is not a connected acceptor whose paths all have num_sequences * "
+                             "frames_per_sequence arcs, with arc-less final states at the last frame")
+    if rc != 0:
+        raise EgsFormatError("tc_supervision_append failed: %d" % rc)
+    ns, na = n_states.value, n_arcs.value
+    return SupFst(float(w), int(sum(s.num_sequences for s in sups)), T, P, ns, o_ab[:ns + 1].copy(), o_il[:na].copy(),
+                  o_w[:na].copy(), o_nx[:na].copy(), o_fin[:ns].copy())
 
 
 def merge_chain_examples(examples):

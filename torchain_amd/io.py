@@ -8,6 +8,7 @@ here too, on top of ``torchain_amd.egs`` (a Kaldi-free parser of the ``<Nnet3Cha
 """
 import ctypes as C
 import os
+from concurrent.futures import ThreadPoolExecutor
 from contextlib import contextmanager
 
 import numpy as np
@@ -260,11 +261,16 @@ class RandExample(Example):
     from the egs.  The shuffle uses NumPy's MT19937 seeded with ``seed``: the same generator as the reference's
     ``std::mt19937`` but not the same draw order as ``std::shuffle``, whose algorithm is not specified."""
 
-    def __init__(self, scp_path, seed, batchsize, len_file=""):
+    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True):
         assert os.path.exists(scp_path)
         self.scp_path = scp_path
         self.rspec = scp_path
         self.batchsize = int(batchsize)
+        # One minibatch ahead on a background thread (reading, parsing and merging release the GIL in file I/O, numpy
+        # and the library's tc_supervision_append): the training thread finds its next batch ready instead of
+        # re-opening and re-parsing every scp entry synchronously.
+        self._pool = ThreadPoolExecutor(max_workers=1) if prefetch else None
+        self._pending = None  # (position, future)
         self._rng = np.random.RandomState(int(seed))
         self._where = {key: (p, off) for key, p, off in _egs.read_scp(scp_path)}
         self._length_to_keys = {}
@@ -292,9 +298,28 @@ class RandExample(Example):
         self._rng.shuffle(self._key_batch)
 
     def reset(self):
+        self._drop_pending()
         self._pos = -1
         self._cur = None
         self._shuffle_keys()
+
+    def _drop_pending(self):
+        if self._pending is not None:
+            self._pending[1].cancel()
+            try:
+                self._pending[1].result()
+            except Exception:  # (a cancelled or failed look-ahead is simply not used)
+                pass
+            self._pending = None
+
+    def _load(self, pos):
+        batch = [_egs.read_scp_entry(*self._where[k]) for k in self._key_batch[pos]]
+        return _egs.merge_chain_examples(batch)
+
+    def __del__(self):
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=False)
 
     @property
     def n_batch(self):
@@ -309,6 +334,12 @@ class RandExample(Example):
         if self._pos >= len(self._key_batch):
             self._cur = None
             return False
-        batch = [_egs.read_scp_entry(*self._where[k]) for k in self._key_batch[self._pos]]
-        self._cur = _egs.merge_chain_examples(batch)
+        if self._pending is not None and self._pending[0] == self._pos:
+            fut, self._pending = self._pending[1], None
+            self._cur = fut.result()
+        else:
+            self._drop_pending()
+            self._cur = self._load(self._pos)
+        if self._pool is not None and self._pos + 1 < len(self._key_batch):
+            self._pending = (self._pos + 1, self._pool.submit(self._load, self._pos + 1))
         return True
