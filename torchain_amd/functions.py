@@ -27,9 +27,28 @@ from ._lib import check, lib
 class ChainResults:
     def __init__(self):
         self.data = torch.zeros(3)
-        # Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the
-        # reference, functions.py:88-89): filled by chain_loss when a xent branch is trained, else None
-        self.xent_objf = None
+        # Device-side originals: [objf, l2_term, weight] as the kernels left them (float32[3]) and Kaldi's
+        # cross-entropy objective sum(xent_output * xent_deriv) (float64[1]; [K] nnet-chain-training.cc, a TODO in
+        # the reference, functions.py:88-89).  The data-parallel wrapper reduces THESE (one collective, no host
+        # round trip); ``xent_objf`` is read from the device only when somebody asks for it.
+        self._dev = None
+        self._xent_dev = None
+        self._xent_scale = 1.0
+        self._xent_host = None
+        self._defer_host_copy = False  # set by chain_loss_data_parallel: the one D2H follows the all-reduce
+
+    @property
+    def xent_objf(self):
+        """Kaldi's cross-entropy objective, or None without a xent branch.  Lazy: the value stays on the device
+        until it is read (one 8-byte D2H), so a training step has no second host sync."""
+        if self._xent_host is None and self._xent_dev is not None:
+            self._xent_host = float(self._xent_dev.item()) * self._xent_scale
+        return self._xent_host
+
+    @xent_objf.setter
+    def xent_objf(self, value):
+        self._xent_host = value
+        self._xent_dev = None
 
     def __repr__(self):
         return "ChainResults(loss=%f, objf=%f, l2_term=%f, weight=%lf)" % (
@@ -45,15 +64,21 @@ class ChainResults:
         return None if self.xent_objf is None else -self.xent_objf / float(self.data[2])
 
 
-_workspaces = {}
+_workspaces = {}  # (device, stream) -> workspace, most recently used last
+_MAX_WORKSPACES = 4  # per process: a C3 workspace is 1.3 GB, and streams come and go
 
 
 def _workspace(device, stream, nbytes):
+    """The caller's workspace for (device, stream): reused from step to step, at most ``_MAX_WORKSPACES`` alive (least
+    recently used dropped; the caching allocator keeps a dropped block away from other streams until the work
+    queued on its own stream has passed)."""
     key = (device.index, stream)
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    _workspaces[key] = ws
+    while len(_workspaces) > _MAX_WORKSPACES:
+        _workspaces.pop(next(iter(_workspaces)))
     return ws
 
 
@@ -63,11 +88,12 @@ def _ptr(t):
 
 def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, nnet_output_deriv,
                                  xent_output_deriv, l2_regularize, leaky_hmm_coefficient, xent_regularize,
-                                 as_gradients=False):
+                                 as_gradients=False, holder=None):
     """The hot call: replaces ``my_lib.my_lib_ComputeChainObjfAndDeriv`` (``src/my_lib.h:33-42``).
     ``results`` is the CPU float[3] tensor of ``ChainResults`` and is filled on return.  ``as_gradients``: the two
     matrices come back as the reference's backward returns them (``functions.py:106-115``), ``-deriv`` and
-    ``-xent_regularize * xent_deriv`` (``tc_chain_objf_and_grad``)."""
+    ``-xent_regularize * xent_deriv`` (``tc_chain_objf_and_grad``).  ``holder``: the ``ChainResults`` that keeps the
+    device-side float[3]; when it asks for it (data-parallel use) the host copy is left to the caller."""
     assert nnet_output.is_cuda, "Only the HIP (ROCm) implementation is available"
     if nnet_output.dim() != 2 or nnet_output.stride(1) != 1 or nnet_output.dtype != torch.float32:
         raise ValueError("nnet_output must be a 2-D float32 tensor with unit column stride")
@@ -95,12 +121,21 @@ def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, n
             float(l2_regularize), float(leaky_hmm_coefficient), float(xent_regularize), _ptr(ws), ws.numel(),
             device.index, C.c_void_p(stream))
         check(rc, "tc_chain_objf_and_grad" if as_gradients else "tc_chain_objf_and_deriv")
-        results.copy_(res_dev)  # 12-byte D2H, the one host sync of the step (reference: >= 4)
+        if holder is not None:
+            holder._dev = res_dev
+        if holder is None or not holder._defer_host_copy:
+            results.copy_(res_dev)  # 12-byte D2H, the one host sync of the step (reference: >= 4)
     return results
 
 
 def xent_objective(xent_output, xent_output_deriv):
-    """sum(xent_output * xent_output_deriv) on the device (``tc_xent_objf``), as a Python float."""
+    """sum(xent_output * xent_output_deriv) on the device (``tc_xent_objf``), as a float64[1] DEVICE tensor: no host
+    sync (``ChainResults.xent_objf`` reads it when asked)."""
+    for t in (xent_output, xent_output_deriv):
+        if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.dtype != torch.float32:
+            raise ValueError("xent tensors must be 2-D float32 CUDA tensors with unit column stride")
+    if xent_output.shape != xent_output_deriv.shape:
+        raise ValueError("xent_input and its derivative must have the same shape")
     device = xent_output.device
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -110,7 +145,7 @@ def xent_objective(xent_output, xent_output_deriv):
                               _ptr(xent_output_deriv), xent_output_deriv.stride(0), _ptr(out), _ptr(ws), ws.numel(),
                               device.index, C.c_void_p(stream))
         check(rc, "tc_xent_objf")
-        return float(out.item())
+        return out
 
 
 class _ChainLoss(Function):
@@ -127,16 +162,21 @@ class _ChainLoss(Function):
         use_xent = xent_input is not None and xent_regularize != 0.0
         xent_grad = torch.empty_like(xent_input, memory_format=torch.contiguous_format) if use_xent else None
         compute_chain_objf_and_deriv(den_graph, supervision, input.detach(), results.data, mmi_grad, xent_grad,
-                                     l2_regularize, leaky_hmm_coefficient, xent_regularize, as_gradients=True)
+                                     l2_regularize, leaky_hmm_coefficient, xent_regularize, as_gradients=True,
+                                     holder=results)
         ctx.mmi_grad = mmi_grad
         if use_xent:
             # sum(xent_output * xent_deriv) from the scaled matrix: the scale is one factor of every term
-            results.xent_objf = xent_objective(xent_input.detach(), xent_grad) / -float(xent_regularize)
+            results._xent_dev = xent_objective(xent_input.detach(), xent_grad)
+            results._xent_scale = 1.0 / -float(xent_regularize)
+            results._xent_host = None
             if not kaldi_way:  # the reference's second call (functions.py:96-103)
                 compute_chain_objf_and_deriv(den_graph, supervision, xent_input.detach(), results.data, mmi_grad,
                                              xent_grad, l2_regularize, leaky_hmm_coefficient, xent_regularize,
-                                             as_gradients=True)
+                                             as_gradients=True, holder=results)
             ctx.xent_grad = xent_grad
+        if results._defer_host_copy:
+            return input.new_zeros(1)  # (filled in behind the all-reduce: parallel.chain_loss_data_parallel)
         return input.new_tensor([float(results.loss)])
 
     @staticmethod
@@ -184,18 +224,22 @@ class _ChainLoss3d(Function):
         xe2d = to2d_hip(xent_input.detach()) if use_xent else None
         xent_grad = torch.empty_like(xe2d) if use_xent else None
         compute_chain_objf_and_deriv(den_graph, supervision, x2d, results.data, mmi_grad, xent_grad,
-                                     l2_regularize, leaky_hmm_coefficient, xent_regularize)
+                                     l2_regularize, leaky_hmm_coefficient, xent_regularize, holder=results)
         if use_xent:
-            results.xent_objf = xent_objective(xe2d, xent_grad)
+            results._xent_dev = xent_objective(xe2d, xent_grad)
+            results._xent_scale = 1.0
+            results._xent_host = None
         if use_xent and not kaldi_way:  # the reference's second call (functions.py:96-103)
             compute_chain_objf_and_deriv(den_graph, supervision, xe2d, results.data, mmi_grad, xent_grad,
-                                         l2_regularize, leaky_hmm_coefficient, xent_regularize)
+                                         l2_regularize, leaky_hmm_coefficient, xent_regularize, holder=results)
         ctx.mmi_grad = mmi_grad
         ctx.in_shape = tuple(input.shape)
         if use_xent:
             ctx.xent_grad = xent_grad
             ctx.xent_shape = tuple(xent_input.shape)
             ctx.xent_scale = float(xent_regularize)
+        if results._defer_host_copy:
+            return input.new_zeros(1)
         return input.new_tensor([float(results.loss)])
 
     @staticmethod
@@ -220,7 +264,14 @@ def _fusable(x):
 def chain_loss(input, den_graph, supervision,
                l2_regularize=0.0, leaky_hmm_coefficient=1e-5,
                xent_regularize=0.0, xent_input=None, kaldi_way=False):
-    results = ChainResults()
+    return _chain_loss_into(ChainResults(), input, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
+                            xent_regularize, xent_input, kaldi_way)
+
+
+def _chain_loss_into(results, input, den_graph, supervision, l2_regularize, leaky_hmm_coefficient, xent_regularize,
+                     xent_input, kaldi_way):
+    """``chain_loss`` with the ``ChainResults`` given (parallel.chain_loss_data_parallel passes one that defers the
+    host copy of the three floats until after its all-reduce)."""
     if _fusable(input) and (xent_input is None or _fusable(xent_input)):
         loss = _ChainLoss3d.apply(input, xent_input, results, den_graph, supervision,
                                   l2_regularize, leaky_hmm_coefficient, xent_regularize, kaldi_way)

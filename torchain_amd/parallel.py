@@ -16,7 +16,7 @@ over the gathered batch and ``parallel_train.py:26-75`` (per-device loss) is bro
 import numpy as np
 import torch
 
-from .functions import ChainResults, chain_loss
+from .functions import ChainResults, _chain_loss_into
 
 
 def shard_range(num_sequences, rank, world_size):
@@ -68,43 +68,66 @@ def shard_supervision_fst(sup, lo, hi):
 
 
 def all_reduce_results(results, group=None, device=None, even_if_alone=False):
-    """SUM-all-reduces ``results.data = [objf, l2_term, weight]`` over the process group in place (one
-    12-byte collective) and returns ``results``.  With the ``nccl`` backend (RCCL) the three floats
-    travel through a device tensor on ``device`` (default: current CUDA device).  A group of one rank is
-    a no-op unless ``even_if_alone`` (which lets a 1-GPU box exercise the RCCL branch)."""
+    """SUM-all-reduces ``[objf, l2_term, weight, xent_objf]`` over the process group -- ONE collective of four
+    float64 -- updates ``results`` in place and returns it.  With the ``nccl`` backend (RCCL) the buffer is built on
+    the device from the kernels' own outputs (``results._dev`` / ``results._xent_dev``: no host-to-device copy) and
+    one 32-byte device-to-host copy delivers the reduced values.  A group of one rank is a no-op unless
+    ``even_if_alone`` (which lets a 1-GPU box exercise the RCCL branch)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
+        _finish_host_copy(results)
         return results
     if dist.get_world_size(group) == 1 and not even_if_alone:
+        _finish_host_copy(results)
         return results
-    backend = dist.get_backend(group)
-    if backend == "nccl":
+    has_xent = results._xent_dev is not None or results._xent_host is not None
+    if dist.get_backend(group) == "nccl":
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        buf = results.data.to(dev)
+        buf = torch.zeros(4, dtype=torch.float64, device=dev)
+        if results._dev is not None:
+            buf[:3] = results._dev.to(dev)  # device to device
+        else:
+            buf[:3] = results.data.to(dev)
+        if results._xent_dev is not None:
+            buf[3:] = results._xent_dev.to(dev) * results._xent_scale
+        elif results._xent_host is not None:
+            buf[3] = results._xent_host
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        results.data.copy_(buf)
-        if getattr(results, "xent_objf", None) is not None:
-            xe = torch.tensor([results.xent_objf], dtype=torch.float64, device=dev)
-            dist.all_reduce(xe, op=dist.ReduceOp.SUM, group=group)
-            results.xent_objf = float(xe.item())
+        host = buf.cpu()  # the step's one device-to-host copy (32 bytes)
     else:
-        dist.all_reduce(results.data, op=dist.ReduceOp.SUM, group=group)
-        if getattr(results, "xent_objf", None) is not None:
-            xe = torch.tensor([results.xent_objf], dtype=torch.float64)
-            dist.all_reduce(xe, op=dist.ReduceOp.SUM, group=group)
-            results.xent_objf = float(xe.item())
+        _finish_host_copy(results)
+        host = torch.zeros(4, dtype=torch.float64)
+        host[:3] = results.data.double()
+        if has_xent:
+            host[3] = results.xent_objf
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    results.data.copy_(host[:3].float())
+    results._dev = None  # (the device copy holds this rank's share only)
+    results._defer_host_copy = False
+    if has_xent:
+        results.xent_objf = float(host[3])
     return results
+
+
+def _finish_host_copy(results):
+    if results._defer_host_copy and results._dev is not None:
+        results.data.copy_(results._dev)
+    results._defer_host_copy = False
 
 
 def chain_loss_data_parallel(input, den_graph, supervision, l2_regularize=0.0, leaky_hmm_coefficient=1e-5,
                              xent_regularize=0.0, xent_input=None, kaldi_way=False, group=None, even_if_alone=False):
     """``chain_loss`` on this rank's shard followed by the one all-reduce.  Returns
-    ``(loss, results)`` where ``results`` holds the GLOBAL ``[objf, l2_term, weight]`` and ``loss`` is a
-    tensor whose value is the global ``-objf/weight`` and whose backward is this rank's local
-    gradient (``-deriv``, exactly as the single-GPU wrapper; DDP then averages parameter grads)."""
-    loss, results = chain_loss(input, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
-                               xent_regularize, xent_input, kaldi_way)
+    ``(loss, results)`` where ``results`` holds the GLOBAL ``[objf, l2_term, weight]`` (and ``xent_objf``) and
+    ``loss`` is a tensor whose value is the global ``-objf/weight`` and whose backward is this rank's local
+    gradient (``-deriv``, exactly as the single-GPU wrapper; DDP then averages parameter grads).  The rank's own
+    results never visit the host: the kernels' device-side floats go into the collective and one copy brings the
+    reduced values back."""
+    results = ChainResults()
+    results._defer_host_copy = bool(input.is_cuda)
+    loss, results = _chain_loss_into(results, input, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
+                                     xent_regularize, xent_input, kaldi_way)
     all_reduce_results(results, group=group, device=input.device if input.is_cuda else None, even_if_alone=even_if_alone)
     with torch.no_grad():
         loss.copy_(results.loss)
@@ -114,6 +137,9 @@ def chain_loss_data_parallel(input, den_graph, supervision, l2_regularize=0.0, l
 def combine_results(list_of_results):
     """Host-side sum of per-shard ChainResults (what the all-reduce computes); for tests and logs."""
     out = ChainResults()
+    xe = [r.xent_objf for r in list_of_results]
     for r in list_of_results:
         out.data += r.data
+    if all(v is not None for v in xe) and xe:
+        out.xent_objf = float(sum(xe))
     return out
