@@ -1,0 +1,242 @@
+"""Parity holes closed in round 3 ("Next round" item 3) and the two-sequence kernel:
+
+* ``kaldi_way=False`` -- the reference's second call on ``xent_input`` (``torchain/functions.py:96-103``) -- against
+  the ORACLE run on ``xent_input`` (round 2 only compared the 3-D path with the 2-D path);
+* the FULL objective (numerator included) on peaky outputs against the float64 formulation and the oracle, with the
+  distance rule of test_gpu_peaky.py (round 2 ran peaky inputs through the denominator only);
+* phone-LM-structured graphs at full size: R1 at configs[1]'s 64 x 150, R3 (split by the library) at 16 x 150
+  (round 2: S <= 4, T <= 30);
+* ``parallel.chain_loss_data_parallel`` itself across TWO ranks (gloo between two processes that both compute on
+  device 0), so the product function -- not the oracle -- is what the ranks run;
+* the two-sequence kernel (den_tied_pair.hip, ``force_pair``) against the fused kernel and the oracle: odd batches,
+  T = 2, hub states, accumulate + l2, 300 sequences, C3's graph at T = 150.
+Tolerance: 1e-4 relative (north_star), as everywhere."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from torchain_amd import io, synth
+
+from helpers import hip_chain, hip_den, rel_err
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _to3d(a, B, T, P):
+    return torch.from_numpy(a.reshape(T, B, P).transpose(1, 2, 0).copy()).cuda()
+
+
+def _from3d(g, B, T, P):
+    return g.permute(2, 0, 1).reshape(T * B, P).cpu().numpy()
+
+
+@pytest.mark.parametrize("three_d", [True, False])
+def test_kaldi_way_false_is_the_objective_on_xent_input(oracle, three_d):
+    """torchain/functions.py:96-103: with ``kaldi_way=False`` the results and the gradient of ``input`` are those of a
+    second call whose nnet output is ``xent_input``; the gradient of ``xent_input`` is ``-xent_regularize`` times that
+    second call's xent derivative.  All of it against the oracle evaluated on ``xent_input``."""
+    from torchain_amd.functions import chain_loss
+
+    fst = synth.random_den_fst(200, 5, 90, seed=13)
+    B, T, P = 4, 23, 90
+    l2, leaky, xr = 1e-4, 0.05, 0.1
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, B, T, 3, seed=4, weight=0.5, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(B, T, P, seed=5)
+    xe = synth.random_nnet_output(B, T, P, seed=6)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, xe, l2, leaky, want_xent=True)  # the SECOND call's input
+    den, hsup = io.DenominatorGraph(fst, P), io.Supervision.from_synth(sup)
+    if three_d:
+        x, x2 = _to3d(y, B, T, P).requires_grad_(True), _to3d(xe, B, T, P).requires_grad_(True)
+    else:
+        x, x2 = torch.from_numpy(y).cuda().requires_grad_(True), torch.from_numpy(xe).cuda().requires_grad_(True)
+    loss, res = chain_loss(x, den, hsup, l2, leaky, xr, x2, kaldi_way=False)
+    loss.backward()
+    got = res.data.numpy()
+    assert abs(got[0] - ref["objf"]) <= REL * abs(ref["objf"])
+    assert abs(got[1] - ref["l2_term"]) <= REL * abs(ref["l2_term"])
+    assert got[2] == ref["weight"]
+    assert abs(float(loss) - (-ref["objf"] / ref["weight"])) <= REL * abs(ref["objf"] / ref["weight"])
+    gx = _from3d(x.grad, B, T, P) if three_d else x.grad.cpu().numpy()
+    gxe = _from3d(x2.grad, B, T, P) if three_d else x2.grad.cpu().numpy()
+    assert rel_err(gx, -ref["deriv"], floor=0.5) <= REL          # MMI gradient: replaced by the second call's
+    assert rel_err(gxe, -xr * ref["xent_deriv"], floor=0.05) <= REL
+
+
+@pytest.mark.parametrize("scale", [5.0, 10.0])
+def test_full_objective_on_peaky_outputs(oracle, scale):
+    """objf, l2_term and the whole derivative (numerator + denominator + l2) on y ~ N(0, scale^2), T = 150, against the
+    float64 log-semiring formulation; the distance to the Kaldi-style fp32 oracle is bounded by the oracle's own
+    distance to that truth (test_gpu_peaky.py's rule: at scale 10 the oracle drifts by 3e-4, the HIP path does not)."""
+    from oracle import independent_f64 as ind
+
+    fst = synth.config_den_fst("C2")
+    S, T, P = 2, 150, fst.num_pdfs
+    l2, leaky = 5e-5, 0.1
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 3, seed=9, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, P, seed=21, scale=scale)
+    assert np.abs(y).max() < 30.0 * (scale / 5.0)  # (scale 5: inside the exp clamp; scale 10: a few rows beyond)
+    truth = ind.chain_objf_and_deriv(fst, g.initial_probs(), sup, np.clip(y, -30.0, 30.0), l2, leaky)
+    truth_deriv = truth["deriv"] + sup.weight * l2 * (np.clip(y, -30, 30) - y)  # the l2 term sees the unclamped y
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, l2, leaky)
+    out = hip_chain(fst, sup, y, l2=l2, leaky=leaky)
+    res = out["results"]
+    truth_l2 = -0.5 * sup.weight * l2 * float((y.astype(np.float64) ** 2).sum())
+    assert abs(res[0] - truth["objf"]) <= REL * abs(truth["objf"])
+    assert abs(res[1] - truth_l2) <= REL * abs(truth_l2)
+    assert res[2] == truth["weight"] == S * T
+    assert np.abs(out["deriv"] - truth_deriv).max() <= 2e-5       # absolute: posteriors live in [0, 1]
+    assert np.abs(out["deriv"] - ref["deriv"]).max() <= np.abs(ref["deriv"] - truth_deriv).max() + 2e-5
+    assert abs(res[0] - ref["objf"]) <= REL * abs(ref["objf"])
+
+
+@pytest.mark.parametrize("name,S", [("R1", 64), ("R3", 16)])
+def test_phone_lm_graphs_at_full_size(oracle, name, S):
+    """Graphs with the structure of a real chain den.fst (pruned phone LM x topology x tree; in-degrees 1 .. ~130): R1
+    at configs[1]'s batch of 64 x 150 frames, R3 -- whose empty-history states the library splits into 9681
+    chain-structured ones (16 states per thread) -- at 16 x 150; full objective vs the oracle."""
+    c = synth.CONFIGS[name]
+    fst = synth.config_den_fst(name)
+    T, P = c["T"], c["P"]
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 3, seed=9, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, P, seed=1240)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, c["l2"], c["leaky"], want_xent=True)
+    out = hip_chain(fst, sup, y, l2=c["l2"], leaky=c["leaky"], xent=True)
+    assert out["graph"].stats()["tied"] == 1
+    res = out["results"]
+    assert abs(res[0] - ref["objf"]) <= REL * abs(ref["objf"]), (res, ref["results"])
+    assert abs(res[1] - ref["l2_term"]) <= REL * abs(ref["l2_term"])
+    assert res[2] == ref["weight"] == S * T
+    assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+    assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL
+
+
+# ---- chain_loss_data_parallel across two ranks -----------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, S, T, P, out_dir):
+    """One rank: its shard of the sequences through parallel.chain_loss_data_parallel on cuda:0 (both ranks share the
+    GPU of the test box; the collective travels over gloo, the path every backend but RCCL takes)."""
+    import torch.distributed as dist
+
+    from torchain_amd import parallel
+    from torchain_amd.synth import SupFst  # noqa: F401
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = np.load(os.path.join(out_dir, "inputs.npz"))
+        fst = synth.random_den_fst(120, 5, P, seed=71)
+        sup = synth.SupFst(float(d["w"]), S, T, P, int(d["nst"]), d["arc_begin"], d["ilabel"], d["arc_weight"], d["nextstate"], d["final"])
+        lo, hi = parallel.shard_range(S, rank, world)
+        y_local = np.ascontiguousarray(parallel.shard_rows(torch.from_numpy(d["y"]), S, lo, hi).numpy())
+        xe_local = np.ascontiguousarray(parallel.shard_rows(torch.from_numpy(d["xe"]), S, lo, hi).numpy())
+        sup_local = parallel.shard_supervision_fst(sup, lo, hi)
+        den, hsup = io.DenominatorGraph(fst, P), io.Supervision.from_synth(sup_local)
+        B = hi - lo
+        x = _to3d(y_local, B, T, P).requires_grad_(True)
+        x2 = _to3d(xe_local, B, T, P).requires_grad_(True)
+        loss, res = parallel.chain_loss_data_parallel(x, den, hsup, 1e-3, 0.1, 0.1, x2, kaldi_way=True)
+        loss.backward()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), res=res.data.numpy(), xent=res.xent_objf, loss=float(loss),
+                 grad=_from3d(x.grad, B, T, P), xgrad=_from3d(x2.grad, B, T, P))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chain_loss_data_parallel_two_ranks(oracle, tmp_path):
+    """example/chime5/parallel_train.py:59-75 done right: every rank holds the GLOBAL [objf, l2_term, weight] and xent
+    objective after ONE all-reduce, its loss is the global -objf/weight, and its gradient rows are the full batch's
+    rows of its own sequences -- with the product function on both ranks."""
+    import torch.multiprocessing as mp
+
+    from torchain_amd import parallel
+
+    world, S, T, P = 2, 5, 12, 64  # uneven shards: 3 + 2 sequences
+    fst = synth.random_den_fst(120, 5, P, seed=71)
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 1, seed=72, weight=0.5, initial_probs=g.initial_probs())  # 1 path: single boundary states
+    y = synth.random_nnet_output(S, T, P, seed=73)
+    xe = torch.log_softmax(torch.from_numpy(synth.random_nnet_output(S, T, P, seed=74)), dim=1).numpy()
+    np.savez(str(tmp_path / "inputs.npz"), y=y, xe=xe, w=sup.weight, nst=sup.num_states, arc_begin=sup.arc_begin,
+             ilabel=sup.ilabel, arc_weight=sup.arc_weight, nextstate=sup.nextstate, final=sup.final)
+    mp.spawn(_dp_worker, args=(world, _free_port(), S, T, P, str(tmp_path)), nprocs=world, join=True)
+    full = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-3, 0.1, want_xent=True)
+    want_xent = float((xe.astype(np.float64) * full["xent_deriv"].astype(np.float64)).sum())
+    r = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(world)]
+    np.testing.assert_array_equal(r[0]["res"], r[1]["res"])  # every rank holds the same global results
+    assert r[0]["loss"] == r[1]["loss"]
+    assert abs(r[0]["res"][0] - full["objf"]) <= REL * abs(full["objf"])
+    assert abs(r[0]["res"][1] - full["l2_term"]) <= REL * abs(full["l2_term"])
+    assert r[0]["res"][2] == full["weight"]
+    assert abs(float(r[0]["xent"]) - want_xent) <= REL * abs(want_xent) and float(r[0]["xent"]) == float(r[1]["xent"])
+    assert abs(r[0]["loss"] - (-full["objf"] / full["weight"])) <= REL * abs(full["objf"] / full["weight"])
+    for k in range(world):
+        lo, hi = parallel.shard_range(S, k, world)
+        want = parallel.shard_rows(torch.from_numpy(full["deriv"]), S, lo, hi).numpy()
+        wantx = parallel.shard_rows(torch.from_numpy(full["xent_deriv"]), S, lo, hi).numpy()
+        assert rel_err(r[k]["grad"], -want, floor=0.5) <= REL
+        assert rel_err(r[k]["xgrad"], -0.1 * wantx, floor=0.05) <= REL
+
+
+# ---- the two-sequence kernel -------------------------------------------------------------------------------
+def _pair_vs_fused(oracle, kernel_family, fst, S, T, leaky, seed, l2=0.0, accumulate=False, with_oracle=True):
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=seed)
+    kernel_family("no_pair")
+    kernel_family("no_phase_split")
+    graph = io.DenominatorGraph(fst, fst.num_pdfs)
+    a = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    kernel_family("no_pair", 0)
+    kernel_family("force_pair")
+    b = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    c = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    assert a["status"] == 0 and b["status"] == 0
+    assert b["logprob"] == c["logprob"] and np.array_equal(b["deriv"], c["deriv"])  # reproducible bit for bit
+    assert abs(a["logprob"] - b["logprob"]) <= 1e-6 * abs(a["logprob"])
+    assert rel_err(b["deriv"], a["deriv"]) <= 2e-5
+    if with_oracle:
+        ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=leaky, deriv_weight=1.0)
+        want = ref["deriv"] - l2 * y + (0.25 if accumulate else 0.0)
+        assert abs(b["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+        assert rel_err(b["deriv"], want) <= REL
+        rows = b["deriv"] + l2 * y - (0.25 if accumulate else 0.0)
+        assert np.abs(rows.sum(axis=1, dtype=np.float64) - 1.0).max() <= 1e-4  # [K]: sum_pdf gamma_t = 1
+
+
+@pytest.mark.parametrize("case", ["even", "odd", "two_frames", "one_sequence", "accumulate_l2"])
+def test_two_sequence_kernel_small_graph(oracle, kernel_family, case):
+    fst = synth.random_den_fst(256, 6, 100, seed=5)
+    S, T, leaky, kw = {"even": (4, 20, 0.1, {}), "odd": (5, 7, 1e-5, {}), "two_frames": (2, 2, 0.1, {}),
+                       "one_sequence": (1, 3, 0.1, {}), "accumulate_l2": (6, 11, 0.1, dict(l2=5e-5, accumulate=True))}[case]
+    _pair_vs_fused(oracle, kernel_family, fst, S, T, leaky, seed=1, **kw)
+
+
+def test_two_sequence_kernel_hub_states_and_two_planes(oracle, kernel_family):
+    """R1 (phone-LM structure: secondary rows of hub states go through LDS slots, folded by the owner lane) and a
+    3000-state graph (one plane of positions: the second plane's loads fall outside their descriptors)."""
+    _pair_vs_fused(oracle, kernel_family, synth.config_den_fst("R1"), 6, 20, 0.1, seed=7)
+    _pair_vs_fused(oracle, kernel_family, synth.random_den_fst(3000, 8, 1500, seed=6), 7, 30, 0.1, seed=6)
+
+
+@pytest.mark.parametrize("leaky", [0.1, 1e-5])
+def test_two_sequence_kernel_c3_graph_t150(oracle, kernel_family, leaky):
+    _pair_vs_fused(oracle, kernel_family, synth.config_den_fst("C3"), 9, 150, leaky, seed=8)
+
+
+def test_two_sequence_kernel_more_workgroups_than_cus(oracle, kernel_family):
+    """300 sequences = 300 workgroups on 256 CUs: pairs are formed by ticket, so the partner of a running workgroup is
+    always one that has started or is the next to start."""
+    _pair_vs_fused(oracle, kernel_family, synth.config_den_fst("C3"), 300, 40, 0.1, seed=10, with_oracle=False)

@@ -1,7 +1,7 @@
 """The N > 1 path on CPU: two processes, gloo backend.  Each rank owns a contiguous shard of the
 sequences, evaluates the chain objective on its shard (here with the CPU oracle standing in for the
 per-GPU HIP call -- the oracle is the checker, the thing under test is the sharding and the
-collective), then ONE all-reduce of (objf, l2_term, weight) must reproduce the full-batch result, and
+collective), then ONE all-reduce of (objf, l2_term, weight, xent_objf) must reproduce the full-batch result, and
 each rank's derivative rows must equal the corresponding rows of the full-batch derivative."""
 import os
 import socket
@@ -41,7 +41,9 @@ def _worker(rank, world, port, S, T, out_dir):
         local = pyoracle.compute_chain_objf_and_deriv(g, sup_local, y_local, 1e-3, 0.1)
         res = ChainResults()
         res.data[:] = torch.from_numpy(local["results"])
+        res.xent_objf = 1.5 + rank  # (a stand-in: the fourth value of the one collective)
         parallel.all_reduce_results(res)
+        assert res.xent_objf == 1.5 + 2.5
         np.save(os.path.join(out_dir, "res%d.npy" % rank), res.data.numpy())
         np.save(os.path.join(out_dir, "deriv%d.npy" % rank), local["deriv"])
     finally:
