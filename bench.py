@@ -239,15 +239,18 @@ def main():
         hsup = io.Supervision.from_synth(sup)
         res = ChainResults()
         compute_chain_objf_and_deriv(graph, hsup, y, res.data, deriv, None, l2, cfg["leaky"], 0.0)
-        local3 = res.data.to(dev)
+        # (parallel.all_reduce_results' buffer: four float64 -- objf, l2_term, weight, xent objective -- built on the
+        # device; no xent branch here, so the fourth is 0)
+        local3 = torch.zeros(4, dtype=torch.float64, device=dev)
+        local3[:3] = res.data.to(dev)
         red = local3.clone()
         dist.all_reduce(red)
         torch.cuda.synchronize()
         total = red.cpu()
         assert float(total[2]) == float(world * S * T), (total, world, S, T)  # reduced weight = N * S * T
-        exchange = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "objf": float(total[0]),
-                    "l2_term": float(total[1]), "weight": float(total[2]),
-                    "loss": float(-total[0] / total[2])}
+        exchange = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "collectives_per_step": 1,
+                    "payload": "4 x float64", "objf": float(total[0]), "l2_term": float(total[1]),
+                    "weight": float(total[2]), "loss": float(-total[0] / total[2])}
 
     pending = [None]
 
@@ -259,7 +262,7 @@ def main():
     def step():
         den_step()
         if dist is not None:
-            # 12 bytes over xGMI.  Nothing on the GPU needs the result (it feeds logging), so it is issued
+            # 32 bytes over xGMI.  Nothing on the GPU needs the result (it feeds logging), so it is issued
             # asynchronously and the next step's kernel runs under it; the previous step's reduction is
             # waited for first, the last one before the timer stops.
             drain()
@@ -349,7 +352,7 @@ def main():
         }
         if exchange is not None:
             out["exchange"] = exchange
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # (rank 0, at every N: the other ranks have left their timed region)
             base, ref = cpu_baseline(fst, cfg, y_np, min(args.cpu_seqs, S))
             out["cpu_baseline"] = base
             # the oracle's outputs on the sample against the timed kernel's, same y (rows of the sample's

@@ -119,7 +119,14 @@ int tc_supervision_prepare(tc_supervision *supervision, int device, void *stream
 /* Bytes of device scratch the calls below need for this problem size (alpha history etc.; for batches of at most
  * 128 sequences of graphs on the on-chip tied kernel also a second history of the same size: such batches run the
  * forward and the backward recursion of a sequence on two CUs at once -- inside the call, forking to a per-device
- * side stream and joining `stream` again, which HIP-graph capture follows). */
+ * side stream and joining `stream` again, which HIP-graph capture follows).
+ * Sizes, with S sequences, T frames, Hs = graph states rounded up (tied on-chip graphs: to whole planes of 4096):
+ *   on-chip graphs          4 (T + 1) S Hs                     the alpha history  (1.27 GB at 256 x 150 x 8192)
+ *     tied, Hs <= 8192      + 4 S Hs + ~80 (T + 2) S bytes      one more row, the two-sequence form's normalisers
+ *     tied, S <= 128        + 4 (T + 1) S Hs                    the second history of the two-CU form
+ *   graphs beyond LDS       4 (T + 1) S' H + 8 S' H + 4 S' P    S' = S rounded up to 64 (streamed path)
+ *                           + 4 T S' P if that is <= 1 GB       exp(y) of every frame, transposed once (else per frame)
+ * plus a few KB of per-sequence scalars. */
 int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);
 
 /* Replaces my_lib_ComputeChainObjfAndDeriv (src/my_lib.h:33-42, src/my_lib_chain.cpp:104-136), i.e.

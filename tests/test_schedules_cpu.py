@@ -92,3 +92,14 @@ def test_phone_lm_graph_near_the_state_limit_stays_on_chip():
     stats = io.DenominatorGraph(fst, fst.num_pdfs).stats()
     assert stats["tied"] == 1 and 0 < stats["lds_bytes"] <= 160 * 1024 + 1024  # (lds_bytes is quoted for T = 256)
     assert stats["fwd_rows"] >= fst.num_states and stats["bwd_rows"] == fst.num_states
+
+
+def test_split_graph_that_does_not_fit_goes_back_to_the_general_kernel():
+    """A graph that is tied only after state splitting, whose split version (9500 work states -> 16 states per thread,
+    next to 12000 pdfs) fits no owner-computes LDS layout: the ORIGINAL 5000-state graph is tried on the general
+    on-chip kernel -- which it fits -- before the streamed kernels (~8x slower per arc) get it; and the schedules built
+    for it replay exactly."""
+    fst = synth.nearly_tied_den_fst(5000, 6, 12000, seed=3, fraction=0.9)
+    check_graph(fst, 0)
+    stats = io.DenominatorGraph(fst, fst.num_pdfs).stats()
+    assert 0 < stats["lds_bytes"] <= 160 * 1024 and stats["fwd_rows"] >= fst.num_states

@@ -66,9 +66,10 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.gs = (float *)take((size_t)S * 4);
   w.fail = (int32_t *)take(256);
   w.scalar = (double *)take(4096);  // also the stamp area of diagnostic builds
-  // streamed path: exp(y) of every frame, transposed once and used by both passes, when that is at most 4 GB
-  // (else one frame at a time, recomputed by the backward pass)
-  w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)4 << 30) ? T : 1;
+  // streamed path: exp(y) of every frame, transposed once and used by both passes, when that is at most 1 GB
+  // (else one frame at a time, recomputed by the backward pass: 2-7 % slower, measured; the cap keeps the workspace
+  // of exactly the largest graphs from growing by gigabytes -- include/torchain_hip.h states the sizes)
+  w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)1 << 30) ? T : 1;
   w.big_expy = big_P ? (float *)take((size_t)w.big_exp_frames * Sp * big_P * sizeof(float)) : nullptr;
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
@@ -286,7 +287,7 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   // When the denominator leaves CUs idle (small batches) the numerator's recursion runs beside it on a side
   // stream, leaving its posteriors in the supervision's staging area; the scatter follows the denominator.
   SideStreams *ss = nullptr;
-  rc = side_streams(&ss);
+  rc = side_streams(stream, &ss);
   if (rc != TC_OK) return rc;
   if ((deriv || xent) && den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
     std::lock_guard<std::recursive_mutex> lock(ss->enqueue);
@@ -294,13 +295,22 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
     TC_HIP_CHECK(hipEventRecord(ss->num_fork, stream));
     TC_HIP_CHECK(hipStreamWaitEvent(ss->num_side, ss->num_fork, 0));
     rc = launch_num(np, ss->num_side);
-    if (rc != TC_OK) return rc;
-    TC_HIP_CHECK(hipEventRecord(ss->num_join, ss->num_side));
-    rc = launch_den(dp, stream);
-    if (rc != TC_OK) return rc;
-    TC_HIP_CHECK(hipStreamWaitEvent(stream, ss->num_join, 0));
+    if (rc == TC_OK) rc = launch_den(dp, stream);
+    // Join the side stream also when something failed after the fork: the caller sees an error and may free or reuse
+    // the workspace and the supervision, which the numerator kernel could still be reading or writing -- and the
+    // supervision's pool slot must learn of its last reader before it can be handed out again.
+    hipError_t e = hipEventRecord(ss->num_join, ss->num_side);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, ss->num_join, 0);
+    if (rc != TC_OK || e != hipSuccess) {
+      (void)supervision_mark_use(sup, device, stream);
+      if (rc != TC_OK) return rc;
+      TC_HIP_CHECK(e);
+    }
     rc = launch_num_scatter(np, stream);
-    if (rc != TC_OK) return rc;
+    if (rc != TC_OK) {
+      (void)supervision_mark_use(sup, device, stream);
+      return rc;
+    }
   } else {
     rc = launch_den(dp, stream);
     if (rc != TC_OK) return rc;

@@ -312,7 +312,7 @@ inline size_t pair_stamp_bytes(int T) { return ((size_t)2 * kWaves * (T + 2) * 8
 int64_t big_small_floats(int H, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_num_scatter(const NumParams &p, hipStream_t stream);
-// Per-device side streams and fork / join events (made on first use; the hot path only records and waits):
+// Side streams and fork / join events per (device, caller stream) (made on first use; the hot path only records and waits):
 // `den_side` carries the backward recursion of the two-CU form (den_tied_split.hip), `num_side` the numerator when
 // the denominator leaves CUs idle (api.cpp).
 struct SideStreams {
@@ -321,7 +321,7 @@ struct SideStreams {
   int num_cus = 0;
   std::recursive_mutex enqueue;  // one caller at a time records / waits on the events (a wait binds to the latest record)
 };
-int side_streams(SideStreams **out);  // den_graph.cpp
+int side_streams(hipStream_t stream, SideStreams **out);  // den_graph.cpp
 // CUs a denominator launch of S sequences occupies (two per sequence in the two-CU form, all for the streamed path)
 int den_cus_used(const DenParams &p, int num_cus);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,

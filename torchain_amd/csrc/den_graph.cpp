@@ -33,18 +33,38 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes) {
   return e;
 }
 
-int side_streams(SideStreams **out) {
+// One set of side streams and fork / join events per (device, CALLER stream): callers on different streams neither
+// share events (a wait binds to the latest record) nor serialise on one mutex.  Created on first use, all or nothing.
+int side_streams(hipStream_t stream, SideStreams **out) {
   static std::mutex mu;
-  static std::map<int, SideStreams> ctx;
+  static std::map<std::pair<int, hipStream_t>, SideStreams> ctx;
   int device = 0;
   TC_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mu);
-  SideStreams &c = ctx[device];
+  SideStreams &c = ctx[std::make_pair(device, stream)];
   if (!c.den_side) {
-    TC_HIP_CHECK(hipDeviceGetAttribute(&c.num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    for (hipEvent_t *e : {&c.fork, &c.join, &c.num_fork, &c.num_join}) TC_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    TC_HIP_CHECK(hipStreamCreateWithFlags(&c.num_side, hipStreamNonBlocking));
-    TC_HIP_CHECK(hipStreamCreateWithFlags(&c.den_side, hipStreamNonBlocking));
+    int num_cus = 0;
+    TC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device));
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+    if (e != hipSuccess) {  // nothing half-built stays behind: the next call starts again
+      for (hipEvent_t x : ev)
+        if (x) (void)hipEventDestroy(x);
+      for (hipStream_t x : st)
+        if (x) (void)hipStreamDestroy(x);
+      g_last_hip_error = (int)e;
+      return TC_ERR_HIP;
+    }
+    c.fork = ev[0];
+    c.join = ev[1];
+    c.num_fork = ev[2];
+    c.num_join = ev[3];
+    c.num_side = st[0];
+    c.den_side = st[1];
+    c.num_cus = num_cus;
   }
   *out = &c;
   return TC_OK;
@@ -116,6 +136,7 @@ static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
 
 int build_schedules(tc_den_graph *g) {
   bool want_big = debug_flag(kDbgForceStreamed) || g->H > kMaxIndex || g->P > kMaxIndex;
+  bool split_made = false;  // tied only thanks to make_work_graph
   // ---- the tied path: on the FST as it is, or on its tied-ified work graph
   std::vector<char> special;
   {
@@ -128,9 +149,27 @@ int build_schedules(tc_den_graph *g) {
     g->copy_first.resize(g->H + 1);
     std::iota(g->copy_first.begin(), g->copy_first.end(), 0);
     bool tied = !debug_flag(kDbgForceGeneral) && detect_tied(g, &special);
-    if (!tied && !debug_flag(kDbgForceGeneral) && !debug_flag(kDbgNoSplit) && make_work_graph(g)) tied = detect_tied(g, &special);
+    if (!tied && !debug_flag(kDbgForceGeneral) && !debug_flag(kDbgNoSplit) && make_work_graph(g)) {
+      tied = detect_tied(g, &special);
+      split_made = tied;
+    }
     g->tied = tied;
   }
+  auto restore_unsplit = [&]() {
+    g->work_H = g->H;
+    g->work_src = g->arc_src;
+    g->work_dst = g->arc_dst;
+    g->work_pdf = g->arc_pdf;
+    g->work_prob = g->arc_prob;
+    g->work_pi = g->initial_probs;
+    g->copy_first.resize(g->H + 1);
+    std::iota(g->copy_first.begin(), g->copy_first.end(), 0);
+    g->tied = false;
+    g->tied_fs.clear();
+    g->tied_w.clear();
+    g->fwd = ScheduleHost();
+    g->bwd = ScheduleHost();
+  };
   if (!want_big && g->tied) {
     // Rows longer than kMaxRowLen spill into secondary rows, each with a private accumulator slot in LDS; a graph
     // with many popular states (real phone-LM graphs: in-degrees of a hundred and more) and close to the 16384-state
@@ -141,6 +180,34 @@ int build_schedules(tc_den_graph *g) {
         g->layout_ok = true;
         return TC_OK;
       }
+    if (split_made) {
+      // The graph became tied only through state splitting, and the enlarged work graph does not fit the owner-computes
+      // layouts.  Before it is given up to the streamed kernels (~8x slower per arc), the ORIGINAL graph gets its
+      // chance on the general on-chip kernel, which it may well fit.
+      std::vector<char> special_split = special;
+      std::vector<int32_t> ws = g->work_src, wd = g->work_dst, wp = g->work_pdf, cf = g->copy_first, tf = g->tied_f, ts = g->tied_s;
+      std::vector<float> wpr = g->work_prob, wpi = g->work_pi, tw = g->tied_w;
+      std::vector<uint32_t> tfs = g->tied_fs;
+      const int32_t wH = g->work_H;
+      restore_unsplit();
+      build_general(g);
+      g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
+      if (g->layout_ok) return TC_OK;
+      // no: back to the split graph for the streamed tied kernels
+      g->work_H = wH;
+      g->work_src.swap(ws);
+      g->work_dst.swap(wd);
+      g->work_pdf.swap(wp);
+      g->work_prob.swap(wpr);
+      g->work_pi.swap(wpi);
+      g->copy_first.swap(cf);
+      g->tied_f.swap(tf);
+      g->tied_s.swap(ts);
+      g->tied_w.swap(tw);
+      g->tied_fs.swap(tfs);
+      g->tied = true;
+      special.swap(special_split);
+    }
     want_big = true;  // tied but beyond the on-chip layouts: the streamed kernels keep the tied factorisation
   }
   if (!want_big) {

@@ -441,11 +441,13 @@ static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t
   DenParams pf = p;
   pf.deriv = nullptr;  // forward only
   int rc = launch_den_tied(pf, 0, stream);
+  if (rc == TC_OK) rc = launch_den_tied_backward_only(p, c->den_side);
+  // Join whatever reached the side stream, also on a failure: the caller sees an error and may free or reuse the
+  // workspace, which a kernel on the side stream could still be writing.
+  hipError_t e = hipEventRecord(c->join, c->den_side);
+  if (e == hipSuccess) e = hipStreamWaitEvent(stream, c->join, 0);
   if (rc != TC_OK) return rc;
-  rc = launch_den_tied_backward_only(p, c->den_side);
-  if (rc != TC_OK) return rc;
-  TC_HIP_CHECK(hipEventRecord(c->join, c->den_side));
-  TC_HIP_CHECK(hipStreamWaitEvent(stream, c->join, 0));
+  TC_HIP_CHECK(e);
   return launch_den_tied_combine(p, accumulate, c->num_cus, stream);
 }
 
@@ -479,7 +481,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   const int JV = p.L.JV, PV = p.L.PV;
   if (p.tied_fs != nullptr) {
     SideStreams *c = nullptr;
-    const int src = side_streams(&c);
+    const int src = side_streams(stream, &c);
     if (src != TC_OK) return src;
     if (pair_wanted(p, c->num_cus)) return launch_den_tied_pair(p, p.pair_extra_slots, accumulate, stream);
     if (split_wanted(p)) {
