@@ -34,6 +34,15 @@ extern "C" {
 typedef struct tc_den_graph tc_den_graph;     /* replaces the void* to kaldi::chain::DenominatorGraph */
 typedef struct tc_supervision tc_supervision; /* replaces the void* to kaldi::chain::Supervision      */
 
+/* Replaces my_lib_test_chain (src/my_lib.h:45, src/my_lib_chain.cpp:138-213), the reference's native self test: runs
+ * the full objective on a small synthetic problem on `device` and checks the properties its Kaldi tests assert
+ * (src/chain-supervision-test.hpp:239-341, 388-463).  Returns TC_OK, a negative TC_ERR_* if the library could not
+ * run, or the number of the property that failed: 1 weight = w * S * T; 2 objf <= 0 for a numerator inside the
+ * denominator; 3 derivative rows sum to ~0; 4 finite differences agree with the derivative; 5 the objective is the
+ * failure value -10 * weight.  report6 (nullable, host): objf, weight, worst |row sum|, predicted and observed change
+ * of objf under the test perturbation, l2_term.  A C-only integrator can validate an install with this one call. */
+int tc_self_test(int device, void *stream, float *report6);
+
 const char *tc_strerror(int code);
 int tc_version(void);
 int tc_last_hip_error(void);

@@ -240,3 +240,18 @@ def test_two_sequence_kernel_more_workgroups_than_cus(oracle, kernel_family):
     """300 sequences = 300 workgroups on 256 CUs: pairs are formed by ticket, so the partner of a running workgroup is
     always one that has started or is the next to start."""
     _pair_vs_fused(oracle, kernel_family, synth.config_den_fst("C3"), 300, 40, 0.1, seed=10, with_oracle=False)
+
+
+def test_native_self_test_entry():
+    """tc_self_test: the C-only counterpart of the reference's my_lib_test_chain (src/my_lib_chain.cpp:138-213) --
+    weight = w S T, objf <= 0 for a numerator inside the denominator, derivative rows sum to 0, finite differences."""
+    import ctypes as C
+
+    from torchain_amd._lib import lib
+
+    rep = (C.c_float * 6)()
+    rc = lib.tc_self_test(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.cast(rep, C.c_void_p))
+    objf, weight, worst_row, predicted, observed, l2_term = list(rep)
+    assert rc == 0, (rc, list(rep))
+    assert weight == 0.5 * 3 * 9 and objf < 0 and l2_term == 0.0
+    assert worst_row <= 1e-4 and abs(observed - predicted) <= 0.1 * abs(predicted) + 1e-4 and predicted != 0.0

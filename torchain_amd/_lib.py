@@ -56,6 +56,8 @@ def _load():
     L.tc_den_graph_initial_probs.argtypes = [vp, vp]
     L.tc_supervision_append.restype = C.c_int
     L.tc_supervision_append.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.tc_self_test.restype = C.c_int
+    L.tc_self_test.argtypes = [C.c_int, vp, vp]
     L.tc_den_graph_prepare.restype = C.c_int
     L.tc_den_graph_prepare.argtypes = [vp, C.c_int]
     L.tc_den_graph_stats.restype = C.c_int
