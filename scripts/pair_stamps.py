@@ -15,6 +15,7 @@ cfg = synth.CONFIGS[cfgname]
 S, T, P = cfg["S"], cfg["T"], cfg["P"]
 fst = synth.config_den_fst(cfgname)
 dev = torch.device("cuda", 0)
+check(lib.tc_debug_set(b"force_pair", 1), "force_pair")  # (the two-sequence form is opt-in)
 graph = io.DenominatorGraph(fst, P).prepare(dev)
 y = torch.randn(S * T, P, device=dev)
 deriv = torch.empty_like(y)

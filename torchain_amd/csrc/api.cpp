@@ -78,7 +78,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.fwd_norm = split ? (float *)take((size_t)S * (T + 2) * sizeof(float)) : nullptr;
   w.bwd_norm = split ? (float *)take((size_t)S * (T + 1) * sizeof(float)) : nullptr;
   w.pair_sync = pair ? (uint32_t *)take(pair_sync_bytes(S)) : nullptr;
-  w.pair_norm = pair ? (float *)take((size_t)2 * S * pair_norm_stride(T) * sizeof(float)) : nullptr;
+  w.pair_norm = pair ? (float *)take((size_t)2 * (S + 1) * pair_norm_stride(T) * sizeof(float)) : nullptr;  // (+ a spare row each)
   w.pair_stamps = pair ? (long long *)take(pair_stamp_bytes(T)) : nullptr;  // (the workspace's last block)
   w.total = off;
   return w;

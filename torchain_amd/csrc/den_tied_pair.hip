@@ -164,6 +164,15 @@ __device__ __forceinline__ void block_sums(float (&v)[N], uint32_t red, int wave
   }
 }
 
+// An opaque copy of a per-thread offset, made INSIDE a loop body: every address formed from it (offset + region base +
+// constant) is then formed inside the loop as well.  Formed from the loop-invariant original, the compiler hoists each
+// such sum into a register of its own -- a dozen of them in these kernels -- and, short of registers, spills them;
+// their reloads wait behind every store and HBM request in flight (den_tied_kernel.hip met the same with its tail).
+__device__ __forceinline__ uint32_t opq(uint32_t x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // the 4 consecutive positions a thread owns in one plane, both sequences, as they lie in LDS: {p0s0, p0s1, p1s0, p1s1},
 // {p2s0, p2s1, p3s0, p3s1}
 struct Own8 {
@@ -198,6 +207,7 @@ struct PairParams {
   int npairs;
   int norm_stride;    // floats per sequence in fwd_norm / bwd_norm (a multiple of 32: no 128-byte line is shared)
   uint32_t aGM, aSEC, aRed;  // LDS byte offsets: gamma [2][Ps], secondary-row slots, reduction scratch
+  uint32_t aY2;              // per-thread {sum y^2 of sequence 0, of sequence 1} (forward role: two registers less)
 };
 
 // reduction scratch, byte offsets from PairParams::aRed (which is 16-byte aligned)
@@ -268,8 +278,9 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   const float leaky = p.leaky;
   const int64_t hist_step = (int64_t)S * Hs;
   float *const hist0 = p.alpha_hist + (int64_t)s0 * Hs, *const hist1 = p.alpha_hist + (int64_t)s1 * Hs;
-  float *const fn0 = p.fwd_norm + (int64_t)s0 * q.norm_stride, *const fn1 = p.fwd_norm + (int64_t)s1 * q.norm_stride;
-  const float *const bn0 = p.bwd_norm + (int64_t)s0 * q.norm_stride, *const bn1 = p.bwd_norm + (int64_t)s1 * q.norm_stride;
+  // (an odd batch's phantom second sequence keeps its normalisers in the spare row S: no per-lane test per frame)
+  float *const fn0 = p.fwd_norm + (int64_t)s0 * q.norm_stride, *const fn1 = p.fwd_norm + (int64_t)(valid1 ? s1 : S) * q.norm_stride;
+  const float *const bn0 = p.bwd_norm + (int64_t)s0 * q.norm_stride, *const bn1 = p.bwd_norm + (int64_t)(valid1 ? s1 : S) * q.norm_stride;
   auto yrow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, bytes); };
   auto drow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, bytes); };
 
@@ -290,15 +301,19 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
       bst4(make_rsrc(hist0, hb0), own16 + j * kPlane, a);
       bst4(make_rsrc(hist1, hb1), own16 + j * kPlane, a);
     }
-  float y2a = 0.f, y2b = 0.f;
+  const uint32_t aY2 = q.aY2 + 8u * tid;  // this thread's running sums of y^2 (thread-private LDS: not two registers)
+  auto add_y2 = [&](float a, float b) __attribute__((always_inline)) {
+    const f2 old2 = lds2(aY2);
+    *reinterpret_cast<lds_f2 *>(aY2) = f2{old2.x + a, old2.y + b};
+  };
+  *reinterpret_cast<lds_f2 *>(aY2) = f2{0.f, 0.f};
   {
     const rsrc_t ya = yrow(0, s0, rb0), yb = yrow(0, s1, rb1);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
       if (4 * ((int)tid + kThreads * v) < Ps) {
         const f4 yp0 = row_ld(ya, own16 + v * kPlane, p.y_vec), yp1 = row_ld(yb, own16 + v * kPlane, p.y_vec);
-        y2a += hsum(yp0 * yp0);
-        y2b += hsum(yp1 * yp1);
+        add_y2(hsum(yp0 * yp0), hsum(yp1 * yp1));
         put_exp2(kPB, own32, v, yp0, yp1);
         lds4_st(aGM0 + own16 + v * kPlane, mk4(0.f));
         lds4_st(aGM1 + own16 + v * kPlane, mk4(0.f));
@@ -307,7 +322,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   }
   if (tid == 0) {
     fn0[0] = asum_a;
-    if (valid1) fn1[0] = asum_b;
+    fn1[0] = asum_b;
   }
   float inv_a = __builtin_amdgcn_rcpf(asum_a), inv_b = inv_a;
 
@@ -317,7 +332,6 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
                                      (int64_t)(__builtin_amdgcn_readfirstlane(frange.x) / kChunk) * (3 * 64 * 16),
                                  (uint32_t)(fnch + 4) * (3 * 64 * 16));
   const uint32_t *const fmask = p.fwd.masks + wave * p.fwd.mask_stride;
-  const int ffx0 = p.fwd.nfix ? p.fwd.fix_begin[tid] : 0, ffx1 = p.fwd.nfix ? p.fwd.fix_begin[tid + 1] : 0;
   const PairCommit frc{0, K, q.aSEC + 512u * (uint32_t)p.fwd.extra_first[wave]};
   constexpr int RESMAX = RES1 > RES2 ? RES1 : RES2;
   Chunk6 fres[RESMAX > 0 ? RESMAX : 1];
@@ -328,9 +342,17 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   float chat_a = 0.f, chat_b = 0.f;  // c^_t used by the fixed-point adds of the running frame
 
   // secondary rows of hub states: add the slots other lanes of this wave filled to the owner's row sums
-  auto fold = [&](Rows &r, const ScheduleDev &sd, int e0, int e1) __attribute__((always_inline)) {
+  auto fold = [&](Rows &r) __attribute__((always_inline)) {
+    if (p.fwd.nfix == 0) return;
+    // (buffer addressing: a flat load keeps a 64-bit per-lane pointer per table alive through the whole role)
+    const rsrc_t r_fb = make_rsrc(p.fwd.fix_begin, 4u * (kThreads + 1)), r_fx = make_rsrc(p.fwd.fix, 8u * (uint32_t)p.fwd.nfix);
+    const uint32_t t4 = opq(4u * tid);
+    const int e0 = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fb, (int)t4, 0, 0);
+    const int e1 = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fb, (int)t4, 4, 0);
     for (int e = e0; e < e1; ++e) {
-      const int2 f = sd.fix[e];
+      int2 f;
+      f.x = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fx, 8 * e, 0, 0);
+      f.y = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fx, 8 * e, 4, 0);
       const int k = 4 * (f.x / (4 * kThreads)) + (f.x & 3);
       const uint32_t src = q.aSEC + 512u * (uint32_t)((f.y - Hs - 4) >> 6) + 4u * (uint32_t)((f.y - Hs - 4) & 63);
       const float x0 = ldsf(src), x1 = ldsf(src + 256u);
@@ -349,23 +371,26 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   f4 yr0[PV], yr1[PV];  // y_t of the thread's pdfs
   f4 bt0[2] = {mk4(0.f), mk4(0.f)}, bt1[2] = {mk4(0.f), mk4(0.f)};  // B_t of the owned states
   auto request_y = [&](int t) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
     const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
-      yr0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-      yr1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+      yr0[v] = row_ld(ya, o16 + v * kPlane, p.y_vec);
+      yr1[v] = row_ld(yb, o16 + v * kPlane, p.y_vec);
     }
   };
   auto request_b = [&](int t) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
     const rsrc_t ba = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), bb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bt0[j] = bld4(ba, own16, j * kPlane);
-      bt1[j] = bld4(bb, own16, j * kPlane);
+      bt0[j] = bld4(ba, o16, j * kPlane);
+      bt1[j] = bld4(bb, o16, j * kPlane);
     }
   };
   // One frame t: alpha_t from alpha'_{t-1}; GAMMA: also gamma_{t-1} and its derivative row from B_t.
   auto frame = [&](int t, auto res_tag, auto gamma_tag) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
     constexpr int RES = decltype(res_tag)::value;
     constexpr bool GAMMA = decltype(gamma_tag)::value;
     TC_PSTAMP(0, t, 0)
@@ -386,21 +411,11 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     f4 ws[2], cpi[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      fs[j] = bld4u(r_fs, own16, j * kPlane);
-      ws[j] = bld4(r_ws, own16, j * kPlane);
+      fs[j] = bld4u(r_fs, o16, j * kPlane);
+      ws[j] = bld4(r_ws, o16, j * kPlane);
     }
     f4 yp0[PV], yp1[PV];
-    if (GAMMA) {
-      // y_{t-1} (the derivative row's l2 term) is read again rather than held in registers across the walk: the row
-      // was this CU's a frame ago (L2), and its first use is behind the pass and the reduction
-      const rsrc_t ya = yrow(t - 1, s0, rb0), yb = yrow(t - 1, s1, rb1);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) {
-        yp0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-        yp1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
-      }
-    }
-    fold(r, p.fwd, ffx0, ffx1);
+    fold(r);
     float sums[GAMMA ? 4 : 2];
 #pragma unroll
     for (int i = 0; i < (GAMMA ? 4 : 2); ++i) sums[i] = 0.f;
@@ -409,7 +424,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     for (int j = 0; j < 2; ++j) {
       v0[j] = v1[j] = mk4(0.f);
       if (j < planes) {
-        const Own8 al = own_ld(kA0 + own32 + j * kPlane2);  // alpha'_{t-1} of the owned states
+        const Own8 al = own_ld(kA0 + o32 + j * kPlane2);  // alpha'_{t-1} of the owned states
         const f4 al0 = seq0(al), al1 = seq1(al);
         // alpha_t(g) asum_{t-1} = p(f(g)) F(g) + p(s(g)) w_s alpha'_{t-1}(g); with B_t(g): the two parts are the
         // occupations of the forward-class arcs into g and of its self-loop in frame t-1
@@ -446,19 +461,29 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     }
     // pi: first touched behind the reduction, which hides its L2 trip
 #pragma unroll
-    for (int j = 0; j < 2; ++j) cpi[j] = bld4(r_pi, own16, j * kPlane);
-    // the next frame's B row (unconditional, index clamped: a conditional assignment would keep the old values alive
-    // through the whole frame)
-    if (GAMMA) request_b(t + 1 <= T ? t + 1 : T);
+    for (int j = 0; j < 2; ++j) cpi[j] = bld4(r_pi, o16, j * kPlane);
+    if (GAMMA) {
+      // y_{t-1} (the derivative row's l2 term) is read again rather than held in registers across the frame: the row
+      // was this CU's a frame ago (L2), and its first use is behind the reduction
+      const rsrc_t ya = yrow(t - 1, s0, rb0), yb = yrow(t - 1, s1, rb1);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        yp0[v] = row_ld(ya, o16 + v * kPlane, p.y_vec);
+        yp1[v] = row_ld(yb, o16 + v * kPlane, p.y_vec);
+      }
+      // the next frame's B row (unconditional, index clamped: a conditional assignment would keep the old values alive
+      // through the whole frame)
+      request_b(t + 1 <= T ? t + 1 : T);
+    }
     // the history row of frame t-1 (first phase), behind everything this frame still loads
     if (!GAMMA && t > 1) {
       const rsrc_t ha = make_rsrc(hist0 + (int64_t)(t - 1) * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)(t - 1) * hist_step, hb1);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (j < planes) {
-          const Own8 o = own_ld(kA0 + own32 + j * kPlane2);  // alpha'_{t-1} of the owned states: still in the gather buffer
-          bst4(ha, own16 + j * kPlane, seq0(o));
-          bst4(hb, own16 + j * kPlane, seq1(o));
+          const Own8 o = own_ld(kA0 + o32 + j * kPlane2);  // alpha'_{t-1} of the owned states: still in the gather buffer
+          bst4(ha, o16 + j * kPlane, seq0(o));
+          bst4(hb, o16 + j * kPlane, seq1(o));
         }
     }
     TC_PSTAMP(0, t, 3)
@@ -471,7 +496,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     for (int j = 0; j < 2; ++j)
       if (j < planes) {
         const f4 a0 = v0[j] + (leaky * cpi[j]) * asum_a, a1 = v1[j] + (leaky * cpi[j]) * asum_b;
-        own_st(kA0 + own32 + j * kPlane2, a0, a1);
+        own_st(kA0 + o32 + j * kPlane2, a0, a1);
         part_tot_a += hsum(a0);
         part_tot_b += hsum(a1);
       }
@@ -486,17 +511,17 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
 #pragma unroll
       for (int v = 0; v < PV; ++v)
         if (4 * ((int)tid + kThreads * v) < Ps) {
-          const u4 ga = lds4u(aGM0 + own16 + v * kPlane), gb = lds4u(aGM1 + own16 + v * kPlane);
-          lds4_st(aGM0 + own16 + v * kPlane, mk4(0.f));
-          lds4_st(aGM1 + own16 + v * kPlane, mk4(0.f));
+          const u4 ga = lds4u(aGM0 + o16 + v * kPlane), gb = lds4u(aGM1 + o16 + v * kPlane);
+          lds4_st(aGM0 + o16 + v * kPlane, mk4(0.f));
+          lds4_st(aGM1 + o16 + v * kPlane, mk4(0.f));
           f4 oa = (p.deriv_weight * sa) * f4{(float)ga.x, (float)ga.y, (float)ga.z, (float)ga.w} - p.l2_scale * yp0[v];
           f4 ob = (p.deriv_weight * sb) * f4{(float)gb.x, (float)gb.y, (float)gb.z, (float)gb.w} - p.l2_scale * yp1[v];
           if (ACCUM) {
-            oa += row_ld(da, own16 + v * kPlane, p.d_vec);
-            ob += row_ld(db, own16 + v * kPlane, p.d_vec);
+            oa += row_ld(da, o16 + v * kPlane, p.d_vec);
+            ob += row_ld(db, o16 + v * kPlane, p.d_vec);
           }
-          row_st(da, own16 + v * kPlane, p.d_vec, oa);
-          row_st(db, own16 + v * kPlane, p.d_vec, ob);
+          row_st(da, o16 + v * kPlane, p.d_vec, oa);
+          row_st(db, o16 + v * kPlane, p.d_vec, ob);
         }
       // c^_{t+1} = c_t asum_t / n_t
       chat_a = ca * asum_a * __builtin_amdgcn_rcpf(n_a);
@@ -508,14 +533,13 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
 #pragma unroll
       for (int v = 0; v < PV; ++v)
         if (4 * ((int)tid + kThreads * v) < Ps) {
-          y2a += hsum(yr0[v] * yr0[v]);
-          y2b += hsum(yr1[v] * yr1[v]);
-          put_exp2(kPB, own32, v, yr0[v], yr1[v]);
+          add_y2(hsum(yr0[v] * yr0[v]), hsum(yr1[v] * yr1[v]));
+          put_exp2(kPB, o32, v, yr0[v], yr1[v]);
         }
     }
     if (tid == 0) {
       fn0[t] = asum_a;
-      if (valid1) fn1[t] = asum_b;
+      fn1[t] = asum_b;
     }
     inv_a = __builtin_amdgcn_rcpf(asum_a);
     inv_b = __builtin_amdgcn_rcpf(asum_b);
@@ -570,7 +594,8 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
 #endif
 
   // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h); log-prob = log tot + sum_{t<T} log asum_t
-  float fin[4] = {part_tot_a, part_tot_b, y2a, y2b};
+  const f2 y2 = lds2(aY2);
+  float fin[4] = {part_tot_a, part_tot_b, y2.x, y2.y};
   block_sums(fin, aRed + kScrFinal, wave, lane);
   {
     // the asum_t this workgroup wrote (same CU: its own L1 / L2 path), summed as (double) logf like the fused kernel
@@ -643,8 +668,8 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   const float leaky = p.leaky;
   const int64_t hist_step = (int64_t)S * Hs;
   float *const hist0 = p.alpha_hist + (int64_t)s0 * Hs, *const hist1 = p.alpha_hist + (int64_t)s1 * Hs;
-  const float *const fn0 = p.fwd_norm + (int64_t)s0 * q.norm_stride, *const fn1 = p.fwd_norm + (int64_t)s1 * q.norm_stride;
-  float *const bn0 = p.bwd_norm + (int64_t)s0 * q.norm_stride, *const bn1 = p.bwd_norm + (int64_t)s1 * q.norm_stride;
+  const float *const fn0 = p.fwd_norm + (int64_t)s0 * q.norm_stride, *const fn1 = p.fwd_norm + (int64_t)(valid1 ? s1 : S) * q.norm_stride;
+  float *const bn0 = p.bwd_norm + (int64_t)s0 * q.norm_stride, *const bn1 = p.bwd_norm + (int64_t)(valid1 ? s1 : S) * q.norm_stride;
   auto yrow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, bytes); };
   auto drow = [&](int t, int s, uint32_t bytes) __attribute__((always_inline)) { return make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, bytes); };
   const float inv_h = 1.0f / (float)H;
@@ -663,9 +688,15 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
 
   auto fold = [&](Rows &r) __attribute__((always_inline)) {
     if (p.bwd.nfix == 0) return;
-    const int e0 = p.bwd.fix_begin[tid], e1 = p.bwd.fix_begin[tid + 1];
+    // (buffer addressing: a flat load keeps a 64-bit per-lane pointer per table alive through the whole role)
+    const rsrc_t r_fb = make_rsrc(p.bwd.fix_begin, 4u * (kThreads + 1)), r_fx = make_rsrc(p.bwd.fix, 8u * (uint32_t)p.bwd.nfix);
+    const uint32_t t4 = opq(4u * tid);
+    const int e0 = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fb, (int)t4, 0, 0);
+    const int e1 = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fb, (int)t4, 4, 0);
     for (int e = e0; e < e1; ++e) {
-      const int2 f = p.bwd.fix[e];
+      int2 f;
+      f.x = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fx, 8 * e, 0, 0);
+      f.y = (int)__builtin_amdgcn_raw_buffer_load_b32(r_fx, 8 * e, 4, 0);
       const int k = 4 * (f.x / (4 * kThreads)) + (f.x & 3);
       const uint32_t src = q.aSEC + 512u * (uint32_t)((f.y - Hs - 4) >> 6) + 4u * (uint32_t)((f.y - Hs - 4) & 63);
       const float x0 = ldsf(src), x1 = ldsf(src + 256u);
@@ -750,27 +781,33 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   f4 al0[2] = {mk4(0.f), mk4(0.f)}, al1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_{t-1}: gamma_{t-1} is formed at the end of frame t
   f4 au0[2] = {mk4(0.f), mk4(0.f)}, au1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_t
   auto request_yn = [&](int t) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
     const int tn = t > 0 ? t - 1 : 0;
     const rsrc_t ya = yrow(tn, s0, rb0), yb = yrow(tn, s1, rb1);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
-      yn0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-      yn1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+      yn0[v] = row_ld(ya, o16 + v * kPlane, p.y_vec);
+      yn1[v] = row_ld(yb, o16 + v * kPlane, p.y_vec);
     }
   };
-  // alpha'_{tl} -> al, alpha'_{tl+1} -> au (the second one was this CU's a frame ago: L2; it goes first)
-  auto request_alpha = [&](int tl) __attribute__((always_inline)) {
-    const rsrc_t u0r = make_rsrc(hist0 + (int64_t)(tl + 1) * hist_step, hb0), u1r = make_rsrc(hist1 + (int64_t)(tl + 1) * hist_step, hb1);
+  // alpha'_{tl} -> al (HBM: requested behind the pass), alpha'_{tl+1} -> au (this CU's a frame ago, L2: requested
+  // behind the derivative row, whose conversion needs the registers)
+  auto request_al = [&](int tl) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
     const rsrc_t a0r = make_rsrc(hist0 + (int64_t)tl * hist_step, hb0), a1r = make_rsrc(hist1 + (int64_t)tl * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      au0[j] = bld4(u0r, own16, j * kPlane);
-      au1[j] = bld4(u1r, own16, j * kPlane);
+      al0[j] = bld4(a0r, o16, j * kPlane);
+      al1[j] = bld4(a1r, o16, j * kPlane);
     }
+  };
+  auto request_au = [&](int tl) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
+    const rsrc_t u0r = make_rsrc(hist0 + (int64_t)(tl + 1) * hist_step, hb0), u1r = make_rsrc(hist1 + (int64_t)(tl + 1) * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      al0[j] = bld4(a0r, own16, j * kPlane);
-      al1[j] = bld4(a1r, own16, j * kPlane);
+      au0[j] = bld4(u0r, o16, j * kPlane);
+      au1[j] = bld4(u1r, o16, j * kPlane);
     }
   };
   float chat_a = 0.f, chat_b = 0.f;  // c^_{t+1}: the scale of B_{t+1} the fixed-point adds of gamma_t used
@@ -818,6 +855,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   // (LAST: frame 0, instantiated on its own -- an early exit inside the loop's frame would make every assignment of
   // the tail conditional and so keep last frame's values alive through the whole frame)
   auto frame = [&](int t, auto res_tag, auto gamma_tag, auto last_tag) __attribute__((always_inline)) {
+    const uint32_t o16 = opq(own16), o32 = opq(own32);
     constexpr int RES = decltype(res_tag)::value;
     constexpr bool GAMMA = decltype(gamma_tag)::value;
     constexpr bool LAST = decltype(last_tag)::value;
@@ -834,9 +872,15 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     f4 ws[2], cp[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      fs[j] = bld4u(r_fs, own16, j * kPlane);
-      ws[j] = bld4(r_ws, own16, j * kPlane);
-      cp[j] = leaky * bld4(r_pi, own16, j * kPlane);
+      fs[j] = bld4u(r_fs, o16, j * kPlane);
+      ws[j] = bld4(r_ws, o16, j * kPlane);
+      cp[j] = leaky * bld4(r_pi, o16, j * kPlane);
+    }
+    if (GAMMA) {
+      // the frame's HBM rows, behind the tables (in-order completion: the pass waits for the tables only): alpha'_{t-1}
+      // for gamma_{t-1} at the end of this frame, y_{t-1} for the exp(y) rewrite behind the derivative row
+      request_al(LAST ? 0 : t - 1);
+      request_yn(t);
     }
     fold(r);
     constexpr int NS = GAMMA ? 6 : 4;
@@ -861,15 +905,13 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
       sums[4] = dpart_a;
       sums[5] = dpart_b;
       // Behind the pass, first used behind the reduction: y_t (the l2 term of the derivative row; this CU read it a
-      // frame ago: L2), alpha'_t (likewise) and, from HBM, alpha'_{t-1} and y_{t-1}
+      // frame ago: L2)
       const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
 #pragma unroll
       for (int v = 0; v < PV; ++v) {
-        yc0[v] = row_ld(ya, own16 + v * kPlane, p.y_vec);
-        yc1[v] = row_ld(yb, own16 + v * kPlane, p.y_vec);
+        yc0[v] = row_ld(ya, o16 + v * kPlane, p.y_vec);
+        yc1[v] = row_ld(yb, o16 + v * kPlane, p.y_vec);
       }
-      request_alpha(LAST ? 0 : t - 1);
-      request_yn(t);
     }
     TC_PSTAMP(1, t, 3)
     block_sums(sums, aRed, wave, lane);  // its barrier also ends every wave's gathers of Y_t
@@ -878,8 +920,8 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     const float inv_n_a = __builtin_amdgcn_rcpf(n_a), inv_n_b = __builtin_amdgcn_rcpf(n_b);
     const float bsum_a = sums[2] * inv_n_a, bsum_b = sums[3] * inv_n_b;
     if (tid == 0) {
-      bn0[t] = 1.0f / inv_n_a;  // the normaliser actually applied
-      if (valid1) bn1[t] = 1.0f / inv_n_b;
+      bn0[t] = __builtin_amdgcn_rcpf(inv_n_a);  // the normaliser actually applied (its reciprocal is what B was scaled by)
+      bn1[t] = __builtin_amdgcn_rcpf(inv_n_b);
     }
     if (GAMMA) {
       const float ca = __builtin_amdgcn_rcpf(sums[4]), cb = __builtin_amdgcn_rcpf(sums[5]);  // c_{t+1}
@@ -889,28 +931,32 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
 #pragma unroll
       for (int v = 0; v < PV; ++v)
         if (4 * ((int)tid + kThreads * v) < Ps) {
-          const u4 ga = lds4u(aGM0 + own16 + v * kPlane), gb = lds4u(aGM1 + own16 + v * kPlane);
-          lds4_st(aGM0 + own16 + v * kPlane, mk4(0.f));
-          lds4_st(aGM1 + own16 + v * kPlane, mk4(0.f));
-          const f4 g0 = sa * f4{(float)ga.x, (float)ga.y, (float)ga.z, (float)ga.w};
-          const f4 g1 = sb * f4{(float)gb.x, (float)gb.y, (float)gb.z, (float)gb.w};
-          if (LAST) {
-            gs[0] += hsum(g0);
-            gs[1] += hsum(g1);
+          {  // (one sequence after the other: this is where the role's register use peaks)
+            const u4 ga = lds4u(aGM0 + o16 + v * kPlane);
+            lds4_st(aGM0 + o16 + v * kPlane, mk4(0.f));
+            const f4 g0 = sa * f4{(float)ga.x, (float)ga.y, (float)ga.z, (float)ga.w};
+            if (LAST) gs[0] += hsum(g0);
+            f4 oa = p.deriv_weight * g0 - p.l2_scale * yc0[v];
+            if (ACCUM) oa += row_ld(da, o16 + v * kPlane, p.d_vec);
+            row_st(da, o16 + v * kPlane, p.d_vec, oa);
           }
-          f4 oa = p.deriv_weight * g0 - p.l2_scale * yc0[v], ob = p.deriv_weight * g1 - p.l2_scale * yc1[v];
-          if (ACCUM) {
-            oa += row_ld(da, own16 + v * kPlane, p.d_vec);
-            ob += row_ld(db, own16 + v * kPlane, p.d_vec);
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            const u4 gb = lds4u(aGM1 + o16 + v * kPlane);
+            lds4_st(aGM1 + o16 + v * kPlane, mk4(0.f));
+            const f4 g1 = sb * f4{(float)gb.x, (float)gb.y, (float)gb.z, (float)gb.w};
+            if (LAST) gs[1] += hsum(g1);
+            f4 ob = p.deriv_weight * g1 - p.l2_scale * yc1[v];
+            if (ACCUM) ob += row_ld(db, o16 + v * kPlane, p.d_vec);
+            row_st(db, o16 + v * kPlane, p.d_vec, ob);
           }
-          row_st(da, own16 + v * kPlane, p.d_vec, oa);
-          row_st(db, own16 + v * kPlane, p.d_vec, ob);
         }
+      if (!LAST) request_au(t - 1);
       const float as_a = vload_f32(fn0 + t), as_b = vload_f32(fn1 + t);
       const float inv_as_a = __builtin_amdgcn_rcpf(as_a), inv_as_b = __builtin_amdgcn_rcpf(as_b);
       if (LAST) {
         // [K] BetaGeneralFrameDebug(0): alpha'_0 . beta'_0 and sum(gamma_0) must both be ~1 per sequence;
-        // beta'_0 = c_0 U_0 / n_0 = c_1 U_0 / asum_0  (request_alpha(0) above left alpha'_0 in al)
+        // beta'_0 = c_0 U_0 / n_0 = c_1 U_0 / asum_0  (request_al(0) above left alpha'_0 in al)
         float fin[4] = {gs[0], gs[1], 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -937,7 +983,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     // barrier -- and one more barrier publishes it to the Y update below
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
-      if (4 * ((int)tid + kThreads * v) < Ps) put_exp2(kPB, own32, v, yn0[v], yn1[v]);
+      if (4 * ((int)tid + kThreads * v) < Ps) put_exp2(kPB, o32, v, yn0[v], yn1[v]);
     }
     TC_PSTAMP(1, t, 5)
     __syncthreads();
@@ -950,31 +996,41 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
       bo0[j] = u0[j] * inv_n_a + bsum_a;
       bo1[j] = u1[j] * inv_n_b + bsum_b;
     }
-    // (first phase: the chunk requests first, so that the memory pipe works on them while the LDS does form_y's gathers;
-    // the gamma frames have no registers for that)
     if (!GAMMA) {
-      load_chunk(q0, bbase, lane16, RES);
-      load_chunk(q1, bbase, lane16, RES + 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    form_y(fs, ws);
-    if (GAMMA) {
+      // First phase.  The tail has a memory part (the next frame's first chunks, B_t's history row, the next y row)
+      // and an LDS part (form_y's gathers and stores), independent of each other, and all 16 waves reach it together
+      // behind the barrier above: half of the waves take the memory part first, the other half the LDS part, so that
+      // the memory pipe and the LDS work side by side instead of one after the other.
+      auto memory_part = [&]() __attribute__((always_inline)) {
+        load_chunk(q0, bbase, lane16, RES);  // (ahead of the stores and of the HBM request: in-order completion)
+        load_chunk(q1, bbase, lane16, RES + 1);
+        if (t > M) {
+          const rsrc_t ha = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (j < planes) {
+              bst4(ha, o16 + j * kPlane, bo0[j]);
+              bst4(hb, o16 + j * kPlane, bo1[j]);
+            }
+        }
+        request_yn(t - 1);  // the next frame's y row (HBM, unconditional: see the forward role): first used behind its pass
+      };
+      if (wave < kWaves / 2) {
+        memory_part();
+        __builtin_amdgcn_sched_barrier(0);
+        form_y(fs, ws);
+      } else {
+        form_y(fs, ws);
+        __builtin_amdgcn_sched_barrier(0);
+        memory_part();
+      }
+    } else {
+      // (the gamma frames have no registers for the chunks during gamma_block)
+      form_y(fs, ws);
       gamma_block(t - 1, fs, ws, cp);
       __builtin_amdgcn_sched_barrier(0);
       load_chunk(q0, bbase, lane16, RES);
       load_chunk(q1, bbase, lane16, RES + 1);
-    }
-    if (!GAMMA) {
-      if (t > M) {
-        const rsrc_t ha = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), hb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (j < planes) {
-            bst4(ha, own16 + j * kPlane, bo0[j]);
-            bst4(hb, own16 + j * kPlane, bo1[j]);
-          }
-      }
-      request_yn(t - 1);  // the next frame's y row (HBM, unconditional: see the forward role): first used behind its pass
     }
     TC_PSTAMP(1, t, 7)
   };
@@ -1003,7 +1059,8 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   {
     // c_M = 1 / sum_g alpha_M(g) B_M(g), alpha_M = alpha'_M - leaky pi asum_M; then gamma_{M-1} (exp(y_{M-1}) is in LDS,
     // B_M in bo)
-    request_alpha(M - 1);
+    request_au(M - 1);
+    request_al(M - 1);
     u4 fs[2];
     f4 ws[2], cp[2];
 #pragma unroll
@@ -1039,13 +1096,13 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
 }
 
 #ifndef TC_PAIR_RF1
-#define TC_PAIR_RF1 2
+#define TC_PAIR_RF1 0
 #endif
 #ifndef TC_PAIR_RF2
 #define TC_PAIR_RF2 2
 #endif
 #ifndef TC_PAIR_RB1
-#define TC_PAIR_RB1 2
+#define TC_PAIR_RB1 0
 #endif
 #ifndef TC_PAIR_RB2
 #define TC_PAIR_RB2 0
@@ -1070,14 +1127,15 @@ __global__ __launch_bounds__(kThreads) void den_tied_pair_kernel(const DenParams
 }
 
 struct PairLds {
-  uint32_t aGM, aSEC, aRed, total;
+  uint32_t aGM, aSEC, aRed, aY2, total;
 };
 PairLds pair_lds(const DenLayout &L, int extra_slots) {
   PairLds o;
   o.aGM = (uint32_t)L.PV * 32u * kThreads + 8u * (uint32_t)L.Hs;
   o.aSEC = o.aGM + 8u * (uint32_t)L.Ps;
   o.aRed = (o.aSEC + 8u * (uint32_t)extra_slots + 15u) & ~15u;
-  o.total = o.aRed + kScrBytes;
+  o.aY2 = o.aRed + kScrBytes;
+  o.total = o.aY2 + 8u * kThreads;
   return o;
 }
 
@@ -1117,8 +1175,9 @@ int launch_den_tied_pair(const DenParams &p0, int extra_slots, int accumulate, h
   q.aGM = l.aGM;
   q.aSEC = l.aSEC;
   q.aRed = l.aRed;
+  q.aY2 = l.aY2;
   p.fwd_norm = p0.pair_norm;
-  p.bwd_norm = p0.pair_norm + (int64_t)p0.S * q.norm_stride;
+  p.bwd_norm = p0.pair_norm + (int64_t)(p0.S + 1) * q.norm_stride;  // (S + 1 rows each: the spare row of an odd batch)
   TC_HIP_CHECK(hipMemsetAsync(q.sync, 0, pair_sync_bytes(p0.S), stream));
   const int PV = p.L.PV;
   if (PV == kPvSmall) return launch_pair_v<kPvSmall>(p, q, accumulate, l.total, stream);
