@@ -21,6 +21,7 @@ constexpr int kWaves = kThreads / 64;
 // the two kernel instantiations <JV, PV>: float4s of states / pdfs owned per thread
 constexpr int kJvSmall = 2048 / kThreads, kPvSmall = 1024 / kThreads, kJvLarge = 4096 / kThreads, kPvLarge = 3072 / kThreads;
 constexpr int kPvMid = 2048 / kThreads;  // 4097..8192 pdfs
+constexpr int kJvMid = 3072 / kThreads;  // tied graphs of 8193..12288 positions: 12 states per thread
 constexpr int kMaxRowLen = 32;             // longer in/out-arc lists are split into virtual rows
 constexpr int kLdsLimitBytes = 160 * 1024; // gfx950 LDS per CU / per workgroup
 

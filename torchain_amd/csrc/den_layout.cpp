@@ -30,6 +30,11 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
   } else if (jv <= kJvSmall && pv <= kPvLarge) {
     L->JV = kJvSmall;
     L->PV = kPvLarge;
+  } else if (tied && jv <= kJvMid && pv <= kPvLarge) {
+    // tied graphs of 8193..12288 positions (12 states per thread): the registers the fourth float4 of every per-state
+    // array would take go to resident stream chunks (den_tied_kernel.hip: res_fwd / res_bwd)
+    L->JV = kJvMid;
+    L->PV = pv <= kPvSmall ? kPvSmall : pv <= kPvMid ? kPvMid : kPvLarge;
   } else if (jv <= kJvLarge && pv <= kPvSmall) {
     L->JV = kJvLarge;
     L->PV = kPvSmall;

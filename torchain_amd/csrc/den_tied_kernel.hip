@@ -491,8 +491,11 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
 #ifndef TC_RESB
 #define TC_RESB 4
 #endif
-constexpr int res_fwd(int jv, int pv) { return jv > 2 ? 0 : pv == 1 ? TC_RESF : 2; }
-constexpr int res_bwd(int jv, int pv) { return jv > 2 ? 0 : pv == 1 ? TC_RESB : 2; }
+#ifndef TC_RES_JV3
+#define TC_RES_JV3 2
+#endif
+constexpr int res_fwd(int jv, int pv) { return jv > 3 ? 0 : jv == 3 ? (pv == 1 ? TC_RES_JV3 : 0) : pv == 1 ? TC_RESF : 2; }
+constexpr int res_bwd(int jv, int pv) { return jv > 3 ? 0 : jv == 3 ? (pv == 1 ? TC_RES_JV3 : 0) : pv == 1 ? TC_RESB : 2; }
 
 template <int JV, int PV>
 int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipStream_t stream) {
@@ -528,6 +531,9 @@ int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream) {
   TC_DISPATCH(kJvSmall, kPvSmall)
   TC_DISPATCH(kJvSmall, kPvMid)
   TC_DISPATCH(kJvSmall, kPvLarge)
+  TC_DISPATCH(kJvMid, kPvSmall)
+  TC_DISPATCH(kJvMid, kPvMid)
+  TC_DISPATCH(kJvMid, kPvLarge)
   TC_DISPATCH(kJvLarge, kPvSmall)
   TC_DISPATCH(kJvLarge, kPvMid)
   TC_DISPATCH(kJvLarge, kPvLarge)

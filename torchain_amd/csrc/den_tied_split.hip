@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_combine_kernel(const DenPar
 
 template <int JV, int PV>
 int launch_bwd_jp(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
-  constexpr int RB = JV > 2 ? 0 : PV == 1 ? 4 : 2;
+  constexpr int RB = JV > 3 ? 0 : JV == 3 ? (PV == 1 ? 2 : 0) : PV == 1 ? 4 : 2;
   void (*k)(const DenParams) = den_tied_bwd_kernel<JV, PV, RB>;
   TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds_bytes));
   hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
@@ -370,6 +370,9 @@ int launch_combine_jp(const DenParams &p, int accumulate, int groups, hipStream_
   if (JV == kJvSmall && PV == kPvSmall) return CALL(kJvSmall, kPvSmall); \
   if (JV == kJvSmall && PV == kPvMid) return CALL(kJvSmall, kPvMid);     \
   if (JV == kJvSmall && PV == kPvLarge) return CALL(kJvSmall, kPvLarge); \
+  if (JV == kJvMid && PV == kPvSmall) return CALL(kJvMid, kPvSmall);     \
+  if (JV == kJvMid && PV == kPvMid) return CALL(kJvMid, kPvMid);         \
+  if (JV == kJvMid && PV == kPvLarge) return CALL(kJvMid, kPvLarge);     \
   if (JV == kJvLarge && PV == kPvSmall) return CALL(kJvLarge, kPvSmall); \
   if (JV == kJvLarge && PV == kPvMid) return CALL(kJvLarge, kPvMid);     \
   if (JV == kJvLarge && PV == kPvLarge) return CALL(kJvLarge, kPvLarge);
