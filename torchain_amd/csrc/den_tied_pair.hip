@@ -951,7 +951,6 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
             row_st(db, o16 + v * kPlane, p.d_vec, ob);
           }
         }
-      if (!LAST) request_au(t - 1);
       const float as_a = vload_f32(fn0 + t), as_b = vload_f32(fn1 + t);
       const float inv_as_a = __builtin_amdgcn_rcpf(as_a), inv_as_b = __builtin_amdgcn_rcpf(as_b);
       if (LAST) {
@@ -1028,6 +1027,13 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
       // (the gamma frames have no registers for the chunks during gamma_block)
       form_y(fs, ws);
       gamma_block(t - 1, fs, ws, cp);
+      // alpha'_{t-1} is the next frame's alpha'_{tl+1}: kept in registers across that frame's (light) walk and pass
+      // rather than read again
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        au0[j] = al0[j];
+        au1[j] = al1[j];
+      }
       __builtin_amdgcn_sched_barrier(0);
       load_chunk(q0, bbase, lane16, RES);
       load_chunk(q1, bbase, lane16, RES + 1);
@@ -1081,6 +1087,11 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     chat_a = __builtin_amdgcn_rcpf(d[0]);
     chat_b = __builtin_amdgcn_rcpf(d[1]);
     gamma_block(M - 1, fs, ws, cp);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      au0[j] = al0[j];
+      au1[j] = al1[j];
+    }
   }
   // ---- second phase: frames M-1 .. 0: the derivative row of frame t, gamma_{t-1}
   load_chunk(q0, bbase, lane16, RES2);
