@@ -206,6 +206,18 @@ int tc_xent_objf(const float *xent_output, int64_t num_rows, int32_t num_cols, i
  * layout and runs the streamed kernel, 0 for the general on-chip kernel). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
+/* Kernel choice of batches above one sequence per two CUs.  Tied on-chip graphs of up to 8192 positions have two
+ * kernels: the fused one (one sequence per workgroup) and the two-sequence one (a pair of sequences on two CUs that
+ * share the arc walk), which is the faster from about 11 arcs per state on.  tc_den_graph_prepare times both once per
+ * graph and device on a zero-filled scratch batch (one sequence per CU, 48 frames; the scratch, about
+ * 2 * CUs * 48 * num_pdfs * 4 bytes plus that batch's workspace, is freed again) and keeps the two-sequence kernel
+ * when it is at least 3% faster; tc_debug_set("no_tune", 1) or ("no_pair", 1) before the graph's first use on the
+ * device keeps the fused kernel, ("force_pair", 1) selects the other wherever it fits.  Both kernels agree with the
+ * reference to the same tolerance; their results differ from each other in the last bits.
+ * Reports the choice (1 = two-sequence kernel) and the two times in ms; prepares the graph if it was not. */
+int tc_den_graph_tuning(tc_den_graph *graph, int device, int32_t *two_sequence_kernel, float *fused_ms,
+                        float *two_sequence_ms);
+
 /* ---- layout conversion either side of the path -------------------------- */
 
 /* Replaces `to2d` (torchain/functions.py:118-125: x.permute(2,0,1).contiguous().view(-1, C)):

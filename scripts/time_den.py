@@ -14,7 +14,12 @@ for key in os.environ.get("TC_DEBUG", "").split(","):  # e.g. TC_DEBUG=force_gen
         name, _, value = key.partition("=")
         check(lib.tc_debug_set(name.encode(), int(value or 1)), "tc_debug_set")
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C3"
-cfg = synth.CONFIGS[cfgname]
+cfg = dict(synth.CONFIGS[cfgname])
+for kv in os.environ.get("TC_CFG", "").split(","):  # e.g. TC_CFG=degree=12,P=2928: overrides of the named workload
+    if kv:
+        k, _, v = kv.partition("=")
+        cfg[k] = float(v) if "." in v else int(v)
+synth.CONFIGS[cfgname] = cfg
 S, T, P = cfg["S"], cfg["T"], cfg["P"]
 if len(sys.argv) > 2:
     S = int(sys.argv[2])

@@ -255,3 +255,24 @@ def test_native_self_test_entry():
     assert rc == 0, (rc, list(rep))
     assert weight == 0.5 * 3 * 9 and objf < 0 and l2_term == 0.0
     assert worst_row <= 1e-4 and abs(observed - predicted) <= 0.1 * abs(predicted) + 1e-4 and predicted != 0.0
+
+
+def test_kernel_choice_is_timed_per_graph(oracle, kernel_family):
+    """tc_den_graph_tuning: a graph the two-sequence kernel fits is timed with both kernels when it reaches the device
+    and keeps the two-sequence one only when that is at least 3% faster; a batch above one sequence per two CUs then
+    agrees with the oracle whichever kernel it ran on.  ``no_tune`` keeps the fused kernel without timing."""
+    dense = synth.random_den_fst(8192, 14, 4096, seed=3)  # 14 arcs per state: where the shared walk pays
+    graph = io.DenominatorGraph(dense, 4096).prepare(0)
+    t = graph.tuning(0)
+    assert t["fused_ms"] > 0 and t["two_sequence_ms"] > 0
+    assert t["two_sequence_kernel"] == int(t["two_sequence_ms"] < 0.97 * t["fused_ms"])
+    S, T = 130, 5
+    y = synth.random_nnet_output(S, T, 4096, seed=12)
+    got = hip_den(dense, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
+    ref = oracle.den_forward_backward(oracle.DenGraph(dense), y, S, leaky=0.1, deriv_weight=1.0)
+    assert got["status"] == 0
+    assert abs(got["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+    assert rel_err(got["deriv"], ref["deriv"]) <= REL
+    kernel_family("no_tune")
+    untimed = io.DenominatorGraph(dense, 4096).prepare(0).tuning(0)
+    assert untimed == {"two_sequence_kernel": 0, "fused_ms": 0.0, "two_sequence_ms": 0.0}

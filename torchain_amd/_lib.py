@@ -62,6 +62,8 @@ def _load():
     L.tc_den_graph_prepare.argtypes = [vp, C.c_int]
     L.tc_den_graph_stats.restype = C.c_int
     L.tc_den_graph_stats.argtypes = [vp, vp]
+    L.tc_den_graph_tuning.restype = C.c_int
+    L.tc_den_graph_tuning.argtypes = [vp, C.c_int, vp, vp, vp]
     L.tc_debug_set.restype = C.c_int
     L.tc_debug_set.argtypes = [C.c_char_p, C.c_int]
     L.tc_debug_counter.restype = C.c_int64

@@ -101,16 +101,18 @@ struct DeviceGuard {
 
 int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int64_t rows, int32_t cols,
                     int64_t y_stride, float leaky, float deriv_weight, float l2_scale, float *deriv,
-                    int64_t deriv_stride, const Workspace &w, DenParams *p) {
+                    int64_t deriv_stride, const Workspace &w, DenParams *p, const DenGraphDev *tuning = nullptr) {
   if (!g || !y || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   if (cols != g->P || y_stride < cols) return TC_ERR_INVALID_ARGUMENT;
   if (deriv && deriv_stride < cols) return TC_ERR_INVALID_ARGUMENT;
   if (!(leaky > 0.0f && leaky < 1.0f)) return TC_ERR_INVALID_ARGUMENT;  // [K] KALDI_ASSERT in the ctor
   const int T = (int)(rows / S);
-  int rc = tc_den_graph_prepare(g, device);
-  if (rc != TC_OK) return rc;
   DenGraphDev d;
-  {
+  if (tuning) {
+    d = *tuning;  // (tune_den_variant: the variant under test is in its pair_choice)
+  } else {
+    int rc = tc_den_graph_prepare(g, device);
+    if (rc != TC_OK) return rc;
     std::lock_guard<std::mutex> lock(g->mu);
     d = g->dev[device];
   }
@@ -138,6 +140,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->pair_sync = w.pair_sync;
   p->pair_stamps = w.pair_stamps;
   p->pair_extra_slots = std::max(g->fwd.extra_slots, g->bwd.extra_slots);
+  p->pair_choice = d.pair_choice > 0 ? 1 : 0;
   p->big_Sp = (S + 63) & ~63;
   p->big_sum_pi = g->big_sum_pi;
   p->tied_fs = tied ? d.tied_fs : nullptr;
@@ -196,9 +199,102 @@ int fill_num_params(tc_supervision *sup, int device, hipStream_t stream, const f
   return TC_OK;
 }
 
+
 }  // namespace
 
+namespace tc {
+
+// Fused kernel or two-sequence kernel for this graph on this device?  Both are run on a zero-filled batch of one
+// sequence per CU and kTuneFrames frames (their time does not depend on the values) in scratch memory that is freed
+// again; the two-sequence kernel is kept when it is at least 3% faster.  Any failure here leaves the fused kernel.
+constexpr int kTuneFrames = 48, kTuneWarmup = 60, kTuneRounds = 4;
+
+int tune_den_variant(tc_den_graph *g, int device) {
+  DenGraphDev d;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    DenGraphDev &slot = g->dev[device];
+    if (slot.pair_choice != -1) return TC_OK;
+    slot.pair_choice = -2;  // (a concurrent caller runs the fused kernel meanwhile)
+    d = slot;
+  }
+  int choice = 0;
+  float ms[2] = {0.f, 0.f};
+  auto finish = [&]() {
+    std::lock_guard<std::mutex> lock(g->mu);
+    DenGraphDev &slot = g->dev[device];
+    slot.pair_choice = choice;
+    slot.tune_ms[0] = ms[0];
+    slot.tune_ms[1] = ms[1];
+    return TC_OK;
+  };
+  if (!pair_room(g) || !d.fwd.cells_pair || debug_flag(kDbgNoPair) || debug_flag(kDbgNoTune) || debug_flag(kDbgForcePair))
+    return finish();
+  DeviceGuard guard(device);
+  if (!guard.ok) return finish();
+  int num_cus = 0;
+  if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || num_cus < 2)
+    return finish();
+  const int S = num_cus & ~1, T = kTuneFrames, P = g->P;
+  const Workspace w0 = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S), pair_room(g));
+  const size_t ybytes = (size_t)S * T * P * sizeof(float);
+  char *mem = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = hipMalloc((void **)&mem, 2 * ybytes + w0.total + 512) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  ok = ok && hipMemsetAsync(mem, 0, 2 * ybytes + w0.total + 512, stream) == hipSuccess;
+  if (ok) {
+    float *y = (float *)mem, *deriv = (float *)(mem + ybytes);
+    char *wsp = mem + 2 * ybytes;
+    wsp += (256 - ((uintptr_t)wsp & 255)) & 255;
+    const Workspace w = carve(wsp, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S), pair_room(g));
+    DenParams p[2];
+    for (int variant = 0; variant < 2 && ok; ++variant) {
+      d.pair_choice = variant;
+      ok = fill_den_params(g, device, S, y, (int64_t)S * T, P, P, 0.1f, -1.0f, 0.f, deriv, P, w, &p[variant], &d) == TC_OK;
+    }
+    // Untimed launches until the clocks have settled (a graph usually arrives on an idle device), then the two
+    // kernels in turn, the best of kRounds each.
+    for (int i = 0; i < kTuneWarmup && ok; ++i) ok = launch_den_mode(p[i & 1], 0, stream) == TC_OK;
+    ms[0] = ms[1] = 1e30f;
+    for (int round = 0; round < kTuneRounds && ok; ++round)
+      for (int variant = 0; variant < 2 && ok; ++variant) {
+        float t = 0.f;
+        ok = hipEventRecord(e0, stream) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) ok = launch_den_mode(p[variant], 0, stream) == TC_OK;
+        ok = ok && hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+        ok = ok && hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+        ms[variant] = std::min(ms[variant], 0.5f * t);
+      }
+    if (!ok) ms[0] = ms[1] = 0.f;
+    if (ok && ms[1] < 0.97f * ms[0]) choice = 1;
+  }
+  if (stream) (void)hipStreamSynchronize(stream);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (stream) (void)hipStreamDestroy(stream);
+  if (mem) (void)hipFree(mem);
+  (void)hipGetLastError();  // (a failed scratch allocation is not the caller's error)
+  return finish();
+}
+
+}  // namespace tc
+
 extern "C" {
+
+int tc_den_graph_tuning(tc_den_graph *g, int device, int32_t *two_sequence_kernel, float *fused_ms, float *two_sequence_ms) {
+  if (!g) return TC_ERR_INVALID_ARGUMENT;
+  const int rc = tc_den_graph_prepare(g, device);
+  if (rc != TC_OK) return rc;
+  std::lock_guard<std::mutex> lock(g->mu);
+  const DenGraphDev &d = g->dev[device];
+  if (two_sequence_kernel) *two_sequence_kernel = d.pair_choice > 0 ? 1 : 0;
+  if (fused_ms) *fused_ms = d.tune_ms[0];
+  if (two_sequence_ms) *two_sequence_ms = d.tune_ms[1];
+  return TC_OK;
+}
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;

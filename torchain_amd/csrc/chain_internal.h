@@ -122,6 +122,10 @@ struct DenGraphDev {
   const uint32_t *tied_fs = nullptr;  // tied graphs: per state, forward-pdf*4 | self-loop-pdf*4 << 16
   const float *tied_w = nullptr;      // tied graphs: per state, self-loop probability (0 if none)
   void *blob = nullptr;
+  // Two-sequence kernel (den_tied_pair.hip) or fused kernel for batches beyond one sequence per two CUs: decided per
+  // graph and device by timing both once (api.cpp: tune_den_variant).  -1 not decided yet, -2 being decided.
+  int pair_choice = -1;
+  float tune_ms[2] = {0.f, 0.f};  // what the decision was made on: fused, two-sequence (ms for kTuneFrames frames)
 };
 
 // LDS layout of the fused kernel, in floats: [P | A | ACC | GAMMA | ALPHA? | red | asum].  exp(y)
@@ -174,6 +178,7 @@ struct DenParams {
   uint32_t *pair_sync = nullptr;
   long long *pair_stamps = nullptr;  // diagnostic builds (-DTC_PAIR_STAMPS): [role][wave][T + 2][8] raw cycle stamps of pair 0
   int pair_extra_slots = 0;     // secondary-row slots of the graph's schedules (LDS layout of the pair kernel)
+  int pair_choice = 0;        // the graph's tuned choice (DenGraphDev::pair_choice > 0)
 };
 
 }  // namespace tc
@@ -307,6 +312,7 @@ constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most h
 // den_tied_pair.hip: two sequences per workgroup, the two recursions of a pair on two CUs meeting in the middle
 int launch_den_tied_pair(const DenParams &p, int extra_slots, int accumulate, hipStream_t stream);
 bool pair_fits(const DenLayout &L, int extra_slots, int T);
+int tune_den_variant(tc_den_graph *g, int device);  // api.cpp
 int pair_norm_stride(int T);
 size_t pair_sync_bytes(int S);
 inline size_t pair_stamp_bytes(int T) { return ((size_t)2 * kWaves * (T + 2) * 8 * 8 + 255) & ~(size_t)255; }
@@ -343,7 +349,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -236,7 +236,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair"};
+                                               "force_pair", "no_tune"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -607,8 +607,18 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   return TC_OK;
 }
 
+static int upload_den_graph(tc_den_graph *g, int device);
+
+// Uploads the graph's tables to `device` once; the first call for an eligible graph also times the fused and the
+// two-sequence kernel on that device and keeps the faster (tune_den_variant).
 int tc_den_graph_prepare(tc_den_graph *g, int device) {
   if (!g) return TC_ERR_INVALID_ARGUMENT;
+  const int rc = upload_den_graph(g, device);
+  if (rc != TC_OK) return rc;
+  return tune_den_variant(g, device);
+}
+
+static int upload_den_graph(tc_den_graph *g, int device) {
   std::lock_guard<std::mutex> lock(g->mu);
   if (g->dev.count(device)) return TC_OK;
   int prev = 0;

@@ -460,10 +460,11 @@ static bool split_wanted(const DenParams &p) {
 static bool pair_wanted(const DenParams &p, int num_cus) {
   if (!p.tied_fs || p.big.in_begin || !p.deriv || !p.pair_norm || !p.pair_sync || !p.fwd.cells_pair) return false;
   if (debug_flag(kDbgNoPair) || !pair_fits(p.L, p.pair_extra_slots, p.T)) return false;
-  // (round 3: correct everywhere it is tested, but at C3 still a few per cent behind the fused kernel -- see DESIGN.md;
-  // until it wins it runs only on request)
-  (void)num_cus;
-  return debug_flag(kDbgForcePair);
+  if (debug_flag(kDbgForcePair)) return true;
+  // Which of the two is faster depends on the graph (the two-sequence kernel shares the walk between its sequences and
+  // wins from about 11 arcs per state on; at C3's 8 the fused kernel is ahead): measured once per graph and device.
+  // Batches of up to one sequence per two CUs are the two-CU form's.
+  return p.pair_choice > 0 && 2 * p.S > num_cus;
 }
 
 int den_cus_used(const DenParams &p, int num_cus) {

@@ -371,7 +371,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
   f4 yr0[PV], yr1[PV];  // y_t of the thread's pdfs
   f4 bt0[2] = {mk4(0.f), mk4(0.f)}, bt1[2] = {mk4(0.f), mk4(0.f)};  // B_t of the owned states
   auto request_y = [&](int t) __attribute__((always_inline)) {
-    const uint32_t o16 = opq(own16), o32 = opq(own32);
+    const uint32_t o16 = opq(own16);
     const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
 #pragma unroll
     for (int v = 0; v < PV; ++v) {
@@ -380,7 +380,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     }
   };
   auto request_b = [&](int t) __attribute__((always_inline)) {
-    const uint32_t o16 = opq(own16), o32 = opq(own32);
+    const uint32_t o16 = opq(own16);
     const rsrc_t ba = make_rsrc(hist0 + (int64_t)t * hist_step, hb0), bb = make_rsrc(hist1 + (int64_t)t * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -417,6 +417,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     f4 yp0[PV], yp1[PV];
     fold(r);
     float sums[GAMMA ? 4 : 2];
+    constexpr int GA = GAMMA ? 2 : 0, GB = GAMMA ? 3 : 1;  // (the gamma frames' extra sums; in range either way)
 #pragma unroll
     for (int i = 0; i < (GAMMA ? 4 : 2); ++i) sums[i] = 0.f;
     const float gsa = kGammaScale * chat_a, gsb = kGammaScale * chat_b;
@@ -440,8 +441,8 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
             gamma_add_a(aGM0 + (fsx >> 16), g0 * sp0);
             gamma_add_a(aGM1 + (fsx & 0xffffu), g1 * fp1);
             gamma_add_a(aGM1 + (fsx >> 16), g1 * sp1);
-            sums[2] = fmaf(o0, b0, sums[2]);
-            sums[3] = fmaf(o1, b1, sums[3]);
+            sums[GA] = fmaf(o0, b0, sums[GA]);
+            sums[GB] = fmaf(o1, b1, sums[GB]);
           }
         };
         float oa[4], ob[4];
@@ -505,7 +506,7 @@ __device__ __forceinline__ void pair_forward(const DenParams &p, const PairParam
     load_chunk(q1, fbase, lane16, RES + 1);
     if (GAMMA) {
       // the derivative row of frame t-1: gamma_{t-1} * (c_t / c^_t)
-      const float ca = __builtin_amdgcn_rcpf(sums[2]), cb = __builtin_amdgcn_rcpf(sums[3]);
+      const float ca = __builtin_amdgcn_rcpf(sums[GA]), cb = __builtin_amdgcn_rcpf(sums[GB]);
       const float sa = kGammaInvScale * (ca * __builtin_amdgcn_rcpf(chat_a)), sb = kGammaInvScale * (cb * __builtin_amdgcn_rcpf(chat_b));
       const rsrc_t da = drow(t - 1, s0, rb0), db = drow(t - 1, s1, rb1);
 #pragma unroll
@@ -781,7 +782,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   f4 al0[2] = {mk4(0.f), mk4(0.f)}, al1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_{t-1}: gamma_{t-1} is formed at the end of frame t
   f4 au0[2] = {mk4(0.f), mk4(0.f)}, au1[2] = {mk4(0.f), mk4(0.f)};  // alpha'_t
   auto request_yn = [&](int t) __attribute__((always_inline)) {
-    const uint32_t o16 = opq(own16), o32 = opq(own32);
+    const uint32_t o16 = opq(own16);
     const int tn = t > 0 ? t - 1 : 0;
     const rsrc_t ya = yrow(tn, s0, rb0), yb = yrow(tn, s1, rb1);
 #pragma unroll
@@ -793,7 +794,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
   // alpha'_{tl} -> al (HBM: requested behind the pass), alpha'_{tl+1} -> au (this CU's a frame ago, L2: requested
   // behind the derivative row, whose conversion needs the registers)
   auto request_al = [&](int tl) __attribute__((always_inline)) {
-    const uint32_t o16 = opq(own16), o32 = opq(own32);
+    const uint32_t o16 = opq(own16);
     const rsrc_t a0r = make_rsrc(hist0 + (int64_t)tl * hist_step, hb0), a1r = make_rsrc(hist1 + (int64_t)tl * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -802,7 +803,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     }
   };
   auto request_au = [&](int tl) __attribute__((always_inline)) {
-    const uint32_t o16 = opq(own16), o32 = opq(own32);
+    const uint32_t o16 = opq(own16);
     const rsrc_t u0r = make_rsrc(hist0 + (int64_t)(tl + 1) * hist_step, hb0), u1r = make_rsrc(hist1 + (int64_t)(tl + 1) * hist_step, hb1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -885,6 +886,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     fold(r);
     constexpr int NS = GAMMA ? 6 : 4;
     float sums[NS];
+    constexpr int GA = GAMMA ? 4 : 0, GB = GAMMA ? 5 : 1;  // (the gamma frames' extra sums; in range either way)
 #pragma unroll
     for (int i = 0; i < NS; ++i) sums[i] = 0.f;
     f4 u0[2], u1[2];
@@ -902,8 +904,8 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
     }
     f4 yc0[PV], yc1[PV];
     if (GAMMA) {
-      sums[4] = dpart_a;
-      sums[5] = dpart_b;
+      sums[GA] = dpart_a;
+      sums[GB] = dpart_b;
       // Behind the pass, first used behind the reduction: y_t (the l2 term of the derivative row; this CU read it a
       // frame ago: L2)
       const rsrc_t ya = yrow(t, s0, rb0), yb = yrow(t, s1, rb1);
@@ -924,7 +926,7 @@ __device__ __forceinline__ void pair_backward(const DenParams &p, const PairPara
       bn1[t] = __builtin_amdgcn_rcpf(inv_n_b);
     }
     if (GAMMA) {
-      const float ca = __builtin_amdgcn_rcpf(sums[4]), cb = __builtin_amdgcn_rcpf(sums[5]);  // c_{t+1}
+      const float ca = __builtin_amdgcn_rcpf(sums[GA]), cb = __builtin_amdgcn_rcpf(sums[GB]);  // c_{t+1}
       const float sa = kGammaInvScale * (ca * __builtin_amdgcn_rcpf(chat_a)), sb = kGammaInvScale * (cb * __builtin_amdgcn_rcpf(chat_b));
       const rsrc_t da = drow(t, s0, rb0), db = drow(t, s1, rb1);
       float gs[2] = {0.f, 0.f};

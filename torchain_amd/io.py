@@ -92,6 +92,16 @@ class DenominatorGraph:
         return dict(zip(keys, (int(x) for x in out)))
 
 
+    def tuning(self, device):
+        """Which kernel batches above one sequence per two CUs run on ``device`` (``tc_den_graph_tuning``) and the
+        two times the choice was made on."""
+        import ctypes as C
+        dev = device.index if hasattr(device, "index") else int(device)
+        choice, a, b = C.c_int32(0), C.c_float(0), C.c_float(0)
+        check(lib.tc_den_graph_tuning(self.ptr, int(dev or 0), C.byref(choice), C.byref(a), C.byref(b)),
+              "tc_den_graph_tuning")
+        return {"two_sequence_kernel": int(choice.value), "fused_ms": float(a.value), "two_sequence_ms": float(b.value)}
+
     def debug_walk(self, direction, gather, pdf_factor):
         """Diagnostic (host only): replays one arc walk from the built schedules, see
         ``tc_den_graph_debug_walk``.  Used by the CPU tests of the schedule builder."""
