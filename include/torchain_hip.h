@@ -108,6 +108,34 @@ int tc_supervision_append(int32_t num_pieces, const int32_t *piece_num_states, c
                           int64_t cap_arcs, int32_t *out_num_states, int64_t *out_num_arcs, int32_t *out_arc_begin,
                           int32_t *out_ilabel, float *out_weight, int32_t *out_nextstate, float *out_final);
 
+/* ---- chain examples ("egs") on the host: reading and merging a minibatch -------------------------------------- */
+
+/* Replaces the reading half of the reference's random-access minibatch reader (src/my_lib_example_rand.cpp:35-177:
+ * RandomAccessNnetChainExampleReader::Value per key + kaldi::nnet3::MergeChainExamples): opens the n scp entries
+ * (paths[i], byte offsets[i] of the "\0B" binary marker; offsets NULL or < 0 = start of file), parses the binary
+ * <Nnet3ChainEg> objects (NnetIo with FM/DM/CM/CM2/CM3 matrices, NnetChainSupervision with a compact_acceptor FST,
+ * <DW>/<DW2> deriv weights) and, for n > 1 or merge_single != 0, merges them: every input stacked example by example
+ * with n = the example's position, supervisions appended as by tc_supervision_append, output indexes and
+ * deriv_weights frame-major.  Host memory only, no GPU, thread-safe; TC_ERR_IO (file), TC_ERR_BAD_FST (format; text in
+ * tc_example_last_error, per thread), TC_ERR_INVALID_ARGUMENT (examples that cannot be merged). */
+typedef struct tc_example tc_example;
+int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n, int merge_single, tc_example **out);
+void tc_example_free(tc_example *example);
+const char *tc_example_last_error(void);
+/* out2 = {number of inputs, number of outputs}. */
+int tc_example_counts(const tc_example *example, int32_t *out2);
+/* Input j (reference my_lib_example_feats, src/my_lib_example.cpp:79-100): pointers into the object, valid until
+ * tc_example_free; indexes = num_indexes x (n, t, x); features = rows x cols, row-major.  Any out pointer may be NULL. */
+int tc_example_input(const tc_example *example, int32_t j, const char **name, int32_t *rows, int32_t *cols,
+                     int32_t *num_indexes, const float **features, const int32_t **indexes);
+/* Output j (reference my_lib_supervision_new / my_lib_example_reader_indexes, src/my_lib_example.cpp:71-76, 102-127):
+ * dims5 = {num_sequences, frames_per_sequence, label_dim, num_states, num_arcs}; the FST arrays are what
+ * tc_supervision_create takes. */
+int tc_example_output(const tc_example *example, int32_t j, const char **name, int32_t *num_indexes,
+                      const int32_t **indexes, const float **deriv_weights, float *weight, int32_t *dims5,
+                      const int32_t **arc_begin, const int32_t **ilabel, const float **arc_weight,
+                      const int32_t **nextstate, const float **final_weight);
+
 /* Replaces my_lib_supervision_free (src/my_lib.h:22). */
 void tc_supervision_free(tc_supervision *supervision);
 /* Replace my_lib_supervision_num_pdf / _num_sequence / _num_frame (src/my_lib.h:23-25). */

@@ -10,3 +10,17 @@ echo "== C3 forced general"; TC_DEBUG=force_general python scripts/time_den.py C
 echo "== C3 forced streamed"; TC_DEBUG=force_streamed python scripts/time_den.py C3 2>&1 | tail -1
 echo "== C3 forced streamed general"; TC_DEBUG=force_streamed,force_general python scripts/time_den.py C3 2>&1 | tail -1
 echo "== C4 (2048 sequences on one GPU)"; python scripts/time_den.py C4 2>&1 | tail -2
+echo "== kernel choice per graph (tc_den_graph_tuning: ms for 48 frames, one sequence per CU)"
+python scripts/tuning_report.py C3 C5 R1 2>&1 | grep -v amdgpu.ids
+echo "== batch curve (fwd+bwd ms): default path | fused kernel only (no_pair, no_phase_split)"
+for c in C3 R1; do for S in 64 96 128 129 160 192 224 256; do
+  a=$(python scripts/time_den.py $c $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  b=$(TC_DEBUG=no_pair,no_phase_split python scripts/time_den.py $c $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  echo "$c batch $S: $a | $b"
+done; done
+echo "== two-sequence kernel forced vs fused (batch 256)"
+for c in C3 C5 R1; do
+  a=$(TC_DEBUG=force_pair python scripts/time_den.py $c 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  b=$(TC_DEBUG=no_pair python scripts/time_den.py $c 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  echo "$c: two-sequence $a | fused $b"
+done

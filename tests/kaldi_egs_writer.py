@@ -35,6 +35,8 @@ def general_matrix(m, kind="FM"):
     rows, cols = m.shape
     if kind == "FM":
         return _tok("FM") + _basic("i", rows) + _basic("i", cols) + m.tobytes()
+    if kind == "DM":
+        return _tok("DM") + _basic("i", rows) + _basic("i", cols) + m.astype(np.float64).tobytes()
     mn, mx = float(m.min()), float(m.max())
     rng = mx - mn if mx > mn else 1.0
     hdr = struct.pack("<ffii", mn, rng, rows, cols)

@@ -171,8 +171,8 @@ def test_rand_reader_batches_by_length(tmp_path):
     assert [tuple(b) for b in rd._key_batch] != first  # reshuffled
 
 
-def test_rand_reader_prefetches_one_batch_ahead(tmp_path):
-    """RandExample prepares the next minibatch on a background thread while the current one is in use; the batches it
+def test_rand_reader_prefetches_batches_ahead(tmp_path):
+    """RandExample prepares the next minibatches on background threads while the current one is in use; the batches it
     delivers are those of the synchronous reader, in the same order, also across reset()."""
     fst = synth.random_den_fst(40, 4, 24, seed=1)
     lengths = [5] * 7 + [8] * 4 + [11]
@@ -183,10 +183,8 @@ def test_rand_reader_prefetches_one_batch_ahead(tmp_path):
         n = 0
         while a.next():
             assert b.next()
-            if n + 1 < a.n_batch:
-                assert a._pending is not None and a._pending[0] == n + 1  # the look-ahead is under way (or done)
-            else:
-                assert a._pending is None
+            ahead = sorted(a._pending)  # the look-ahead: the next batches are under way (or done), nothing else
+            assert ahead == list(range(n + 1, min(n + 1 + a._depth, a.n_batch)))
             sa, sb = a._cur["outputs"][0]["supervision"], b._cur["outputs"][0]["supervision"]
             assert same_fst(sa, sb) and sa.num_sequences == sb.num_sequences
             np.testing.assert_array_equal(a._cur["inputs"][0]["features"], b._cur["inputs"][0]["features"])
@@ -263,3 +261,74 @@ def test_committed_fixture(oracle):
     sup = merged["outputs"][0]["supervision"]
     y = synth.random_nnet_output(sup.num_sequences, sup.frames_per_sequence, sup.label_dim, seed=meta["y_seed"])
     assert abs(oracle.num_forward_backward(sup, y)["logprob_weighted"] - meta["merged_num_logprob"]) <= 1e-4 * abs(meta["merged_num_logprob"])
+
+
+def _same_example(a, b):
+    assert [i["name"] for i in a["inputs"]] == [i["name"] for i in b["inputs"]]
+    for x, y in zip(a["inputs"], b["inputs"]):
+        np.testing.assert_array_equal(x["indexes"], y["indexes"])
+        np.testing.assert_array_equal(x["features"], y["features"])  # bit for bit, compressed kinds included
+    for x, y in zip(a["outputs"], b["outputs"]):
+        assert x["name"] == y["name"] and same_fst(x["supervision"], y["supervision"])
+        np.testing.assert_array_equal(x["indexes"], y["indexes"])
+        np.testing.assert_array_equal(x["deriv_weights"], y["deriv_weights"])
+    assert len(a["outputs"]) == len(b["outputs"])
+
+
+@pytest.mark.parametrize("kind,dw,e2e", [("FM", "DW2", False), ("DM", "DW", False), ("CM", "DW2", True), ("CM2", "DW", False),
+                                         ("CM3", None, False)])
+def test_native_reader_equals_the_numpy_reader(tmp_path, kind, dw, e2e):
+    """``tc_example_read`` (csrc/egs_reader.cpp; the reference reads and merges natively through Kaldi,
+    src/my_lib_example_rand.cpp:35-177) against this package's numpy statement of the same formats: single examples
+    as stored, and minibatches merged -- every matrix kind, both deriv-weight encodings, the <End2End> flag, examples
+    of more than one sequence, explicit (127-marked) index elements."""
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    keyed = [("utt%d" % i, make_example(fst, 6, seed=40 + i, n_seq=1 + i % 2)) for i in range(5)]
+    ark, scp = str(tmp_path / "egs.ark"), str(tmp_path / "egs.scp")
+    kw.write_ark(ark, keyed, scp_path=scp, matrix_kind=kind, dw=dw, e2e_flag=e2e)
+    where = [(p, off) for _key, p, off in egs.read_scp(scp)]
+    for p, off in where:
+        _same_example(egs.read_merged_native([(p, off)], merge_single=False), egs.read_scp_entry(p, off))
+    for pick in ([0], [0, 2, 4], [1, 3], [4, 3, 2, 1, 0]):
+        entries = [where[i] for i in pick]
+        want = egs.merge_chain_examples([egs.read_scp_entry(p, off) for p, off in entries])
+        _same_example(egs.read_merged_native(entries), want)
+
+
+def test_native_reader_refuses_what_the_numpy_reader_refuses(tmp_path):
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    good = b"\0B" + kw.chain_example(make_example(fst, 5, seed=3))
+    for name, blob in (("truncated", good[:len(good) // 2]), ("text", b"<Nnet3ChainEg> "), ("token", good.replace(b"<NnetIo>", b"<NnetIO>"))):
+        path = str(tmp_path / name)
+        open(path, "wb").write(blob)
+        with pytest.raises(egs.EgsFormatError):
+            egs.read_merged_native([(path, 0)])
+    with pytest.raises(OSError):
+        egs.read_merged_native([(str(tmp_path / "absent"), 0)])
+    # examples that do not merge: different frames per sequence
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    open(a, "wb").write(good)
+    open(b, "wb").write(b"\0B" + kw.chain_example(make_example(fst, 7, seed=4)))
+    with pytest.raises(egs.EgsFormatError):
+        egs.read_merged_native([(a, 0), (b, 0)])
+
+
+def test_native_reader_time_bound(tmp_path):
+    """A minibatch of 64 one-sequence examples of 150 frames (40-dim input windows, a supervision of a few hundred
+    states each) is read, parsed and merged in a few ms -- the numpy reader needs tens -- so that RandExample's
+    look-ahead keeps ahead of a 1 ms training step (scripts/time_chain_loss_egs.py on the GPU box)."""
+    import time
+
+    fst = synth.random_den_fst(400, 6, 200, seed=2)
+    keyed = [("utt%03d" % i, make_example(fst, 150, seed=60 + i, feat_dim=40, ivec_dim=10)) for i in range(64)]
+    ark, scp = str(tmp_path / "egs.ark"), str(tmp_path / "egs.scp")
+    kw.write_ark(ark, keyed, scp_path=scp)
+    where = [(p, off) for _key, p, off in egs.read_scp(scp)]
+    egs.read_merged_native(where)
+    best = 1e9
+    for _ in range(5):
+        t0 = time.perf_counter()
+        got = egs.read_merged_native(where)
+        best = min(best, time.perf_counter() - t0)
+    assert got["outputs"][0]["supervision"].num_sequences == 64 and got["inputs"][0]["features"].shape == (64 * 458, 40)
+    assert best <= 0.015, "native read + merge of 64 x 150 frames took %.1f ms" % (best * 1e3)

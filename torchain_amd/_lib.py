@@ -62,6 +62,18 @@ def _load():
     L.tc_den_graph_prepare.argtypes = [vp, C.c_int]
     L.tc_den_graph_stats.restype = C.c_int
     L.tc_den_graph_stats.argtypes = [vp, vp]
+    L.tc_example_read.restype = C.c_int
+    L.tc_example_read.argtypes = [vp, vp, C.c_int32, C.c_int, vp]
+    L.tc_example_free.restype = None
+    L.tc_example_free.argtypes = [vp]
+    L.tc_example_last_error.restype = C.c_char_p
+    L.tc_example_last_error.argtypes = []
+    L.tc_example_counts.restype = C.c_int
+    L.tc_example_counts.argtypes = [vp, vp]
+    L.tc_example_input.restype = C.c_int
+    L.tc_example_input.argtypes = [vp, C.c_int32] + [vp] * 6
+    L.tc_example_output.restype = C.c_int
+    L.tc_example_output.argtypes = [vp, C.c_int32] + [vp] * 11
     L.tc_den_graph_tuning.restype = C.c_int
     L.tc_den_graph_tuning.argtypes = [vp, C.c_int, vp, vp, vp]
     L.tc_debug_set.restype = C.c_int

@@ -173,6 +173,17 @@ int tc_supervision_create(tc_supervision **out, float weight, int32_t S, int32_t
   tb.seq_uniq_off.push_back(0);
   const float kInf = std::numeric_limits<float>::infinity();
   std::vector<float> boundary_final;  // final weights (tropical) of the states at time (q+1)*T for sequence q
+  std::vector<int32_t> map_this_frame, touched, ucount;  // scratch of the unique-(frame, pdf) pass
+  tb.arc_src.reserve(num_arcs);
+  tb.arc_dst.reserve(num_arcs);
+  tb.arc_logw.reserve(num_arcs);
+  tb.arc_uniq.reserve(num_arcs);
+  tb.in_arc.reserve(num_arcs);
+  tb.uniq_arc.reserve(num_arcs);
+  tb.final_logw.reserve((size_t)num_states + S);
+  tb.out_begin.reserve((size_t)num_states + 2 * S);
+  tb.in_begin.reserve((size_t)num_states + 2 * S);
+  tb.level_begin.reserve((size_t)S * (T + 2));
 
   for (int32_t q = 0; q < S; ++q) {
     const int32_t b0 = time_begin[(size_t)q * T];           // first state at this sequence's start time
@@ -244,8 +255,11 @@ int tc_supervision_create(tc_supervision **out, float weight, int32_t S, int32_t
     // unique (frame, pdf) pairs, in first-occurrence order like [K] ComputeLookupIndexes
     {
       const int32_t ubase = (int32_t)tb.uniq_t.size();
-      std::vector<int32_t> map_this_frame(label_dim, -1), touched;
-      std::vector<std::vector<int32_t>> members;
+      // (counting sort by unique id: a list per id would be one heap allocation per (frame, pdf) pair -- tens of
+      // thousands per minibatch, most of this function's time when a fresh supervision arrives every step)
+      map_this_frame.assign(label_dim, -1);
+      touched.clear();
+      ucount.clear();
       int32_t cur_t = 0;
       int32_t t = 0;  // arcs are emitted in source-state order, so the frame only ever moves forward
       for (int32_t a = 0; a < narc; ++a) {
@@ -259,22 +273,25 @@ int tc_supervision_create(tc_supervision **out, float weight, int32_t S, int32_t
         const int32_t pdf = tb.arc_uniq[abase + a];
         int32_t u = map_this_frame[pdf];
         if (u < 0) {
-          u = (int32_t)members.size();
+          u = (int32_t)ucount.size();
           map_this_frame[pdf] = u;
           touched.push_back(pdf);
           tb.uniq_t.push_back(t);
           tb.uniq_pdf.push_back(pdf);
-          members.emplace_back();
+          ucount.push_back(0);
         }
-        members[u].push_back(a);
+        ucount[u]++;
         tb.arc_uniq[abase + a] = u;
       }
       int32_t run = 0;
-      for (auto &m : members) {
+      const size_t ub = tb.uniq_begin.size(), ua = tb.uniq_arc.size();
+      for (int32_t c : ucount) {
         tb.uniq_begin.push_back(run);
-        for (int32_t a : m) tb.uniq_arc.push_back(a);
-        run += (int32_t)m.size();
+        run += c;
       }
+      tb.uniq_arc.resize(ua + narc);
+      for (size_t u = 0; u < ucount.size(); ++u) ucount[u] = tb.uniq_begin[ub + u];  // fill positions
+      for (int32_t a = 0; a < narc; ++a) tb.uniq_arc[ua + ucount[tb.arc_uniq[abase + a]]++] = a;
       tb.uniq_begin.push_back(run);
       tb.seq_uniq_off.push_back((int32_t)tb.uniq_t.size());
       tb.max_uniq = std::max(tb.max_uniq, (int32_t)tb.uniq_t.size() - ubase);

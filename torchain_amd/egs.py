@@ -487,6 +487,84 @@ def append_supervisions(sups):
                   o_w[:na].copy(), o_nx[:na].copy(), o_fin[:ns].copy())
 
 
+class _NativeExample:
+    """Owns one ``tc_example`` (freed with the last array that views its memory)."""
+
+    def __init__(self, handle, free):
+        self._handle, self._free = handle, free
+
+    def __del__(self):
+        if self._handle:
+            self._free(self._handle)
+            self._handle = None
+
+
+def read_merged_native(entries, merge_single=True):
+    """The minibatch of the scp entries ``[(path, offset), ...]`` read and merged by the library's native reader
+    (``tc_example_read``: what the reference does through Kaldi in ``src/my_lib_example_rand.cpp:35-177``) -- the same
+    dict ``merge_chain_examples([read_scp_entry(p, o) for p, o in entries])`` returns.  Runs without the interpreter
+    lock apart from the final copies into numpy arrays."""
+    import ctypes as C
+
+    from ._lib import lib
+
+    n = len(entries)
+    if n == 0:
+        raise ValueError("nothing to read")
+    paths = (C.c_char_p * n)(*[os.fsencode(p) for p, _ in entries])
+    offsets = (C.c_int64 * n)(*[-1 if o is None else int(o) for _, o in entries])
+    handle = C.c_void_p()
+    rc = lib.tc_example_read(C.cast(paths, C.c_void_p), C.cast(offsets, C.c_void_p), n, int(bool(merge_single)),
+                             C.cast(C.byref(handle), C.c_void_p))
+    if rc != 0:
+        msg = (lib.tc_example_last_error() or b"").decode()
+        if rc == -6:
+            raise OSError(msg or "cannot read an example")
+        raise EgsFormatError(msg or "tc_example_read failed: %d" % rc)
+    owner = _NativeExample(handle, lib.tc_example_free)
+    try:
+        def arr(ptr, ctype, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).astype(dtype, copy=True)
+
+        def view(ptr, ctype, count, dtype):
+            # the large arrays (stacked features: megabytes per minibatch) are not copied: the array's buffer keeps the
+            # native object alive for as long as the array (or anything sliced from it) lives
+            if count == 0:
+                return np.zeros(0, dtype)
+            buf = (ctype * count).from_address(ptr.value)
+            buf._owner = owner
+            return np.frombuffer(buf, dtype=dtype)
+
+        counts = (C.c_int32 * 2)()
+        lib.tc_example_counts(handle, C.cast(counts, C.c_void_p))
+        ref = lambda x: C.cast(C.byref(x), C.c_void_p)
+        inputs, outputs = [], []
+        for j in range(counts[0]):
+            name, feats, idx = C.c_char_p(), C.c_void_p(), C.c_void_p()
+            rows, cols, nidx = C.c_int32(), C.c_int32(), C.c_int32()
+            lib.tc_example_input(handle, j, ref(name), ref(rows), ref(cols), ref(nidx), ref(feats), ref(idx))
+            inputs.append(dict(name=name.value.decode(),
+                               indexes=arr(idx, C.c_int32, 3 * nidx.value, np.int32).reshape(-1, 3),
+                               features=view(feats, C.c_float, rows.value * cols.value, np.float32).reshape(rows.value, cols.value)))
+        for j in range(counts[1]):
+            name, idx, dw = C.c_char_p(), C.c_void_p(), C.c_void_p()
+            ab, il, aw, nx, fin = (C.c_void_p() for _ in range(5))
+            nidx, weight, dims = C.c_int32(), C.c_float(), (C.c_int32 * 5)()
+            lib.tc_example_output(handle, j, ref(name), ref(nidx), ref(idx), ref(dw), ref(weight), C.cast(dims, C.c_void_p),
+                                  ref(ab), ref(il), ref(aw), ref(nx), ref(fin))
+            S, T, P, ns, na = (int(v) for v in dims)
+            sup = SupFst(float(weight.value), S, T, P, ns, arr(ab, C.c_int32, ns + 1, np.int32),
+                         arr(il, C.c_int32, na, np.int32), arr(aw, C.c_float, na, np.float32),
+                         arr(nx, C.c_int32, na, np.int32), arr(fin, C.c_float, ns, np.float32))
+            outputs.append(dict(name=name.value.decode(), indexes=arr(idx, C.c_int32, 3 * nidx.value, np.int32).reshape(-1, 3),
+                                supervision=sup, deriv_weights=arr(dw, C.c_float, nidx.value, np.float32)))
+        return dict(inputs=inputs, outputs=outputs)
+    finally:
+        del owner  # (freed now unless a feature array holds it)
+
+
 def merge_chain_examples(examples):
     """[K] MergeChainExamples for examples with one output: inputs with the same name are stacked example by example
     (row blocks; the reference then views them as (batch, time, feat), ``io.py:98-103``); the ``n`` of every index is the

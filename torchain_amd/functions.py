@@ -26,7 +26,12 @@ from ._lib import check, lib
 
 class ChainResults:
     def __init__(self):
-        self.data = torch.zeros(3)
+        # ``data``: the CPU float tensor [objf, l2_term, weight] of the reference (functions.py:11-21).  It is read from
+        # the device when it is first looked at (one 12-byte D2H), not inside ``chain_loss``: a training loop that
+        # logs every few steps enqueues its steps without waiting for the GPU in between -- which is what lets the
+        # reader's hand-over of the next minibatch (io.RandExample) hide behind the running step.
+        self._host = torch.zeros(3)
+        self._stale = False
         # Device-side originals: [objf, l2_term, weight] as the kernels left them (float32[3]) and Kaldi's
         # cross-entropy objective sum(xent_output * xent_deriv) (float64[1]; [K] nnet-chain-training.cc, a TODO in
         # the reference, functions.py:88-89).  The data-parallel wrapper reduces THESE (one collective, no host
@@ -36,6 +41,18 @@ class ChainResults:
         self._xent_scale = 1.0
         self._xent_host = None
         self._defer_host_copy = False  # set by chain_loss_data_parallel: the one D2H follows the all-reduce
+
+    @property
+    def data(self):
+        if self._stale and not self._defer_host_copy and self._dev is not None:
+            self._host.copy_(self._dev)
+            self._stale = False
+        return self._host
+
+    @data.setter
+    def data(self, value):
+        self._host = value
+        self._stale = False
 
     @property
     def xent_objf(self):
@@ -122,9 +139,10 @@ def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, n
             device.index, C.c_void_p(stream))
         check(rc, "tc_chain_objf_and_grad" if as_gradients else "tc_chain_objf_and_deriv")
         if holder is not None:
-            holder._dev = res_dev
-        if holder is None or not holder._defer_host_copy:
-            results.copy_(res_dev)  # 12-byte D2H, the one host sync of the step (reference: >= 4)
+            holder._dev = res_dev  # (ChainResults.data copies it to the host when it is read)
+            holder._stale = True
+        else:
+            results.copy_(res_dev)  # 12-byte D2H, the one host sync of the call (reference: >= 4)
     return results
 
 
@@ -148,6 +166,13 @@ def xent_objective(xent_output, xent_output_deriv):
         return out
 
 
+def _device_loss(results, like):
+    """-objf / weight as a one-element tensor on the input's device (the reference's ``input.new([results.loss])``,
+    functions.py:104) computed from the device-side results: no host round trip."""
+    r = results._dev
+    return (-(r[0] / r[2])).reshape(1).to(like.dtype)
+
+
 class _ChainLoss(Function):
     """Lattice-free MMI loss; see the reference docstring ``torchain/functions.py:23-60`` for the
     meaning of every argument (identical here)."""
@@ -161,7 +186,7 @@ class _ChainLoss(Function):
         mmi_grad = torch.empty_like(input, memory_format=torch.contiguous_format)
         use_xent = xent_input is not None and xent_regularize != 0.0
         xent_grad = torch.empty_like(xent_input, memory_format=torch.contiguous_format) if use_xent else None
-        compute_chain_objf_and_deriv(den_graph, supervision, input.detach(), results.data, mmi_grad, xent_grad,
+        compute_chain_objf_and_deriv(den_graph, supervision, input.detach(), results._host, mmi_grad, xent_grad,
                                      l2_regularize, leaky_hmm_coefficient, xent_regularize, as_gradients=True,
                                      holder=results)
         ctx.mmi_grad = mmi_grad
@@ -171,13 +196,13 @@ class _ChainLoss(Function):
             results._xent_scale = 1.0 / -float(xent_regularize)
             results._xent_host = None
             if not kaldi_way:  # the reference's second call (functions.py:96-103)
-                compute_chain_objf_and_deriv(den_graph, supervision, xent_input.detach(), results.data, mmi_grad,
+                compute_chain_objf_and_deriv(den_graph, supervision, xent_input.detach(), results._host, mmi_grad,
                                              xent_grad, l2_regularize, leaky_hmm_coefficient, xent_regularize,
                                              as_gradients=True, holder=results)
             ctx.xent_grad = xent_grad
         if results._defer_host_copy:
             return input.new_zeros(1)  # (filled in behind the all-reduce: parallel.chain_loss_data_parallel)
-        return input.new_tensor([float(results.loss)])
+        return _device_loss(results, input)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -223,14 +248,14 @@ class _ChainLoss3d(Function):
         use_xent = xent_input is not None and xent_regularize != 0.0
         xe2d = to2d_hip(xent_input.detach()) if use_xent else None
         xent_grad = torch.empty_like(xe2d) if use_xent else None
-        compute_chain_objf_and_deriv(den_graph, supervision, x2d, results.data, mmi_grad, xent_grad,
+        compute_chain_objf_and_deriv(den_graph, supervision, x2d, results._host, mmi_grad, xent_grad,
                                      l2_regularize, leaky_hmm_coefficient, xent_regularize, holder=results)
         if use_xent:
             results._xent_dev = xent_objective(xe2d, xent_grad)
             results._xent_scale = 1.0
             results._xent_host = None
         if use_xent and not kaldi_way:  # the reference's second call (functions.py:96-103)
-            compute_chain_objf_and_deriv(den_graph, supervision, xe2d, results.data, mmi_grad, xent_grad,
+            compute_chain_objf_and_deriv(den_graph, supervision, xe2d, results._host, mmi_grad, xent_grad,
                                          l2_regularize, leaky_hmm_coefficient, xent_regularize, holder=results)
         ctx.mmi_grad = mmi_grad
         ctx.in_shape = tuple(input.shape)
@@ -240,7 +265,7 @@ class _ChainLoss3d(Function):
             ctx.xent_scale = float(xent_regularize)
         if results._defer_host_copy:
             return input.new_zeros(1)
-        return input.new_tensor([float(results.loss)])
+        return _device_loss(results, input)
 
     @staticmethod
     def backward(ctx, grad_output):

@@ -102,7 +102,8 @@ def all_reduce_results(results, group=None, device=None, even_if_alone=False):
         if has_xent:
             host[3] = results.xent_objf
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-    results.data.copy_(host[:3].float())
+    results._host.copy_(host[:3].float())
+    results._stale = False
     results._dev = None  # (the device copy holds this rank's share only)
     results._defer_host_copy = False
     if has_xent:
@@ -112,7 +113,8 @@ def all_reduce_results(results, group=None, device=None, even_if_alone=False):
 
 def _finish_host_copy(results):
     if results._defer_host_copy and results._dev is not None:
-        results.data.copy_(results._dev)
+        results._host.copy_(results._dev)
+        results._stale = False
     results._defer_host_copy = False
 
 
