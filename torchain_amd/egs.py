@@ -59,6 +59,11 @@ class _Reader:
             self.f.seek(pos)
         return b
 
+    def peek_some(self, n):
+        """Between 1 and ``n`` of the next bytes without consuming them (whatever the buffer holds; at least one)."""
+        b = self.f.peek(n)[:n] if hasattr(self.f, "peek") else b""
+        return b if b else self.peek(1) or self.read(1)[:0]
+
     def token(self):
         out = bytearray()
         while True:
@@ -108,19 +113,28 @@ def _read_index_vector(r):
     r.expect("<I1V>")
     size = r.int32()
     out = np.zeros((size, 3), np.int32)
-    n = t = x = 0
-    for i in range(size):
-        c = struct.unpack("b", r.read(1))[0]
-        if abs(c) < 125:
-            if i == 0:
-                n, t, x = 0, c, 0
-            else:
-                t = t + c
-        else:
-            if c != 127:
-                raise EgsFormatError("bad index vector element")
-            n, t, x = r.int32(), r.int32(), r.int32()
+    n = t = x = 0  # (the first element is "absolute" relative to n = t = x = 0)
+    i = 0
+    while i < size:
+        # a run of one-byte elements (the usual case: all of them but the first of each sequence), decoded at once
+        chunk = r.peek_some(size - i)
+        c = np.frombuffer(chunk, np.int8).astype(np.int32)
+        stop = np.flatnonzero(np.abs(c) >= 125)
+        run = int(stop[0]) if len(stop) else len(c)
+        if run > 0:
+            ts = t + np.cumsum(c[:run])
+            out[i:i + run, 0] = n
+            out[i:i + run, 1] = ts
+            out[i:i + run, 2] = x
+            t = int(ts[-1])
+            r.read(run)
+            i += run
+            continue
+        if r.read(1) != b"\x7f":
+            raise EgsFormatError("bad index vector element")
+        n, t, x = r.int32(), r.int32(), r.int32()
         out[i] = (n, t, x)
+        i += 1
     return out
 
 
