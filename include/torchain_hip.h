@@ -274,6 +274,11 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *                     running forward and backward recursion on two CUs at once)
  *   "no_num_overlap" (1: the numerator always follows the denominator on the caller's stream; by default it runs
  *                     beside it on a side stream when the denominator leaves CUs idle)
+ *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
+ * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):
+ *   "no_pair"        (1: never the two-sequence kernel)        "no_tune" (1: no timing launches; the fused kernel)
+ * The same switches can be set from the environment when the library is loaded:
+ *   TORCHAIN_HIP_DEBUG="no_tune,force_streamed=1"   (unknown keys are reported on stderr and ignored).
  * Returns TC_ERR_INVALID_ARGUMENT for an unknown key. */
 int tc_debug_set(const char *key, int value);
 /* Diagnostic counters: "pool_device_allocs" = device allocations made so far by the per-device supervision pool

@@ -246,6 +246,32 @@ int tc_debug_set(const char *key, int value) {
   return TC_ERR_INVALID_ARGUMENT;
 }
 
+// TORCHAIN_HIP_DEBUG="key[=value],key..." in the environment sets the same switches when the library is loaded (for
+// runs that cannot call tc_debug_set, e.g. a profiler around an unmodified program).
+namespace {
+const bool g_env_applied = [] {
+  const char *env = getenv("TORCHAIN_HIP_DEBUG");
+  if (!env) return false;
+  std::string all(env);
+  size_t pos = 0;
+  while (pos <= all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    std::string item = all.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    int value = 1;
+    const size_t eq = item.find('=');
+    if (eq != std::string::npos) {
+      value = atoi(item.c_str() + eq + 1);
+      item.resize(eq);
+    }
+    if (tc_debug_set(item.c_str(), value) != TC_OK) fprintf(stderr, "libtorchain_hip: unknown switch '%s' in TORCHAIN_HIP_DEBUG\n", item.c_str());
+  }
+  return true;
+}();
+}  // namespace
+
 int64_t tc_debug_counter(const char *key) {
   if (key && !strcmp(key, "pool_device_allocs")) return pool_counter(0);
   if (key && !strcmp(key, "pool_reuses")) return pool_counter(1);
