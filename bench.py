@@ -10,7 +10,7 @@ the device -- over one synthetic batch resident in HBM.  With N > 1 there is one
 by the driver through torch.distributed.run, or, when this script is started plainly with --gpus N, by
 this script itself as N fresh children (before anything here touches the GPU).  Each rank owns its own
 256-sequence shard (weak scaling, no data-path collective) and every step ends with the path's only
-exchange, one RCCL all-reduce of the three floats (objf, l2_term, weight) of the rank's shard.
+exchange, one RCCL all-reduce of four float64 (objf, l2_term, weight, xent objective) of the rank's shard.
 Rank 0 prints ONE JSON line.
 """
 import argparse
