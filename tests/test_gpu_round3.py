@@ -95,11 +95,13 @@ def test_full_objective_on_peaky_outputs(oracle, scale):
     assert abs(res[0] - ref["objf"]) <= REL * abs(ref["objf"])
 
 
-@pytest.mark.parametrize("name,S", [("R1", 64), ("R3", 16)])
+@pytest.mark.parametrize("name,S", [("R1", 64), ("R3", 16), ("R1", 161)])
 def test_phone_lm_graphs_at_full_size(oracle, name, S):
     """Graphs with the structure of a real chain den.fst (pruned phone LM x topology x tree; in-degrees 1 .. ~130): R1
     at configs[1]'s batch of 64 x 150 frames, R3 -- whose empty-history states the library splits into 9681
-    chain-structured ones (16 states per thread) -- at 16 x 150; full objective vs the oracle."""
+    chain-structured ones (12 states per thread) -- at 16 x 150, and R1 at an odd batch above one sequence per two CUs
+    (161 x 150: the kernel the library's own timing chose for the graph -- on an MI355X the two-sequence one --
+    with the numerator beside it); full objective vs the oracle."""
     c = synth.CONFIGS[name]
     fst = synth.config_den_fst(name)
     T, P = c["T"], c["P"]
@@ -276,3 +278,21 @@ def test_kernel_choice_is_timed_per_graph(oracle, kernel_family):
     kernel_family("no_tune")
     untimed = io.DenominatorGraph(dense, 4096).prepare(0).tuning(0)
     assert untimed == {"two_sequence_kernel": 0, "fused_ms": 0.0, "two_sequence_ms": 0.0}
+
+
+def test_two_sequence_kernel_repeated_launches_are_identical(kernel_family):
+    """200 back-to-back launches of the two-sequence kernel at a batch that fills the chip with pairs (R1 graph, 254
+    sequences, short utterances): every launch pairs its workgroups anew by ticket and hands over between CUs once;
+    all results are bit-identical and no launch reports a failed hand-over."""
+    fst = synth.config_den_fst("R1")
+    P = synth.CONFIGS["R1"]["P"]
+    S, T = 254, 12
+    y = synth.random_nnet_output(S, T, P, seed=77)
+    kernel_family("force_pair")
+    graph = io.DenominatorGraph(fst, P)
+    first = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
+    assert first["status"] == 0 and np.isfinite(first["logprob"])
+    for _ in range(200):
+        again = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
+        assert again["status"] == 0 and again["logprob"] == first["logprob"]
+        assert np.array_equal(again["deriv"], first["deriv"])
