@@ -255,6 +255,6 @@ def test_workspace_has_room_for_the_two_cu_form_and_switches_exist():
     assert small >= 2 * 64 * hist and small < 2 * 64 * hist + 64 * row + (1 << 20)
     assert large >= 256 * hist and large < 256 * hist + 256 * row + (1 << 20)
     assert lib.tc_chain_workspace_bytes(g.ptr, 128, T) > 2 * 128 * hist > lib.tc_chain_workspace_bytes(g.ptr, 129, T)
-    for key in (b"no_phase_split", b"no_num_overlap", b"no_pair", b"force_pair"):
+    for key in (b"no_phase_split", b"no_num_overlap", b"no_pair", b"force_pair", b"no_tune", b"no_mitm", b"force_mitm"):
         assert lib.tc_debug_set(key, 1) == 0 and lib.tc_debug_set(key, 0) == 0
     assert lib.tc_debug_set(b"no_such_switch", 1) != 0

@@ -296,3 +296,64 @@ def test_two_sequence_kernel_repeated_launches_are_identical(kernel_family):
         again = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
         assert again["status"] == 0 and again["logprob"] == first["logprob"]
         assert np.array_equal(again["deriv"], first["deriv"])
+
+
+# ---- two CUs per sequence meeting in the middle ---------------------------------------------------------------
+def _mitm_vs_fused(oracle, kernel_family, fst, S, T, leaky, seed, l2=0.0, accumulate=False, with_oracle=True):
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=seed)
+    kernel_family("no_phase_split")
+    graph = io.DenominatorGraph(fst, fst.num_pdfs)
+    a = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    kernel_family("no_phase_split", 0)
+    kernel_family("force_mitm")
+    b = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    c = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    kernel_family("force_mitm", 0)
+    kernel_family("no_mitm")
+    d = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0, l2_scale=l2, graph=graph, accumulate=accumulate, init=0.25)
+    kernel_family("no_mitm", 0)
+    assert a["status"] == 0 and b["status"] == 0 and d["status"] == 0
+    assert b["logprob"] == c["logprob"] and np.array_equal(b["deriv"], c["deriv"])  # reproducible bit for bit
+    assert abs(a["logprob"] - b["logprob"]) <= 1e-6 * abs(a["logprob"])
+    assert rel_err(b["deriv"], a["deriv"]) <= 2e-5 and rel_err(d["deriv"], a["deriv"]) <= 2e-5  # (d: the two-pass form)
+    if with_oracle:
+        ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=leaky, deriv_weight=1.0)
+        want = ref["deriv"] - l2 * y + (0.25 if accumulate else 0.0)
+        assert abs(b["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+        assert rel_err(b["deriv"], want) <= REL
+        rows = b["deriv"] + l2 * y - (0.25 if accumulate else 0.0)
+        assert np.abs(rows.sum(axis=1, dtype=np.float64) - 1.0).max() <= 1e-4  # [K]: sum_pdf gamma_t = 1
+
+
+@pytest.mark.parametrize("case", ["even", "odd_frames", "two_frames", "three_frames", "accumulate_l2"])
+def test_meet_in_the_middle_small_graph(oracle, kernel_family, case):
+    """den_tied_mitm.hip: the two roles of a sequence on two CUs, one hand-over at T/2 (T = 2: one frame each side)."""
+    fst = synth.random_den_fst(256, 6, 100, seed=5)
+    S, T, leaky, kw = {"even": (4, 20, 0.1, {}), "odd_frames": (5, 7, 1e-5, {}), "two_frames": (2, 2, 0.1, {}),
+                       "three_frames": (1, 3, 0.1, {}), "accumulate_l2": (6, 11, 0.1, dict(l2=5e-5, accumulate=True))}[case]
+    _mitm_vs_fused(oracle, kernel_family, fst, S, T, leaky, seed=1, **kw)
+
+
+@pytest.mark.parametrize("name,S,T", [("R1", 6, 20), ("C3", 8, 150), ("C5", 4, 40), ("R3", 3, 20), ("X1", 2, 12)])
+def test_meet_in_the_middle_every_layout(oracle, kernel_family, name, S, T):
+    """Hub states (R1), the metric's graph at its full length (C3), three planes of pdfs (C5), 12 and 16 states per
+    thread (R3, X1: tight LDS layout)."""
+    _mitm_vs_fused(oracle, kernel_family, synth.config_den_fst(name), S, T, synth.CONFIGS[name]["leaky"], seed=8,
+                   with_oracle=name != "X1")
+
+
+def test_meet_in_the_middle_is_the_default_from_64_sequences(oracle, kernel_family):
+    """Batches of 64 .. 128 sequences take it by default: 128 x 30 of the C3 graph through the default path equals
+    the forced form bit for bit and the two-pass form to 2e-5."""
+    fst = synth.config_den_fst("C3")
+    S, T = 128, 30
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=14)
+    graph = io.DenominatorGraph(fst, fst.num_pdfs)
+    default = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
+    kernel_family("force_mitm")
+    forced = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
+    kernel_family("force_mitm", 0)
+    kernel_family("no_mitm")
+    two_pass = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
+    assert default["status"] == 0 and np.array_equal(default["deriv"], forced["deriv"])
+    assert not np.array_equal(default["deriv"], two_pass["deriv"]) and rel_err(default["deriv"], two_pass["deriv"]) <= 2e-5

@@ -21,7 +21,8 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Workspace {
   float *big_expy, *big_beta, *big_small, *big_y;  // streamed path only
   int big_exp_frames = 1;
-  float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU form of small batches only (den_tied_split.hip)
+  float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU forms of small batches only (den_tied_split.hip, den_tied_mitm.hip)
+  uint32_t *mitm_sync = nullptr;
   float *pair_norm = nullptr;                      // two-sequence form (den_tied_pair.hip)
   uint32_t *pair_sync = nullptr;
   long long *pair_stamps = nullptr;                // ... its diagnostic builds (-DTC_PAIR_STAMPS): raw cycle stamps
@@ -77,6 +78,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.beta_hist = split ? (float *)take((size_t)(T + 1) * S * Hs * sizeof(float)) : nullptr;
   w.fwd_norm = split ? (float *)take((size_t)S * (T + 2) * sizeof(float)) : nullptr;
   w.bwd_norm = split ? (float *)take((size_t)S * (T + 1) * sizeof(float)) : nullptr;
+  w.mitm_sync = split ? (uint32_t *)take(mitm_sync_bytes(S)) : nullptr;
   w.pair_sync = pair ? (uint32_t *)take(pair_sync_bytes(S)) : nullptr;
   w.pair_norm = pair ? (float *)take((size_t)2 * (S + 1) * pair_norm_stride(T) * sizeof(float)) : nullptr;  // (+ a spare row each)
   w.pair_stamps = pair ? (long long *)take(pair_stamp_bytes(T)) : nullptr;  // (the workspace's last block)
@@ -136,6 +138,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->beta_hist = w.beta_hist;
   p->fwd_norm = w.fwd_norm;
   p->bwd_norm = w.bwd_norm;
+  p->mitm_sync = w.mitm_sync;
   p->pair_norm = w.pair_norm;
   p->pair_sync = w.pair_sync;
   p->pair_stamps = w.pair_stamps;

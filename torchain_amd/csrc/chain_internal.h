@@ -179,6 +179,7 @@ struct DenParams {
   long long *pair_stamps = nullptr;  // diagnostic builds (-DTC_PAIR_STAMPS): [role][wave][T + 2][8] raw cycle stamps of pair 0
   int pair_extra_slots = 0;     // secondary-row slots of the graph's schedules (LDS layout of the pair kernel)
   int pair_choice = 0;        // the graph's tuned choice (DenGraphDev::pair_choice > 0)
+  uint32_t *mitm_sync = nullptr;  // den_tied_mitm.hip: ticket + hand-over words (workspace of batches the two-CU forms may take)
 };
 
 }  // namespace tc
@@ -313,6 +314,10 @@ constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most h
 int launch_den_tied_pair(const DenParams &p, int extra_slots, int accumulate, hipStream_t stream);
 bool pair_fits(const DenLayout &L, int extra_slots, int T);
 int tune_den_variant(tc_den_graph *g, int device);  // api.cpp
+// den_tied_mitm.hip: two CUs per sequence meeting in the middle (batches of at most half the CUs)
+int launch_den_tied_mitm(const DenParams &p, uint32_t *sync, int accumulate, hipStream_t stream);
+bool mitm_fits(const DenLayout &L, int T);
+size_t mitm_sync_bytes(int S);
 int pair_norm_stride(int T);
 size_t pair_sync_bytes(int S);
 inline size_t pair_stamp_bytes(int T) { return ((size_t)2 * kWaves * (T + 2) * 8 * 8 + 255) & ~(size_t)255; }
@@ -349,7 +354,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -455,6 +455,16 @@ static bool split_wanted(const DenParams &p) {
   return p.tied_fs && !p.big.in_begin && p.deriv && p.beta_hist && split_bwd_fits(p.L, p.T) && !debug_flag(kDbgNoPhaseSplit);
 }
 
+// Two CUs per sequence that meet in the middle (den_tied_mitm.hip) instead of two pure recursions and a combining pass.
+// Its time does not depend on the batch (0.71 - 0.77 ms from 1 to 128 sequences of the C2 graph), the combining pass
+// costs 2.7 - 9 us per sequence: the forms cross between 38 (C2, C5) and 68 (R3) sequences, and at 64 meeting in the
+// middle is within 1.5 % or ahead on every graph measured (profiles/r03_configs.txt).
+constexpr int kMitmMinSeq = 64;
+static bool mitm_wanted(const DenParams &p) {
+  if (!p.mitm_sync || !p.bwd_norm || debug_flag(kDbgNoMitm) || !mitm_fits(p.L, p.T)) return false;
+  return debug_flag(kDbgForceMitm) || p.S >= kMitmMinSeq;
+}
+
 // Two sequences per workgroup, the pair's two recursions on two CUs (den_tied_pair.hip): batches the two-CU form of one
 // sequence does not cover.
 static bool pair_wanted(const DenParams &p, int num_cus) {
@@ -487,6 +497,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
     if (pair_wanted(p, c->num_cus)) return launch_den_tied_pair(p, p.pair_extra_slots, accumulate, stream);
     if (split_wanted(p)) {
       if (2 * p.S <= c->num_cus) {
+        if (mitm_wanted(p)) return launch_den_tied_mitm(p, p.mitm_sync, accumulate, stream);
         std::lock_guard<std::recursive_mutex> lock(c->enqueue);
         return launch_den_tied_split(p, accumulate, stream, c);
       }
