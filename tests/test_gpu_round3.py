@@ -342,8 +342,8 @@ def test_meet_in_the_middle_every_layout(oracle, kernel_family, name, S, T):
                    with_oracle=name != "X1")
 
 
-def test_meet_in_the_middle_is_the_default_from_64_sequences(oracle, kernel_family):
-    """Batches of 64 .. 128 sequences take it by default: 128 x 30 of the C3 graph through the default path equals
+def test_meet_in_the_middle_is_the_default_for_larger_batches(oracle, kernel_family):
+    """Batches from 24 (graphs of the C3 class) / 48 / 64 sequences up to half the CUs take it by default: 128 x 30 of the C3 graph through the default path equals
     the forced form bit for bit and the two-pass form to 2e-5."""
     fst = synth.config_den_fst("C3")
     S, T = 128, 30

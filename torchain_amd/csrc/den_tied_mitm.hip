@@ -623,8 +623,14 @@ __global__ __launch_bounds__(kThreads) void den_tied_mitm_kernel(const DenParams
 }
 
 // resident chunks per role (the gamma frames of role F carry B_t and y_{t-1} next to the forward pass)
-constexpr int mitm_res_fwd(int jv, int pv) { return jv == kJvSmall && pv == kPvSmall ? 2 : jv == kJvSmall ? 2 : 0; }
-constexpr int mitm_res_bwd(int jv, int pv) { return jv > kJvMid ? 0 : jv == kJvMid ? (pv == kPvSmall ? 2 : 0) : pv == kPvSmall ? 4 : 2; }
+#ifndef TC_MITM_RF
+#define TC_MITM_RF 4
+#endif
+#ifndef TC_MITM_RB
+#define TC_MITM_RB 4
+#endif
+constexpr int mitm_res_fwd(int jv, int pv) { return jv == kJvSmall && pv == kPvSmall ? TC_MITM_RF : jv == kJvSmall ? 2 : 0; }
+constexpr int mitm_res_bwd(int jv, int pv) { return jv > kJvMid ? 0 : jv == kJvMid ? (pv == kPvSmall ? 2 : 0) : pv == kPvSmall ? TC_MITM_RB : 2; }
 
 template <int JV, int PV>
 int launch_mitm_jp(const DenParams &p, const MitmParams &q, int accumulate, size_t lds_bytes, hipStream_t stream) {
