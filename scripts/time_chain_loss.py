@@ -23,7 +23,9 @@ x.requires_grad_(True)
 
 def step():
     loss, res = chain_loss(x, graph, sup, l2_regularize=cfg.get("l2", 0.0), leaky_hmm_coefficient=cfg["leaky"])
-    loss.backward()
+    # (the gradient as the model's backward would receive it: loss.backward() into a leaf adds a 629 MB copy or
+    # accumulate pass per step that is not part of the path)
+    torch.autograd.grad(loss, x)
     return res
 
 
