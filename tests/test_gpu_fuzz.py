@@ -45,10 +45,12 @@ def _case(oracle, rng, big_mode):
     # positions, T >= 2; odd batches get a phantom partner) -- decided from a value already drawn, so the cases of
     # earlier rounds keep their inputs
     pair = seed % 3 == 0 and not force
+    mitm = seed % 3 == 1 and not force  # ... and another third the two-CU form that meets in the middle (from 2 frames on)
     for key in ("force_streamed", "force_general"):
         lib.tc_debug_set(key.encode(), 1 if key == force else 0)
     lib.tc_debug_set(b"no_phase_split", 1 if fused else 0)
     lib.tc_debug_set(b"force_pair", 1 if pair else 0)
+    lib.tc_debug_set(b"force_mitm", 1 if mitm else 0)
     try:
         g = oracle.DenGraph(fst)
         sup = synth.random_supervision(fst, S, T, 2, seed=seed + 1, initial_probs=g.initial_probs())
@@ -57,7 +59,7 @@ def _case(oracle, rng, big_mode):
         out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True)
         kern = io.DenominatorGraph(fst, fst.num_pdfs).stats()["tied"]
     finally:
-        for key in ("force_streamed", "force_general", "no_phase_split", "force_pair"):
+        for key in ("force_streamed", "force_general", "no_phase_split", "force_pair", "force_mitm"):
             lib.tc_debug_set(key.encode(), 0)
     res = out["results"]
     # objf = num - den is a difference of two log-probs of size ~S*T: when the numerator covers the whole
@@ -66,7 +68,7 @@ def _case(oracle, rng, big_mode):
     e_der = rel_err(out["deriv"], ref["deriv"], floor=1.0)
     e_x = rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0)
     desc = "%s H=%d A=%d P=%d S=%d T=%d leaky=%g l2=%g scale=%g %s%s kernel=%d: objf %.1e deriv %.1e xent %.1e" % (
-        kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, scale, force or ("force_pair" if pair else ""),
+        kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, scale, force or ("force_pair" if pair else "force_mitm" if mitm else ""),
         " fused" if fused else "", kern,
         e_obj, e_der, e_x)
     assert e_obj <= REL and e_der <= REL and e_x <= REL and res[2] == ref["weight"], desc

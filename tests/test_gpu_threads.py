@@ -61,9 +61,10 @@ def test_back_to_back_calls_on_two_streams_without_host_sync(kernel_family, form
     nbytes = lib.tc_chain_workspace_bytes(graph.ptr, S, T)
 
     def enqueue(y, stream):
-        d = torch.empty_like(y)
-        lp = torch.zeros(1, dtype=torch.float64, device="cuda")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        with torch.cuda.stream(stream):  # (the zero fill of lp must be ordered before the call that writes it)
+            d = torch.empty_like(y)
+            lp = torch.zeros(1, dtype=torch.float64, device="cuda")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         check(lib.tc_den_forward_backward(
             graph.ptr, S, C.c_void_p(y.data_ptr()), S * T, P, y.stride(0), 0.1, -1.0, 1e-4, 0,
             C.c_void_p(d.data_ptr()), d.stride(0), C.c_void_p(lp.data_ptr()), None, C.c_void_p(ws.data_ptr()), nbytes, 0,
