@@ -629,7 +629,10 @@ __global__ __launch_bounds__(kThreads) void den_tied_mitm_kernel(const DenParams
 #ifndef TC_MITM_RB
 #define TC_MITM_RB 4
 #endif
-constexpr int mitm_res_fwd(int jv, int pv) { return jv == kJvSmall && pv == kPvSmall ? TC_MITM_RF : jv == kJvSmall ? 2 : 0; }
+#ifndef TC_MITM_RF3
+#define TC_MITM_RF3 2
+#endif
+constexpr int mitm_res_fwd(int jv, int pv) { return jv == kJvSmall && pv == kPvSmall ? TC_MITM_RF : jv == kJvSmall ? 2 : jv == kJvMid && pv == kPvSmall ? TC_MITM_RF3 : 0; }
 constexpr int mitm_res_bwd(int jv, int pv) { return jv > kJvMid ? 0 : jv == kJvMid ? (pv == kPvSmall ? 2 : 0) : pv == kPvSmall ? TC_MITM_RB : 2; }
 
 template <int JV, int PV>
