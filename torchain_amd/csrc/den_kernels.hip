@@ -457,12 +457,12 @@ static bool split_wanted(const DenParams &p) {
 
 // Two CUs per sequence that meet in the middle (den_tied_mitm.hip) instead of two pure recursions and a combining pass.
 // Its time hardly depends on the batch (0.64 - 0.72 ms from 1 to 128 sequences of the C2 graph) while the combining
-// pass costs 2.7 - 9 us per sequence, so the forms cross: at 16 sequences for graphs of the C2 / C3 / R1 class (8 states
+// pass costs 2.7 - 9 us per sequence, so the forms cross: between 16 and 40 sequences for graphs of the C2 / C3 / R1 class (8 states
 // per thread, up to 4096 pdfs: four resident chunks in both roles), near 40 with more pdfs (C5), near 64 with 12 or 16
 // states per thread (R3, X1) -- profiles/r03_configs.txt.
 static bool mitm_wanted(const DenParams &p) {
   if (!p.mitm_sync || !p.bwd_norm || debug_flag(kDbgNoMitm) || !mitm_fits(p.L, p.T)) return false;
-  const int from = p.L.JV == kJvSmall ? (p.L.PV == kPvSmall ? 24 : 48) : 64;
+  const int from = p.L.JV == kJvSmall ? (p.L.PV == kPvSmall ? 32 : 48) : 64;
   return debug_flag(kDbgForceMitm) || p.S >= from;
 }
 

@@ -492,10 +492,13 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
 #define TC_RESB 4
 #endif
 #ifndef TC_RES_JV3
-#define TC_RES_JV3 2
+#define TC_RES_JV3 4
 #endif
-constexpr int res_fwd(int jv, int pv) { return jv > 3 ? 0 : jv == 3 ? (pv == 1 ? TC_RES_JV3 : 0) : pv == 1 ? TC_RESF : 2; }
-constexpr int res_bwd(int jv, int pv) { return jv > 3 ? 0 : jv == 3 ? (pv == 1 ? TC_RES_JV3 : 0) : pv == 1 ? TC_RESB : 2; }
+#ifndef TC_RES_JV4
+#define TC_RES_JV4 2
+#endif
+constexpr int res_fwd(int jv, int pv) { return jv > 3 ? (pv == 1 ? TC_RES_JV4 : 0) : jv == 3 ? (pv == 1 ? TC_RES_JV3 : 0) : pv == 1 ? TC_RESF : 2; }
+constexpr int res_bwd(int jv, int pv) { return jv > 3 ? (pv == 1 ? TC_RES_JV4 : 0) : jv == 3 ? (pv == 1 ? TC_RES_JV3 : 0) : pv == 1 ? TC_RESB : 2; }
 
 template <int JV, int PV>
 int launch_jp(const DenParams &p, int accumulate, size_t lds_bytes, hipStream_t stream) {

@@ -632,8 +632,18 @@ __global__ __launch_bounds__(kThreads) void den_tied_mitm_kernel(const DenParams
 #ifndef TC_MITM_RF3
 #define TC_MITM_RF3 2
 #endif
-constexpr int mitm_res_fwd(int jv, int pv) { return jv == kJvSmall && pv == kPvSmall ? TC_MITM_RF : jv == kJvSmall ? 2 : jv == kJvMid && pv == kPvSmall ? TC_MITM_RF3 : 0; }
-constexpr int mitm_res_bwd(int jv, int pv) { return jv > kJvMid ? 0 : jv == kJvMid ? (pv == kPvSmall ? 2 : 0) : pv == kPvSmall ? TC_MITM_RB : 2; }
+#ifndef TC_MITM_RF4
+#define TC_MITM_RF4 2
+#endif
+#ifndef TC_MITM_RB4
+#define TC_MITM_RB4 2
+#endif
+constexpr int mitm_res_fwd(int jv, int pv) {
+  return jv == kJvSmall ? (pv == kPvSmall ? TC_MITM_RF : 2) : pv != kPvSmall ? 0 : jv == kJvMid ? TC_MITM_RF3 : TC_MITM_RF4;
+}
+constexpr int mitm_res_bwd(int jv, int pv) {
+  return jv == kJvSmall ? (pv == kPvSmall ? TC_MITM_RB : 2) : pv != kPvSmall ? 0 : jv == kJvMid ? 2 : TC_MITM_RB4;
+}
 
 template <int JV, int PV>
 int launch_mitm_jp(const DenParams &p, const MitmParams &q, int accumulate, size_t lds_bytes, hipStream_t stream) {

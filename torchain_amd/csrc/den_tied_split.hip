@@ -340,7 +340,13 @@ __global__ __launch_bounds__(kThreads) void den_tied_combine_kernel(const DenPar
 
 template <int JV, int PV>
 int launch_bwd_jp(const DenParams &p, size_t lds_bytes, hipStream_t stream) {
-  constexpr int RB = JV > 3 ? 0 : JV == 3 ? (PV == 1 ? 2 : 0) : PV == 1 ? 4 : 2;
+#ifndef TC_SPLIT_RB4
+#define TC_SPLIT_RB4 2
+#endif
+#ifndef TC_SPLIT_RB3
+#define TC_SPLIT_RB3 2
+#endif
+  constexpr int RB = JV > 3 ? (PV == 1 ? TC_SPLIT_RB4 : 0) : JV == 3 ? (PV == 1 ? TC_SPLIT_RB3 : 0) : PV == 1 ? 4 : 2;
   void (*k)(const DenParams) = den_tied_bwd_kernel<JV, PV, RB>;
   TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds_bytes));
   hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds_bytes, stream, p);
