@@ -638,11 +638,17 @@ __global__ __launch_bounds__(kThreads) void den_tied_mitm_kernel(const DenParams
 #ifndef TC_MITM_RB4
 #define TC_MITM_RB4 2
 #endif
+#ifndef TC_MITM_RFP
+#define TC_MITM_RFP 2
+#endif
+#ifndef TC_MITM_RBP
+#define TC_MITM_RBP 2
+#endif
 constexpr int mitm_res_fwd(int jv, int pv) {
-  return jv == kJvSmall ? (pv == kPvSmall ? TC_MITM_RF : 2) : pv != kPvSmall ? 0 : jv == kJvMid ? TC_MITM_RF3 : TC_MITM_RF4;
+  return jv == kJvSmall ? (pv == kPvSmall ? TC_MITM_RF : TC_MITM_RFP) : pv != kPvSmall ? 0 : jv == kJvMid ? TC_MITM_RF3 : TC_MITM_RF4;
 }
 constexpr int mitm_res_bwd(int jv, int pv) {
-  return jv == kJvSmall ? (pv == kPvSmall ? TC_MITM_RB : 2) : pv != kPvSmall ? 0 : jv == kJvMid ? 2 : TC_MITM_RB4;
+  return jv == kJvSmall ? (pv == kPvSmall ? TC_MITM_RB : TC_MITM_RBP) : pv != kPvSmall ? 0 : jv == kJvMid ? 2 : TC_MITM_RB4;
 }
 
 template <int JV, int PV>
