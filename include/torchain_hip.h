@@ -276,7 +276,7 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *                     beside it on a side stream when the denominator leaves CUs idle)
  *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
  *   "no_mitm" / "force_mitm" (two CUs per sequence: never / always the form that meets in the middle instead of
- *                     two pure recursions and a combining pass; by default from 24 / 48 / 64 sequences by layout class)
+ *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
  * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):
  *   "no_pair"        (1: never the two-sequence kernel)        "no_tune" (1: no timing launches; the fused kernel)
  * The same switches can be set from the environment when the library is loaded:
