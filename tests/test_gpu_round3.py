@@ -357,3 +357,19 @@ def test_meet_in_the_middle_is_the_default_for_larger_batches(oracle, kernel_fam
     two_pass = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0, graph=graph)
     assert default["status"] == 0 and np.array_equal(default["deriv"], forced["deriv"])
     assert not np.array_equal(default["deriv"], two_pass["deriv"]) and rel_err(default["deriv"], two_pass["deriv"]) <= 2e-5
+
+
+@pytest.mark.parametrize("form", ["fused", "meet_in_the_middle", "two_sequence", "two_pass"])
+def test_long_utterances(oracle, kernel_family, form):
+    """700 frames (the per-frame normalisers live in LDS, the scale chains of the two-CU forms run over hundreds of
+    frames): every kernel family of tied on-chip graphs against the oracle."""
+    kernel_family({"fused": "no_phase_split", "meet_in_the_middle": "force_mitm", "two_sequence": "force_pair",
+                   "two_pass": "no_mitm"}[form])
+    fst = synth.config_den_fst("C3")
+    S, T = 3, 700
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=3)
+    ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=0.1, deriv_weight=1.0)
+    out = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0)
+    assert out["status"] == 0
+    assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+    assert rel_err(out["deriv"], ref["deriv"]) <= REL
