@@ -256,6 +256,8 @@ void read_supervision(In &in, Sup *s) {
   s->T = in.basic<int32_t>();
   in.expect("<LabelDim>");
   s->P = in.basic<int32_t>();
+  if (s->S < 1 || s->T < 1 || s->P < 1 || (int64_t)s->S * s->T > ((int64_t)1 << 26) || !(s->weight == s->weight))
+    throw FormatError{"bad supervision dimensions"};
   if (in.peek() == '<') {  // later Kaldi: <End2End> flag (the FST otherwise starts with its magic number, never '<')
     in.expect("<End2End>");
     if (in.boolean()) throw FormatError{"end-to-end (e2e) supervisions are outside this path"};
