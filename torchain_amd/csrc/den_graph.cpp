@@ -401,6 +401,7 @@ int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pd
   std::vector<int32_t> src, dst, il;
   std::vector<float> w, fin;
   int64_t start = 0, nstates = 0;
+  try {
   do {
     if (r.get<int32_t>() != 2125659606) { rc = TC_ERR_IO; break; }  // kFstMagicNumber
     std::string fsttype = r.str(), arctype = r.str();
@@ -410,13 +411,14 @@ int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pd
     nstates = r.get<int64_t>();
     int64_t narcs = r.get<int64_t>();
     if (!r.ok || fsttype != "vector" || arctype != "standard" || version < 2 || (flags & 4) /* aligned */ ||
-        nstates <= 0 || nstates > (1 << 28)) {
+        nstates <= 0 || nstates > (1 << 24)) {
       rc = TC_ERR_IO;
       break;
     }
     if (flags & 1) r.skip_symbol_table();
     if (flags & 2) r.skip_symbol_table();
-    if (narcs > 0) { src.reserve(narcs); dst.reserve(narcs); il.reserve(narcs); w.reserve(narcs); }
+    // (the header's arc count is a hint, and in a damaged file anything: never allocated from unchecked)
+    if (narcs > 0 && narcs <= (1 << 24)) { src.reserve(narcs); dst.reserve(narcs); il.reserve(narcs); w.reserve(narcs); }
     fin.resize(nstates);
     for (int64_t s = 0; r.ok && s < nstates; ++s) {
       fin[s] = r.get<float>();
@@ -435,6 +437,9 @@ int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pd
     }
     if (!r.ok) rc = TC_ERR_IO;
   } while (0);
+  } catch (...) {  // (out of memory on a damaged file's sizes: no exception crosses the C boundary)
+    rc = TC_ERR_IO;
+  }
   if (is_pipe) {
     if (pclose(f) != 0 && rc == TC_OK) rc = TC_ERR_IO;
   } else {
