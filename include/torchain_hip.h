@@ -122,6 +122,14 @@ typedef struct tc_example tc_example;
 int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n, int merge_single, tc_example **out);
 void tc_example_free(tc_example *example);
 const char *tc_example_last_error(void);
+/* Sequential archives, what the reference reads through SequentialNnetChainExampleReader (src/my_lib_example.cpp:35-69):
+ * rxfilename is a path or "command |" (popen).  tc_archive_next returns 1 and one example as stored (not merged; its key,
+ * NUL-terminated, in key[0..key_cap)), 0 at the end of the archive, or a negative TC_ERR_* (text in
+ * tc_example_last_error).  tc_archive_close returns TC_ERR_IO when a piped command exited with an error. */
+typedef struct tc_archive tc_archive;
+int tc_archive_open(const char *rxfilename, tc_archive **out);
+int tc_archive_next(tc_archive *archive, char *key, int32_t key_cap, tc_example **out);
+int tc_archive_close(tc_archive *archive);
 /* out2 = {number of inputs, number of outputs}. */
 int tc_example_counts(const tc_example *example, int32_t *out2);
 /* Input j (reference my_lib_example_feats, src/my_lib_example.cpp:79-100): pointers into the object, valid until

@@ -74,9 +74,27 @@ def test_end2end_flag_across_a_read_buffer_boundary(tmp_path):
             f.write(key.encode() + b" " + b"\0B" + blob)
         with open(path, "rb") as f:
             assert f.read(8192)[8191 - shift:8192 - shift] == b"<"
-        got = list(egs.iter_rspecifier("ark:" + path))
-        assert len(got) == 1 and got[0][0] == key
-        assert same_fst(got[0][1]["outputs"][0]["supervision"], eg["outputs"][0]["supervision"])
+        for got in (list(egs.iter_archive(path)), list(egs.iter_rspecifier("ark:" + path))):  # numpy reader, native reader
+            assert len(got) == 1 and got[0][0] == key
+            assert same_fst(got[0][1]["outputs"][0]["supervision"], eg["outputs"][0]["supervision"])
+
+
+def test_native_archive_reader_equals_the_numpy_one(tmp_path):
+    """``tc_archive_*`` (sequential archives and ``command |``) against ``egs.iter_archive``: same keys, same examples."""
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    keyed, ark, scp = _write_set(tmp_path, fst, [5, 5, 8, 5], matrix_kind="CM")
+    want = list(egs.iter_archive(ark))
+    for path in (ark, "cat %s |" % ark):
+        got = list(egs.iter_archive_native(path))
+        assert [k for k, _ in got] == [k for k, _ in want] == [k for k, _ in keyed]
+        for (_, a), (_, b) in zip(got, want):
+            _same_example(a, b)
+    with pytest.raises(OSError):
+        list(egs.iter_archive_native(str(tmp_path / "absent.ark")))
+    bad = str(tmp_path / "bad.ark")
+    open(bad, "wb").write(open(ark, "rb").read()[:300])
+    with pytest.raises(egs.EgsFormatError):
+        list(egs.iter_archive_native(bad))
 
 
 def test_malformed_examples_are_refused():

@@ -64,6 +64,12 @@ def _load():
     L.tc_den_graph_stats.argtypes = [vp, vp]
     L.tc_example_read.restype = C.c_int
     L.tc_example_read.argtypes = [vp, vp, C.c_int32, C.c_int, vp]
+    L.tc_archive_open.restype = C.c_int
+    L.tc_archive_open.argtypes = [C.c_char_p, vp]
+    L.tc_archive_next.restype = C.c_int
+    L.tc_archive_next.argtypes = [vp, vp, C.c_int32, vp]
+    L.tc_archive_close.restype = C.c_int
+    L.tc_archive_close.argtypes = [vp]
     L.tc_example_free.restype = None
     L.tc_example_free.argtypes = [vp]
     L.tc_example_last_error.restype = C.c_char_p

@@ -493,6 +493,86 @@ int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n,
 
 void tc_example_free(tc_example *ex) { delete ex; }
 
+// ---- sequential archives ("ark:file", "ark:command |"): key SPACE \0B object, one after the other
+struct tc_archive {
+  std::FILE *f = nullptr;
+  bool pipe = false;
+};
+
+int tc_archive_open(const char *rxfilename, tc_archive **out) {
+  if (!rxfilename || !out) return TC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  std::string name(rxfilename);
+  while (!name.empty() && (name.back() == ' ' || name.back() == '\t' || name.back() == '\n')) name.pop_back();
+  const bool pipe = !name.empty() && name.back() == '|';
+  if (pipe) name.pop_back();
+  std::FILE *f = pipe ? popen(name.c_str(), "r") : std::fopen(name.c_str(), "rb");
+  if (!f) {
+    g_example_error = std::string("cannot open ") + rxfilename;
+    return TC_ERR_IO;
+  }
+  tc_archive *a = new tc_archive();
+  a->f = f;
+  a->pipe = pipe;
+  *out = a;
+  return TC_OK;
+}
+
+int tc_archive_close(tc_archive *a) {
+  if (!a) return TC_OK;
+  int rc = TC_OK;
+  if (a->f) {
+    if (a->pipe) {
+      if (pclose(a->f) != 0) rc = TC_ERR_IO;
+    } else {
+      std::fclose(a->f);
+    }
+  }
+  delete a;
+  return rc;
+}
+
+// 1: an example was read (its key in key[0..key_cap), NUL-terminated); 0: end of the archive; < 0: error
+int tc_archive_next(tc_archive *a, char *key, int32_t key_cap, tc_example **out) {
+  if (!a || !a->f || !key || key_cap < 2 || !out) return TC_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  g_example_error.clear();
+  int c = getc_unlocked(a->f);
+  while (c == ' ' || c == '\n') c = getc_unlocked(a->f);
+  if (c == EOF) return 0;
+  int32_t n = 0;
+  while (c != ' ') {
+    if (c == EOF || n + 1 >= key_cap) {
+      g_example_error = c == EOF ? "archive ends inside a key" : "key too long";
+      return TC_ERR_BAD_FST;
+    }
+    key[n++] = (char)c;
+    c = getc_unlocked(a->f);
+  }
+  key[n] = '\0';
+  try {
+    tc_example *ex = new tc_example();
+    try {
+      In in{a->f};
+      char marker[2];
+      in.read(marker, 2);
+      if (marker[0] != '\0' || marker[1] != 'B') throw FormatError{"text-mode egs are not supported (expected \\0B)"};
+      read_example(in, &ex->eg);
+    } catch (...) {
+      delete ex;
+      throw;
+    }
+    *out = ex;
+  } catch (const FormatError &e) {
+    g_example_error = e.what;
+    return TC_ERR_BAD_FST;
+  } catch (...) {
+    g_example_error = "out of memory";
+    return TC_ERR_IO;
+  }
+  return 1;
+}
+
 const char *tc_example_last_error(void) { return g_example_error.c_str(); }
 
 int tc_example_counts(const tc_example *ex, int32_t *out2) {

@@ -349,11 +349,11 @@ def read_scp_entry(path, offset):
 def iter_rspecifier(rspec):
     kind, path = _split_rspecifier(rspec)
     if kind == "ark":
-        for kv in iter_archive(path):
+        for kv in iter_archive_native(path):  # (iter_archive is the numpy statement of the same format)
             yield kv
     else:
         for key, p, off in read_scp(path):
-            yield key, read_scp_entry(p, off)
+            yield key, read_merged_native([(p, off)], merge_single=False)  # (read_scp_entry: the numpy statement)
 
 
 # ---- merging ([K] MergeChainExamples / AppendSupervision) ----------------------------------------------------
@@ -535,6 +535,15 @@ def read_merged_native(entries, merge_single=True):
         if rc == -6:
             raise OSError(msg or "cannot read an example")
         raise EgsFormatError(msg or "tc_example_read failed: %d" % rc)
+    return _wrap_native(handle)
+
+
+def _wrap_native(handle):
+    """A ``tc_example`` as the dict the numpy reader returns; takes ownership of the handle."""
+    import ctypes as C
+
+    from ._lib import lib
+
     owner = _NativeExample(handle, lib.tc_example_free)
     try:
         def arr(ptr, ctype, count, dtype):
@@ -577,6 +586,32 @@ def read_merged_native(entries, merge_single=True):
         return dict(inputs=inputs, outputs=outputs)
     finally:
         del owner  # (freed now unless a feature array holds it)
+
+
+def iter_archive_native(path):
+    """(key, example) pairs of a sequential binary archive or of a ``command |`` through the library's reader
+    (``tc_archive_*``: the reference reads these through Kaldi's SequentialNnetChainExampleReader,
+    ``src/my_lib_example.cpp:35-69``)."""
+    import ctypes as C
+
+    from ._lib import lib
+
+    arch = C.c_void_p()
+    rc = lib.tc_archive_open(os.fsencode(path), C.cast(C.byref(arch), C.c_void_p))
+    if rc != 0:
+        raise OSError((lib.tc_example_last_error() or b"cannot open archive").decode())
+    key = C.create_string_buffer(1 << 16)
+    try:
+        while True:
+            handle = C.c_void_p()
+            rc = lib.tc_archive_next(arch, C.cast(key, C.c_void_p), 1 << 16, C.cast(C.byref(handle), C.c_void_p))
+            if rc == 0:
+                return
+            if rc < 0:
+                raise EgsFormatError((lib.tc_example_last_error() or b"").decode() or "tc_archive_next failed: %d" % rc)
+            yield key.value.decode(), _wrap_native(handle)
+    finally:
+        lib.tc_archive_close(arch)
 
 
 def merge_chain_examples(examples):
