@@ -47,7 +47,7 @@ def _check(oracle, fst, S, T, scale, leaky, beyond_clamp=False):
     assert abs(out["logprob"] - ref["logprob"]) <= 1e-4 * abs(ref["logprob"])
 
 
-@pytest.mark.parametrize("form", ["two_cu", "fused"])
+@pytest.mark.parametrize("form", ["two_cu", "fused", "meet_in_the_middle", "two_sequence"])
 @pytest.mark.parametrize("leaky", [1e-5, 0.1])
 @pytest.mark.parametrize("scale", [5.0, 10.0, 20.0])
 def test_tied_kernel_peaky_outputs_t150(oracle, kernel_family, scale, leaky, form):
@@ -56,6 +56,10 @@ def test_tied_kernel_peaky_outputs_t150(oracle, kernel_family, scale, leaky, for
     kernel that batches beyond half the chip take."""
     if form == "fused":
         kernel_family("no_phase_split")
+    elif form == "meet_in_the_middle":  # (round 3: den_tied_mitm.hip, the default from 32 sequences on)
+        kernel_family("force_mitm")
+    elif form == "two_sequence":        # (round 3: den_tied_pair.hip; one sequence = a pair with a phantom partner)
+        kernel_family("force_pair")
     _check(oracle, synth.config_den_fst("C2"), 1, 150, scale, leaky)
 
 
