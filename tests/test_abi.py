@@ -258,3 +258,18 @@ def test_workspace_has_room_for_the_two_cu_form_and_switches_exist():
     for key in (b"no_phase_split", b"no_num_overlap", b"no_pair", b"force_pair", b"no_tune", b"no_mitm", b"force_mitm"):
         assert lib.tc_debug_set(key, 1) == 0 and lib.tc_debug_set(key, 0) == 0
     assert lib.tc_debug_set(b"no_such_switch", 1) != 0
+
+
+def test_debug_switches_from_the_environment():
+    """TORCHAIN_HIP_DEBUG="key[=value],..." sets the tc_debug_set switches when the library is loaded; unknown keys are
+    reported on stderr and ignored (the library still loads)."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); from torchain_amd._lib import lib; "
+            "print(lib.tc_debug_set(b'no_tune', 0), lib.tc_debug_set(b'not_a_switch', 1))" % ROOT)
+    env = dict(os.environ, TORCHAIN_HIP_DEBUG="no_tune,force_streamed=0,not_a_switch")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["0", "-1"]
+    assert "unknown switch 'not_a_switch'" in out.stderr
