@@ -285,6 +285,8 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
  *   "no_mitm" / "force_mitm" (two CUs per sequence: never / always the form that meets in the middle instead of
  *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
+ *   "reg_rows"    (1: the tied kernels keep the row sums of their arc walks in LDS even where they could stay in
+ *                     registers -- graphs without hub states, 8 states per thread)
  * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):
  *   "no_pair"        (1: never the two-sequence kernel)        "no_tune" (1: no timing launches; the fused kernel)
  * The same switches can be set from the environment when the library is loaded:

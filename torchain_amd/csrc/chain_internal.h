@@ -75,10 +75,14 @@ struct ScheduleHost {
   int64_t real_arcs = 0, padded_arcs = 0;
   int32_t rows = 0;
   // owner-computes schedules of tied graphs (schedule_owner.cpp: build_owner)
-  std::vector<uint32_t> masks;        // [wave][mask_stride]: bit i of word j <=> a row ends after pair 8 j + i
+  std::vector<uint32_t> masks;        // [wave][mask_stride]: row-end bits of pairs 8 j .. 8 j + 7 and the rows ended before its two chunks (emit_owner_stream)
   int32_t mask_stride = 0;
   std::vector<int32_t> extra_first;   // per wave: index of its first secondary-row slot group
   int32_t nfix = 0;                   // number of fix-up entries (0: no barrier after the walk)
+  // [wave][img_stride chunks][4]: for each of a chunk's eight cells the 16-bit image of M0 under which the cell's FMA
+  // finds its row register in GPR-index mode, 0xC000 | row index (den_tied_rr.hip); two cells per word
+  std::vector<uint32_t> images;
+  int32_t img_stride = 0, max_chunks = 0;  // max_chunks: the longest wave stream, in chunks
 };
 
 struct ScheduleDev {
@@ -90,6 +94,8 @@ struct ScheduleDev {
   const int32_t *extra_first = nullptr;
   int32_t mask_stride = 0, nfix = 0;
   const void *cells_pair = nullptr;     // tied graphs of at most 8192 positions: the stream with offsets = position * 8
+  const uint32_t *images = nullptr;     // owner-computes schedules: row-register images per chunk (ScheduleHost::images)
+  int32_t img_stride = 0, max_chunks = 0;
 };
 
 // ---- graphs too large for the on-chip layout ("streamed" path, den_big_kernel.hip) ------------------
@@ -304,6 +310,10 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes);             
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip
+// den_tied_rr.hip: the fused kernel with the row sums in registers and one more chunk of the stream in LDS (graphs without
+// hub states, 8 states and 4 pdfs per thread)
+bool rr_fits(const DenParams &p);
+int launch_den_tied_rr(const DenParams &p, int accumulate, hipStream_t stream);
 // den_tied_split.hip: the backward recursion alone (to run beside a forward-only launch_den_tied), and the pass
 // that forms gamma / the derivative from the two histories
 int launch_den_tied_backward_only(const DenParams &p, hipStream_t stream);
@@ -354,7 +364,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -505,6 +505,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
     }
     DenParams pq = p;
     pq.fwd_norm = nullptr;
+    if (rr_fits(pq)) return launch_den_tied_rr(pq, accumulate, stream);  // den_tied_rr.hip
     return launch_den_tied(pq, accumulate, stream);  // den_tied_kernel.hip
   }
 #define TC_DISPATCH(J, V) \

@@ -40,6 +40,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   out->cells.clear();
   out->wave_range.assign(kWaves, make_int2(0, 0));
   std::vector<std::vector<uint32_t>> wave_masks(kWaves);
+  std::vector<std::vector<char>> wave_row_end;  // per wave and pair of cells: flags A | B
   int64_t arc_cells = 0;
   int nrows = 0;
   for (int w = 0; w < kWaves; ++w) {
@@ -94,6 +95,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
       if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
     }
+    wave_row_end.push_back(row_end);
   }
   // readable padding: the kernels request up to four chunks past a wave's range
   for (int i = 0; i < 64 * 32; ++i) out->cells.push_back(ArcRec{0.f, 0u});
@@ -103,6 +105,25 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   out->mask_stride = (int32_t)stride;
   out->masks.assign(stride * kWaves, 0u);
   for (int w = 0; w < kWaves; ++w) std::copy(wave_masks[w].begin(), wave_masks[w].end(), out->masks.begin() + w * stride);
+  // row-register images (den_tied_rr.hip): cell i of a wave's stream belongs to row (number of row ends before it); rows
+  // beyond 15 -- secondary rows of hub states, which that kernel does not take -- are capped
+  {
+    size_t max_chunks = 1;
+    for (auto &re : wave_row_end) max_chunks = std::max(max_chunks, (re.size() + 3) / 4);
+    out->img_stride = (int32_t)std::max<size_t>(max_chunks + 4, 16);  // (+ the chunks a walk may request ahead; a register's worth)
+    out->max_chunks = (int32_t)max_chunks;
+    out->images.assign((size_t)kWaves * out->img_stride * 4, 0xC000C000u);
+    for (int w = 0; w < kWaves; ++w) {
+      int row = 0;
+      for (size_t pr = 0; pr < wave_row_end[w].size(); ++pr) {
+        const uint32_t first = 0xC000u | (uint32_t)std::min(row, 15);
+        if (wave_row_end[w][pr] & 2) ++row;  // the row ends with the pair's first cell
+        const uint32_t second = 0xC000u | (uint32_t)std::min(row, 15);
+        if (wave_row_end[w][pr] & 1) ++row;
+        out->images[((size_t)w * out->img_stride + pr / 4) * 4 + pr % 4] = first | second << 16;
+      }
+    }
+  }
   out->real_arcs = (int64_t)order.size();
   out->padded_arcs = arc_cells;
   out->rows = nrows;
@@ -242,6 +263,63 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     wave_groups[best].push_back(gr.idx);
     load_in[best] += gr.cin;
     load_out[best] += gr.cout;
+  }
+  // A wave's stream is padded to whole chunks of 8 steps, and a chunk of padding costs a walk as much as a chunk of arcs:
+  // dealt by load alone, 10 of C3's 16 forward streams were 57 steps -- 8 chunks -- long.  Groups trade places between
+  // waves while that lowers the number of chunks (first the longest stream's, then the sum over waves and directions).
+  {
+    auto chunks = [](int64_t steps) { return (std::max<int64_t>(steps, (int64_t)kTiedMinChunks * kStreamUnrollTied) + kStreamUnrollTied - 1) / kStreamUnrollTied; };
+    auto cost = [&]() {
+      int64_t mx_in = 0, mx_out = 0, sum = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        mx_in = std::max(mx_in, chunks(load_in[w]));
+        mx_out = std::max(mx_out, chunks(load_out[w]));
+        sum += chunks(load_in[w]) + chunks(load_out[w]);
+      }
+      return (mx_in + mx_out) * 1000 + sum;
+    };
+    bool improved = true;
+    for (int round = 0; round < 50 && improved; ++round) {
+      improved = false;
+      for (int w1 = 0; w1 < kWaves; ++w1)
+        for (int w2 = w1 + 1; w2 < kWaves; ++w2)
+          for (size_t i1 = 0; i1 < wave_groups[w1].size(); ++i1)
+            for (size_t i2 = 0; i2 < wave_groups[w2].size(); ++i2) {
+              const Group &a = groups[wave_groups[w1][i1]], &b = groups[wave_groups[w2][i2]];
+              if (a.cin == b.cin && a.cout == b.cout) continue;
+              const int64_t before = cost();
+              load_in[w1] += b.cin - a.cin;
+              load_out[w1] += b.cout - a.cout;
+              load_in[w2] += a.cin - b.cin;
+              load_out[w2] += a.cout - b.cout;
+              if (cost() < before) {
+                std::swap(wave_groups[w1][i1], wave_groups[w2][i2]);
+                improved = true;
+              } else {
+                load_in[w1] -= b.cin - a.cin;
+                load_out[w1] -= b.cout - a.cout;
+                load_in[w2] -= a.cin - b.cin;
+                load_out[w2] -= a.cout - b.cout;
+              }
+            }
+    }
+  }
+  // ... and the longest streams go to the youngest waves, which the kernels run at the highest issue priority
+  // (den_tied_device.h: age_prio_on): every frame waits for its slowest wave
+  {
+    std::vector<int> order(kWaves);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return load_in[x] + load_out[x] < load_in[y] + load_out[y]; });
+    std::vector<std::vector<int>> wg(kWaves);
+    std::vector<int64_t> li(kWaves), lo(kWaves);
+    for (int w = 0; w < kWaves; ++w) {
+      wg[w] = wave_groups[order[w]];
+      li[w] = load_in[order[w]];
+      lo[w] = load_out[order[w]];
+    }
+    wave_groups.swap(wg);
+    load_in.swap(li);
+    load_out.swap(lo);
   }
   g->pos.assign(H, 0);
   std::vector<int32_t> state_at(Npos, -1);
