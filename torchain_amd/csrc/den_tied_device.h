@@ -194,6 +194,12 @@ __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc
   }
 }
 
+// the mask words of a wave's stream, word i in lane i (streams of up to 128 chunks: far beyond what fits on chip)
+__device__ __forceinline__ uint32_t wave_masks(const ScheduleDev &sc, int wave, uint32_t lane) {
+  const uint32_t i = lane < (uint32_t)sc.mask_stride ? lane : (uint32_t)sc.mask_stride - 1u;
+  return sc.masks[(size_t)wave * sc.mask_stride + i];
+}
+
 // One walk of a wave's stream: RES resident chunks, then the rest through two register buffers in
 // ping-pong (qa arrives preloaded with chunk RES when there is one; the stream is followed by readable
 // padding, so the look-ahead loads need no guard).  The mask words come through the scalar cache.
@@ -204,18 +210,21 @@ constexpr int kWalkEnd = -1000;  // last call of a walk's hook when nothing is r
 
 template <uint32_t SRC, int RES, class AfterChunk>
 __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chunk6 &qa, rsrc_t sbase,
-                                     uint32_t lane16, int nchunks, const uint32_t *masks, RowCommit rc,
+                                     uint32_t lane16, int nchunks, uint32_t vmask, RowCommit rc,
                                      AfterChunk after_chunk TC_WALK_ARG) {
   static_assert(RES % 2 == 0, "a mask word covers two chunks");
-  typedef __attribute__((address_space(4))) const uint32_t const_u32;
-  const_u32 *mk = (const_u32 *)masks;
+  // The wave's mask words sit in ONE vector register, word i in lane i (wave_masks() below), and come out through
+  // v_readlane.  Read from memory where they were needed (one s_load_dword per two chunks), every second chunk lost the
+  // counted waits on its gathers: scalar loads return out of order with LDS operations, so with one in flight the first
+  // wait of the chunk is lgkmcnt(0) -- all eight gathers and a scalar-cache round trip before the first FMA.
+  auto mk = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)vmask, i); };
   float acc = 0.f;
 #ifdef TC_PHASE_STAMPS
   wst[2] = clock64();
 #endif
 #pragma unroll
   for (int i = 0; i < RES / 2; ++i) {
-    const uint32_t m = mk[i];
+    const uint32_t m = mk(i);
     do_chunk<SRC, 0>(res[2 * i], m, acc, rc);
     after_chunk(2 * i);
     do_chunk<SRC, 1>(res[2 * i + 1], m, acc, rc);
@@ -235,7 +244,7 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
   Chunk6 qb;
   int c = RES;
   for (; c + 2 < nchunks; c += 2) {
-    const uint32_t m = mk[c >> 1];
+    const uint32_t m = mk(c >> 1);
     load_chunk(qb, sbase, lane16, c + 1);
     do_chunk<SRC, 0>(qa, m, acc, rc);
     load_chunk(qa, sbase, lane16, c + 2);
@@ -243,12 +252,12 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
     if (RES == 0) after_chunk(-1 - (c >> 1));
   }
   if (c + 1 < nchunks) {
-    const uint32_t m = mk[c >> 1];
+    const uint32_t m = mk(c >> 1);
     load_chunk(qb, sbase, lane16, c + 1);
     do_chunk<SRC, 0>(qa, m, acc, rc);
     do_chunk<SRC, 1>(qb, m, acc, rc);
   } else if (c < nchunks) {
-    do_chunk<SRC, 0>(qa, mk[c >> 1], acc, rc);
+    do_chunk<SRC, 0>(qa, mk(c >> 1), acc, rc);
   }
   if (RES == 0) after_chunk(kWalkEnd);
 #ifdef TC_PHASE_STAMPS

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
     const rsrc_t fbase = make_rsrc(reinterpret_cast<const char *>(p.fwd.cells) +
                                        (int64_t)(__builtin_amdgcn_readfirstlane(frange.x) / kChunk) * (3 * 64 * 16),
                                    (uint32_t)(fnch + 2) * (3 * 64 * 16));
-    const uint32_t *const fmask = p.fwd.masks + wave * p.fwd.mask_stride;
+    const uint32_t fmask = wave_masks(p.fwd, wave, lane);
     const int ffx0 = p.fwd.nfix ? p.fwd.fix_begin[tid] : 0, ffx1 = p.fwd.nfix ? p.fwd.fix_begin[tid + 1] : 0;
     const RowCommit frc{aACC + 256u * (uint32_t)(K * wave), aACC + 256u * (uint32_t)(K * kWaves + p.fwd.extra_first[wave]), K};
     Chunk6 fres[RESF > 0 ? RESF : 1];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
   const rsrc_t bbase = make_rsrc(reinterpret_cast<const char *>(p.bwd.cells) +
                                      (int64_t)(__builtin_amdgcn_readfirstlane(brange.x) / kChunk) * (3 * 64 * 16),
                                  (uint32_t)(bnch + 2) * (3 * 64 * 16));
-  const uint32_t *const bmask = p.bwd.masks + wave * p.bwd.mask_stride;
+  const uint32_t bmask = wave_masks(p.bwd, wave, lane);
   const int bfx0 = p.bwd.nfix ? p.bwd.fix_begin[tid] : 0, bfx1 = p.bwd.nfix ? p.bwd.fix_begin[tid + 1] : 0;
   const RowCommit brc{aACC + 256u * (uint32_t)(K * wave), aACC + 256u * (uint32_t)(K * kWaves + p.bwd.extra_first[wave]), K};
   Chunk6 bres[RESB > 0 ? RESB : 1];
