@@ -165,7 +165,7 @@ def main():
 
     import numpy as np
     import torch
-    from torchain_amd import io, synth
+    from torchain_amd import io, parallel, synth
     from torchain_amd._lib import check, lib
     from torchain_amd.functions import ChainResults, compute_chain_objf_and_deriv
 
@@ -225,7 +225,12 @@ def main():
     # Upload of the graph's tables; tc_den_graph_prepare also times the graph's two kernels once.  Done
     # here, behind the seconds of host-side input generation above, the device goes into the warm-up from the clocks of
     # a running job instead of from idle (the first ~10 launches after idle run 10 - 30 % slow while the clocks ramp).
-    graph.prepare(dev)
+    # Every rank runs the kernel rank 0 chose (cached from an earlier run, or timed once): the two kernels differ in the last bits.
+    if world > 1:
+        parallel.sync_den_graph_variant(graph, dev)
+    else:
+        graph.prepare(dev)
+    tuning = graph.tuning(dev)
 
     def den_step():
         rc = lib.tc_den_forward_backward(
@@ -349,8 +354,13 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("den_tied_kernel (tied graph path)" if tied == 1 else
+                         "kernel": (("den_tied_pair_kernel (tied graph path, two sequences per workgroup)"
+                                     if tuning["two_sequence_kernel"] else "den_tied_kernel (tied graph path, fused)")
+                                    if tied == 1 else
                                     "streamed kernels" if tied == 2 else "den_fwd_bwd_kernel (general graph path)"),
+                         # the per-graph choice between the fused and the two-sequence kernel and the two times it was
+                         # made on (zeros: taken from the cache of an earlier run, or the graph has one kernel only)
+                         "kernel_choice": tuning,
                          "kernel_ms": kern_ms, "algorithmic_bytes": bytes_alg},
             "check": {"den_logprob_per_frame": logprob / (S * T), "status": status},
         }

@@ -254,6 +254,18 @@ int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 int tc_den_graph_tuning(tc_den_graph *graph, int device, int32_t *two_sequence_kernel, float *fused_ms,
                         float *two_sequence_ms);
 
+/* Fixes that choice instead of timing it: two_sequence_kernel = 0 / 1, or -1 to forget a fixed choice (the next
+ * tc_den_graph_prepare on the device times again).  Called BEFORE the graph first reaches `device` no timing launch is
+ * made at all; called later the choice applies from the next launch on.  This is what makes the choice reproducible:
+ * each kernel is bitwise reproducible by itself, the two differ in the last bits, and a timing race decides by clock
+ * noise for a graph near the 3 % threshold -- from run to run and from rank to rank.  The Python wrapper keeps a cache
+ * of the measured choices keyed by tc_den_graph_hash and the device name (io.DenominatorGraph.prepare) and applies
+ * rank 0's choice on every rank of a data-parallel job (parallel.sync_den_graph_variant).
+ * (The reference's call is deterministic for fixed inputs: src/my_lib_chain.cpp:129-131.) */
+int tc_den_graph_set_variant(tc_den_graph *graph, int device, int32_t two_sequence_kernel);
+/* 64-bit FNV-1a hash of the graph (sizes, arcs, pdfs, probabilities): the key of such a cache.  0 for a null handle. */
+uint64_t tc_den_graph_hash(const tc_den_graph *graph);
+
 /* ---- layout conversion either side of the path -------------------------- */
 
 /* Replaces `to2d` (torchain/functions.py:118-125: x.permute(2,0,1).contiguous().view(-1, C)):
@@ -285,8 +297,9 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
  *   "no_mitm" / "force_mitm" (two CUs per sequence: never / always the form that meets in the middle instead of
  *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
- *   "reg_rows"    (1: the tied kernels keep the row sums of their arc walks in LDS even where they could stay in
- *                     registers -- graphs without hub states, 8 states per thread)
+ *   "reg_rows"       (1: den_tied_rr.hip -- row sums of the arc walks in registers, one more chunk of every wave's stream
+ *                     in LDS -- where it fits: graphs without hub states, 8 states and 4 pdfs per thread, aligned rows.
+ *                     Measured slower than the default kernel at C3; kept selectable for that record)
  * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):
  *   "no_pair"        (1: never the two-sequence kernel)        "no_tune" (1: no timing launches; the fused kernel)
  * The same switches can be set from the environment when the library is loaded:

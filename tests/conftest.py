@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the measured kernel choices of the graphs the tests build stay out of the user's cache (io.DenominatorGraph.prepare)
+import tempfile  # noqa: E402
+
+os.environ.setdefault("TORCHAIN_TUNING_CACHE", os.path.join(tempfile.gettempdir(), "torchain_tuning_tests_%d.json" % os.getpid()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

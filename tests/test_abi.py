@@ -273,3 +273,19 @@ def test_debug_switches_from_the_environment():
     assert out.returncode == 0, out.stderr
     assert out.stdout.split() == ["0", "-1"]
     assert "unknown switch 'not_a_switch'" in out.stderr
+
+
+def test_graph_hash_and_fixed_kernel_choice_need_no_gpu():
+    """tc_den_graph_hash keys the cache of measured kernel choices (io.DenominatorGraph.prepare); tc_den_graph_set_variant
+    fixes a choice before the graph reaches a device (nothing is uploaded here)."""
+    from torchain_amd import io, synth
+    from torchain_amd._lib import lib
+    a = io.DenominatorGraph(synth.config_den_fst("C1"), 200)
+    b = io.DenominatorGraph(synth.config_den_fst("C1"), 200)
+    c = io.DenominatorGraph(synth.random_den_fst(300, 4, 200, seed=3), 200)
+    ha, hb, hc = (int(lib.tc_den_graph_hash(g.ptr)) for g in (a, b, c))
+    assert ha == hb and ha != hc and ha != 0 and lib.tc_den_graph_hash(None) == 0
+    for v in (0, 1, -1):
+        assert lib.tc_den_graph_set_variant(a.ptr, 0, v) == 0
+    assert lib.tc_den_graph_set_variant(a.ptr, 0, 2) < 0 and lib.tc_den_graph_set_variant(a.ptr, 0, -2) < 0
+    assert lib.tc_den_graph_set_variant(None, 0, 0) < 0

@@ -251,6 +251,16 @@ def test_native_merge_equals_the_numpy_statement_and_meets_its_time_bound():
     broken = synth.SupFst(bad.weight, 1, 12, bad.label_dim, bad.num_states, bad.arc_begin, bad.ilabel, bad.arc_weight, nx, bad.final)
     with pytest.raises(egs.EgsFormatError):
         egs.append_supervisions([bad, broken])
+    # refused, not read past the end of the per-time counts: a dead-end chain longer than the piece -- states
+    # 0 -> 1 (final) and 0 -> 2 -> 3 -> 4 with frames = 1; the final states alone sit where they should
+    inf = np.float32(np.inf)
+    dead = synth.SupFst(1.0, 1, 1, bad.label_dim, 5, np.array([0, 2, 2, 3, 4, 4], np.int32), np.array([1, 2, 3, 4], np.int32),
+                        np.zeros(4, np.float32), np.array([1, 2, 3, 4], np.int32), np.array([inf, 0.0, inf, inf, inf], np.float32))
+    ok1 = synth.SupFst(1.0, 1, 1, bad.label_dim, 2, np.array([0, 1, 1], np.int32), np.array([1], np.int32), np.zeros(1, np.float32),
+                       np.array([1], np.int32), np.array([inf, 0.0], np.float32))
+    for pieces in ([dead, ok1], [ok1, dead], [ok1, dead, ok1]):
+        with pytest.raises(egs.EgsFormatError):
+            egs.append_supervisions(pieces)
     big = [synth.random_supervision(fst, 1, 150, 10, seed=100 + i) for i in range(64)]
     assert 9.0 <= np.mean([len(p.ilabel) / 150.0 for p in big]) <= 11.0
     egs.append_supervisions(big)

@@ -1,0 +1,167 @@
+"""Round 4 ("Next round" items 4 and 7):
+
+* the per-graph kernel choice is REPRODUCIBLE: a second handle of the same graph takes the first one's measured choice
+  from the cache (``io.DenominatorGraph.prepare``) without timing anything and its derivatives are bit-identical; a
+  choice fixed by the caller (``tc_den_graph_set_variant``) is honoured, and both kernels agree with the oracle
+  (the reference's call is deterministic for fixed inputs: ``src/my_lib_chain.cpp:129-131``);
+* ELEMENT-WISE derivative checks at full size (C2, C5, R1, R3; C3 has had one since round 2): entries above 1e-3 within
+  1e-4 relative, entries above 1e-4 within 1e-3 -- ``north_star``'s "within 1e-4 relative" read per element where an
+  element is large enough to carry four digits in float32 posteriors (DESIGN.md section 1 says where the tied kernels'
+  subtraction form of gamma stops: entries of 1e-6 are a few per cent off);
+* co-tenancy: the kernels whose workgroups wait for each other (two CUs per sequence meeting in the middle, two
+  sequences per workgroup) launched while a long kernel on another stream holds half of the CUs -- no failed
+  hand-over, results identical to an undisturbed run;
+* the opt-in register-row kernel (den_tied_rr.hip) against the default kernel and the oracle.
+Reference property tests these restate: ``src/chain-supervision-test.hpp:239-341``."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from torchain_amd import io, synth
+from torchain_amd._lib import check, lib
+
+from helpers import hip_chain, hip_den, rel_err
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def elementwise(got, ref, what):
+    """entries of |ref| > 1e-3 within 1e-4 relative, entries > 1e-4 within 1e-3 relative"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    for floor, tol in ((1e-3, 1e-4), (1e-4, 1e-3)):
+        m = np.abs(ref) > floor
+        assert m.any(), (what, floor)
+        worst = float((np.abs(got[m] - ref[m]) / np.abs(ref[m])).max())
+        assert worst <= tol, (what, "entries above %g: worst relative error %.3g > %g" % (floor, worst, tol))
+
+
+def test_kernel_choice_is_reproducible_and_can_be_fixed(oracle):
+    """R1 (the graph whose choice the timing makes: the two-sequence kernel wins by 6-12 %)."""
+    fst = synth.config_den_fst("R1")
+    P = synth.CONFIGS["R1"]["P"]
+    S, T = 192, 12
+    y = synth.random_nnet_output(S, T, P, seed=31)
+    g1 = io.DenominatorGraph(fst, P).prepare("cuda:0")
+    t1 = g1.tuning("cuda:0")
+    a = hip_den(fst, y, S, leaky=0.1, graph=g1)
+    # a fresh handle of the same graph: the cached choice, no timing launches (both times reported as zero)
+    g2 = io.DenominatorGraph(fst, P).prepare("cuda:0")
+    t2 = g2.tuning("cuda:0")
+    assert t2["two_sequence_kernel"] == t1["two_sequence_kernel"]
+    assert t1["fused_ms"] > 0 and t2["fused_ms"] == 0.0 and t2["two_sequence_ms"] == 0.0, (t1, t2)
+    b = hip_den(fst, y, S, leaky=0.1, graph=g2)
+    assert a["logprob"] == b["logprob"] and np.array_equal(a["deriv"], b["deriv"])
+    # the other kernel, fixed by the caller on a third handle before it reaches the device: no timing either
+    other = 1 - t1["two_sequence_kernel"]
+    g3 = io.DenominatorGraph(fst, P).prepare("cuda:0", variant=other)
+    t3 = g3.tuning("cuda:0")
+    assert t3["two_sequence_kernel"] == other and t3["fused_ms"] == 0.0
+    c = hip_den(fst, y, S, leaky=0.1, graph=g3)
+    assert not np.array_equal(a["deriv"], c["deriv"])  # (it IS another kernel)
+    assert rel_err(c["deriv"], a["deriv"], floor=1.0) <= 2e-6 and abs(c["logprob"] - a["logprob"]) <= 1e-6 * abs(a["logprob"])
+    # and switched on a graph that is already on the device: from the next launch on
+    check(lib.tc_den_graph_set_variant(g3.ptr, 0, t1["two_sequence_kernel"]), "tc_den_graph_set_variant")
+    d = hip_den(fst, y, S, leaky=0.1, graph=g3)
+    assert np.array_equal(a["deriv"], d["deriv"])
+    g = oracle.DenGraph(fst)
+    ref = oracle.den_forward_backward(g, y, S, 0.1, 1.0)
+    for out in (a, c):
+        assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+    assert lib.tc_den_graph_set_variant(g3.ptr, 0, 2) < 0 and lib.tc_den_graph_set_variant(None, 0, 0) < 0
+
+
+@pytest.mark.parametrize("cfg,S,T", [("C2", 64, 150), ("C5", 128, 150), ("R1", 64, 150), ("R3", 16, 150)])
+def test_full_size_derivative_element_wise(oracle, cfg, S, T):
+    """The denominator's derivative (posteriors in [0, 1]) entry by entry against the oracle."""
+    c = synth.CONFIGS[cfg]
+    fst = synth.config_den_fst(cfg)
+    y = synth.random_nnet_output(S, T, c["P"], seed=77)
+    out = hip_den(fst, y, S, leaky=c["leaky"])
+    ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, c["leaky"], 1.0)
+    assert out["status"] == 0 and abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+    assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
+    elementwise(out["deriv"], ref["deriv"], cfg)
+
+
+def test_golden_derivative_element_wise():
+    """... and against the float64 fixtures (tests/golden: generated by oracle/independent_f64.py)."""
+    import os
+
+    from test_oracle_golden import GOLDEN, load
+    checked = 0
+    for path in GOLDEN:
+        z, fst, sup = load(path)
+        y = np.ascontiguousarray(z["nnet_output"], np.float32)
+        out = hip_den(fst, y, sup.num_sequences, leaky=float(z["leaky"]))
+        ref = np.asarray(z["den_deriv"], np.float64)
+        if (np.abs(ref) > 1e-3).any() and (np.abs(ref) > 1e-4).any():
+            elementwise(out["deriv"], ref, os.path.basename(path))
+            checked += 1
+    assert checked > 0
+
+
+def _occupy_half_the_cus(stream, millis):
+    """A long kernel on ``stream`` that holds half of the CUs: torch kernels sized to the device, far more work than
+    the launches under test (a matmul chain of ~`millis` ms on 128 of the 256 CUs' worth of workgroups)."""
+    n = 2048
+    a = torch.randn(n, n, device="cuda")
+    with torch.cuda.stream(stream):
+        x = a
+        for _ in range(max(1, millis // 2)):
+            x = torch.tanh(x @ a * 1e-3)
+    return x
+
+
+@pytest.mark.parametrize("mode", ["force_mitm", "force_pair"])
+def test_paired_workgroups_with_a_co_tenant(kernel_family, mode):
+    """den_tied_mitm.hip / den_tied_pair.hip pair workgroups by ticket and hand rows over through flags in global memory
+    (bounded spins, soft failure).  Here another stream keeps the GPU busy with large GEMMs meanwhile: the pairs'
+    workgroups are no longer co-resident by default.  No hand-over may fail (status 0, finite log-prob) and the results
+    must equal an undisturbed run's bit for bit."""
+    kernel_family("no_tune")
+    kernel_family(mode)
+    fst = synth.config_den_fst("C2")
+    P = synth.CONFIGS["C2"]["P"]
+    S, T = (96, 60) if mode == "force_mitm" else (200, 60)
+    y = synth.random_nnet_output(S, T, P, seed=5)
+    graph = io.DenominatorGraph(fst, P)
+    quiet = hip_den(fst, y, S, leaky=0.1, graph=graph)
+    assert quiet["status"] == 0 and np.isfinite(quiet["logprob"])
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        busy = _occupy_half_the_cus(side, 40)
+        out = hip_den(fst, y, S, leaky=0.1, graph=graph)
+        side.synchronize()
+        assert out["status"] == 0 and out["logprob"] == quiet["logprob"], (mode, rep)
+        assert np.array_equal(out["deriv"], quiet["deriv"]), (mode, rep)
+        del busy
+
+
+def test_register_row_kernel_matches_the_default_kernel(oracle, kernel_family):
+    """den_tied_rr.hip (opt-in, ``reg_rows``): C2's graph, the fused form of a batch, against the default kernel and the
+    oracle; bitwise reproducible."""
+    kernel_family("no_phase_split")
+    kernel_family("no_tune")
+    fst = synth.config_den_fst("C2")
+    P = synth.CONFIGS["C2"]["P"]
+    S, T = 24, 40
+    y = synth.random_nnet_output(S, T, P, seed=8)
+    graph = io.DenominatorGraph(fst, P)
+    base = hip_den(fst, y, S, leaky=0.1, graph=graph, l2_scale=5e-5)
+    kernel_family("reg_rows")
+    a = hip_den(fst, y, S, leaky=0.1, graph=graph, l2_scale=5e-5)
+    b = hip_den(fst, y, S, leaky=0.1, graph=graph, l2_scale=5e-5)
+    assert a["status"] == 0 and np.array_equal(a["deriv"], b["deriv"]) and a["logprob"] == b["logprob"]
+    assert not np.array_equal(a["deriv"], base["deriv"])  # (another order of the row sums)
+    assert rel_err(a["deriv"], base["deriv"], floor=1.0) <= 2e-6
+    ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, 0.1, 1.0)
+    assert abs(a["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+    assert rel_err(a["deriv"], ref["deriv"] - 5e-5 * y, floor=1.0) <= REL  # (deriv = deriv_weight * gamma - l2_scale * y)
+    # accumulate form
+    acc = hip_den(fst, y, S, leaky=0.1, graph=graph, accumulate=True, init=0.25)
+    plain = hip_den(fst, y, S, leaky=0.1, graph=graph)
+    assert rel_err(acc["deriv"] - 0.25, plain["deriv"], floor=1.0) <= 1e-6

@@ -82,6 +82,10 @@ def _load():
     L.tc_example_output.argtypes = [vp, C.c_int32] + [vp] * 11
     L.tc_den_graph_tuning.restype = C.c_int
     L.tc_den_graph_tuning.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.tc_den_graph_set_variant.restype = C.c_int
+    L.tc_den_graph_set_variant.argtypes = [vp, C.c_int, C.c_int32]
+    L.tc_den_graph_hash.restype = C.c_uint64
+    L.tc_den_graph_hash.argtypes = [vp]
     L.tc_debug_set.restype = C.c_int
     L.tc_debug_set.argtypes = [C.c_char_p, C.c_int]
     L.tc_debug_counter.restype = C.c_int64

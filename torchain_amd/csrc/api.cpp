@@ -223,6 +223,12 @@ int tune_den_variant(tc_den_graph *g, int device) {
   }
   int choice = 0;
   float ms[2] = {0.f, 0.f};
+  int preset = -1;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    auto it = g->preset_variant.find(device);
+    if (it != g->preset_variant.end()) preset = it->second;
+  }
   auto finish = [&]() {
     std::lock_guard<std::mutex> lock(g->mu);
     DenGraphDev &slot = g->dev[device];
@@ -233,6 +239,10 @@ int tune_den_variant(tc_den_graph *g, int device) {
   };
   if (!pair_room(g) || !d.fwd.cells_pair || debug_flag(kDbgNoPair) || debug_flag(kDbgNoTune) || debug_flag(kDbgForcePair))
     return finish();
+  if (preset >= 0) {  // the caller's choice (a cache of an earlier run, or rank 0's): no timing launches
+    choice = preset;
+    return finish();
+  }
   DeviceGuard guard(device);
   if (!guard.ok) return finish();
   int num_cus = 0;
@@ -297,6 +307,41 @@ int tc_den_graph_tuning(tc_den_graph *g, int device, int32_t *two_sequence_kerne
   if (fused_ms) *fused_ms = d.tune_ms[0];
   if (two_sequence_ms) *two_sequence_ms = d.tune_ms[1];
   return TC_OK;
+}
+
+int tc_den_graph_set_variant(tc_den_graph *g, int device, int32_t two_sequence_kernel) {
+  if (!g || two_sequence_kernel < -1 || two_sequence_kernel > 1) return TC_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (two_sequence_kernel < 0)
+    g->preset_variant.erase(device);
+  else
+    g->preset_variant[device] = two_sequence_kernel;
+  auto it = g->dev.find(device);
+  if (it != g->dev.end() && it->second.pair_choice != -2) {
+    // already on the device: the choice applies from the next launch on (-1: timed again at the next prepare); a graph
+    // the two-sequence kernel does not fit keeps the fused one whatever is asked
+    const bool fits = pair_room(g) && it->second.fwd.cells_pair;
+    it->second.pair_choice = two_sequence_kernel < 0 ? -1 : (fits ? two_sequence_kernel : 0);
+  }
+  return TC_OK;
+}
+
+uint64_t tc_den_graph_hash(const tc_den_graph *g) {
+  if (!g) return 0;
+  // FNV-1a over what the schedules are built from: sizes, arcs (source, destination, pdf, probability bits)
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  };
+  mix(&g->H, sizeof(g->H));
+  mix(&g->P, sizeof(g->P));
+  mix(&g->A, sizeof(g->A));
+  mix(g->arc_src.data(), g->arc_src.size() * 4);
+  mix(g->arc_dst.data(), g->arc_dst.size() * 4);
+  mix(g->arc_pdf.data(), g->arc_pdf.size() * 4);
+  mix(g->arc_prob.data(), g->arc_prob.size() * 4);
+  return h ? h : 1;
 }
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {

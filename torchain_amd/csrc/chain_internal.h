@@ -224,6 +224,7 @@ struct tc_den_graph {
   float big_sum_pi = 0.f;
   std::mutex mu;
   std::map<int, tc::DenGraphDev> dev;
+  std::map<int, int> preset_variant;  // device -> kernel choice fixed by the caller (tc_den_graph_set_variant)
 };
 
 // ---- numerator -----------------------------------------------------------------------------------

@@ -56,6 +56,8 @@ extern "C" int tc_supervision_append(int32_t num_pieces, const int32_t *piece_nu
         if (d < 0 || d >= n) return TC_ERR_BAD_FST;
         if (d == 0 && k > 0) return TC_ERR_BAD_FST;  // the start state of a later piece has incoming arcs
         if (tm[d] < 0) {
+          // (a dead-end chain longer than the piece -- no final state on it -- would index past the per-time counts below)
+          if (tm[s] + 1 > piece_num_frames[k]) return TC_ERR_BAD_FST;
           tm[d] = tm[s] + 1;
           queue.push_back(d);
         } else if (tm[d] != tm[s] + 1) {

@@ -37,7 +37,9 @@ class ChainResults:
         # the reference, functions.py:88-89).  The data-parallel wrapper reduces THESE (one collective, no host
         # round trip); ``xent_objf`` is read from the device only when somebody asks for it.
         self._dev = None
+        self._ready = None       # event recorded on the stream that produced _dev: the lazy reads wait for it
         self._xent_dev = None
+        self._xent_ready = None
         self._xent_scale = 1.0
         self._xent_host = None
         self._defer_host_copy = False  # set by chain_loss_data_parallel: the one D2H follows the all-reduce
@@ -45,6 +47,9 @@ class ChainResults:
     @property
     def data(self):
         if self._stale and not self._defer_host_copy and self._dev is not None:
+            # the copy runs on whatever stream is current NOW, which need not be the one chain_loss ran on
+            if self._ready is not None:
+                torch.cuda.current_stream(self._dev.device).wait_event(self._ready)
             self._host.copy_(self._dev)
             self._stale = False
         return self._host
@@ -53,12 +58,16 @@ class ChainResults:
     def data(self, value):
         self._host = value
         self._stale = False
+        self._dev = None  # (callers that sum ChainResults.data over steps own the numbers from here on)
+        self._ready = None
 
     @property
     def xent_objf(self):
         """Kaldi's cross-entropy objective, or None without a xent branch.  Lazy: the value stays on the device
         until it is read (one 8-byte D2H), so a training step has no second host sync."""
         if self._xent_host is None and self._xent_dev is not None:
+            if self._xent_ready is not None:
+                torch.cuda.current_stream(self._xent_dev.device).wait_event(self._xent_ready)
             self._xent_host = float(self._xent_dev.item()) * self._xent_scale
         return self._xent_host
 
@@ -114,6 +123,8 @@ def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, n
     assert nnet_output.is_cuda, "Only the HIP (ROCm) implementation is available"
     if nnet_output.dim() != 2 or nnet_output.stride(1) != 1 or nnet_output.dtype != torch.float32:
         raise ValueError("nnet_output must be a 2-D float32 tensor with unit column stride")
+    if isinstance(den_graph, io.DenominatorGraph):
+        den_graph.prepare(nnet_output.device)  # (a dictionary look-up after the first call on a device)
     den_ptr = den_graph.ptr if isinstance(den_graph, io.DenominatorGraph) else den_graph
     sup_ptr = supervision.ptr if isinstance(supervision, io.Supervision) else supervision
     rows, cols = nnet_output.shape
@@ -141,6 +152,8 @@ def compute_chain_objf_and_deriv(den_graph, supervision, nnet_output, results, n
         if holder is not None:
             holder._dev = res_dev  # (ChainResults.data copies it to the host when it is read)
             holder._stale = True
+            holder._ready = torch.cuda.Event()
+            holder._ready.record(torch.cuda.current_stream(device))
         else:
             results.copy_(res_dev)  # 12-byte D2H, the one host sync of the call (reference: >= 4)
     return results
@@ -193,6 +206,8 @@ class _ChainLoss(Function):
         if use_xent:
             # sum(xent_output * xent_deriv) from the scaled matrix: the scale is one factor of every term
             results._xent_dev = xent_objective(xent_input.detach(), xent_grad)
+            results._xent_ready = torch.cuda.Event()
+            results._xent_ready.record(torch.cuda.current_stream(xent_input.device))
             results._xent_scale = 1.0 / -float(xent_regularize)
             results._xent_host = None
             if not kaldi_way:  # the reference's second call (functions.py:96-103)

@@ -18,6 +18,39 @@ from . import egs as _egs
 from ._lib import check, lib
 
 
+def _tuning_cache_path():
+    return os.environ.get("TORCHAIN_TUNING_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "torchain_amd", "tuning.json")
+
+
+def _tuning_cache_get(key):
+    """The measured kernel choice of a graph on a kind of device from an earlier run, or None (any failure: None)."""
+    import json
+    try:
+        with open(_tuning_cache_path()) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def _tuning_cache_put(key, entry):
+    import json
+    path = _tuning_cache_path()
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except (OSError, ValueError):
+            table = {}
+        table[key] = entry
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "w") as f:
+            json.dump(table, f, indent=1, sort_keys=True)
+        os.replace(tmp, path)
+    except OSError:
+        pass  # (a read-only home: the choice is timed again next run)
+
+
 def set_kaldi_device(device_id=0):
     """Reference ``io.py:15-17`` re-points Kaldi's process-wide CuDevice singleton at a torch
     device.  The HIP path is stateless (device and stream are explicit arguments of every call), so
@@ -78,10 +111,33 @@ class DenominatorGraph:
         check(lib.tc_den_graph_initial_probs(self.ptr, _p(out)), "tc_den_graph_initial_probs")
         return out
 
-    def prepare(self, device=None):
-        """Uploads the immutable tables to ``device`` now instead of on the first loss call."""
+    def prepare(self, device=None, variant=None):
+        """Uploads the immutable tables to ``device`` now instead of on the first loss call, and settles which of the
+        graph's two kernels batches above one sequence per two CUs run there (``tc_den_graph_tuning``): ``variant``
+        (0 fused / 1 two-sequence) if given -- ``parallel.sync_den_graph_variant`` passes rank 0's --, else the choice
+        an earlier run measured for this graph on this kind of device (a JSON cache: ``$TORCHAIN_TUNING_CACHE`` or
+        ``~/.cache/torchain_amd/tuning.json``, keyed by ``tc_den_graph_hash`` and the device name), else the library
+        times the two kernels once and the result goes into that cache.  So the choice -- and with it the last bits of
+        the results -- is the same from run to run and from rank to rank."""
         dev = torch.cuda.current_device() if device is None else torch.device(device).index
-        check(lib.tc_den_graph_prepare(self.ptr, int(dev)), "tc_den_graph_prepare")
+        dev = int(dev or 0)
+        done = self.__dict__.setdefault("_prepared", {})
+        if dev in done and variant is None:
+            return self
+        key = "%016x:%s" % (int(lib.tc_den_graph_hash(self.ptr)), torch.cuda.get_device_name(dev))
+        choice = variant
+        if choice is None and dev not in done:
+            entry = _tuning_cache_get(key)
+            if entry is not None:
+                choice = int(entry.get("two_sequence_kernel", 0))
+        if choice is not None:
+            check(lib.tc_den_graph_set_variant(self.ptr, dev, int(choice)), "tc_den_graph_set_variant")
+        check(lib.tc_den_graph_prepare(self.ptr, dev), "tc_den_graph_prepare")
+        if choice is None:
+            t = self.tuning(dev)
+            if t["fused_ms"] > 0.0 and t["two_sequence_ms"] > 0.0:  # (really timed: not switched off, not unfit)
+                _tuning_cache_put(key, t)
+        done[dev] = True
         return self
 
     def stats(self):
@@ -96,7 +152,7 @@ class DenominatorGraph:
         """Which kernel batches above one sequence per two CUs run on ``device`` (``tc_den_graph_tuning``) and the
         two times the choice was made on."""
         import ctypes as C
-        dev = device.index if hasattr(device, "index") else int(device)
+        dev = device if isinstance(device, int) else torch.device(device).index
         choice, a, b = C.c_int32(0), C.c_float(0), C.c_float(0)
         check(lib.tc_den_graph_tuning(self.ptr, int(dev or 0), C.byref(choice), C.byref(a), C.byref(b)),
               "tc_den_graph_tuning")

@@ -111,6 +111,33 @@ def all_reduce_results(results, group=None, device=None, even_if_alone=False):
     return results
 
 
+def sync_den_graph_variant(den_graph, device, group=None):
+    """Every rank of the group runs the denominator kernel rank 0 chose for ``den_graph`` (``io.DenominatorGraph.prepare``:
+    from the cache of an earlier run, or timed once on rank 0's GPU).  The graph's two kernels differ in the last bits,
+    so a choice made per rank -- by a timing race on each rank's GPU -- would make ranks disagree on them; the reference's
+    call is deterministic for fixed inputs (``src/my_lib_chain.cpp:129-131``).  One broadcast of one integer, once per
+    graph and device; ``chain_loss_data_parallel`` calls it on a graph's first use."""
+    import torch.distributed as dist
+
+    dev = torch.device(device)
+    done = den_graph.__dict__.setdefault("_synced", set())
+    if dev.index in done:
+        return
+    alone = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    if alone or dist.get_rank(group) == 0:
+        den_graph.prepare(dev)
+    if not alone:
+        on_gpu = dist.get_backend(group) == "nccl"
+        choice = torch.zeros(1, dtype=torch.int32, device=dev if on_gpu else "cpu")
+        if dist.get_rank(group) == 0:
+            choice[0] = den_graph.tuning(dev)["two_sequence_kernel"]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(choice, src=src, group=group)
+        if dist.get_rank(group) != 0:
+            den_graph.prepare(dev, variant=int(choice.item()))
+    done.add(dev.index)
+
+
 def _finish_host_copy(results):
     if results._defer_host_copy and results._dev is not None:
         results._host.copy_(results._dev)
@@ -126,6 +153,8 @@ def chain_loss_data_parallel(input, den_graph, supervision, l2_regularize=0.0, l
     gradient (``-deriv``, exactly as the single-GPU wrapper; DDP then averages parameter grads).  The rank's own
     results never visit the host: the kernels' device-side floats go into the collective and one copy brings the
     reduced values back."""
+    if input.is_cuda and hasattr(den_graph, "prepare"):
+        sync_den_graph_variant(den_graph, input.device, group)
     results = ChainResults()
     results._defer_host_copy = bool(input.is_cuda)
     loss, results = _chain_loss_into(results, input, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
