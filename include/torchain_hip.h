@@ -144,6 +144,39 @@ int tc_example_output(const tc_example *example, int32_t j, const char **name, i
                       const int32_t **arc_begin, const int32_t **ilabel, const float **arc_weight,
                       const int32_t **nextstate, const float **final_weight);
 
+/* Random-access minibatch reader: my_lib_example_rand_reader_new / _reset / _num_batch / _num_data / _next / _free,
+ * my_lib_example_rand_feats and my_lib_supervision_rand_new of the reference (src/my_lib.h:8-17 over RandReader,
+ * src/my_lib_example_rand.cpp:35-177).  `scp_path` holds "key path:offset" lines; `len_file` ("" or NULL: scp_path +
+ * ".len"; absent: the lengths are read from the examples) holds "key frames_per_sequence" pairs.  Examples of equal
+ * length are grouped into minibatches of `batchsize` (the last of a length may be smaller), shuffled inside and across
+ * the lengths by a std::mt19937 seeded with `seed` (Fisher-Yates with the draw (engine() * n) >> 32; std::shuffle's
+ * own order is unspecified, so no statement of it reproduces the reference's).  New here:
+ *   rank / world : every rank forms the same shuffled list and takes batches rank, rank + world, ...; all ranks get
+ *                  floor(batches / world) of them per epoch (reference antecedent: example/chime5/parallel_train.py:26-75)
+ *   lookahead    : that many worker threads read, parse, merge ([K] MergeChainExamples) and build the supervision
+ *                  handles of the next batches while the caller uses the current one (0: everything inside _next)
+ * tc_rand_reader_next: 1 = moved to the next minibatch, 0 = the epoch is over, negative TC_ERR_* (text in
+ * tc_rand_reader_last_error).  The reader starts BEFORE its first minibatch.  tc_rand_reader_example: the current merged
+ * minibatch (tc_example_input / _output; owned by the reader, valid until the next _next / _reset / _free);
+ * tc_rand_reader_supervision_new: a supervision handle of it that the caller frees (tc_supervision_free);
+ * tc_rand_reader_take_example: the current minibatch itself, the caller's to free (tc_example_free) -- for callers
+ * that keep its arrays beyond the next _next.
+ * tc_rand_reader_batch_keys: the keys of this rank's batch `batch` of the current epoch, space-separated, into buf;
+ * returns their number.  Host only. */
+typedef struct tc_rand_reader tc_rand_reader;
+int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char *len_file, int rank, int world,
+                       int lookahead, tc_rand_reader **out);
+int tc_rand_reader_reset(tc_rand_reader *reader);
+int tc_rand_reader_num_batch(const tc_rand_reader *reader);
+int tc_rand_reader_num_data(const tc_rand_reader *reader);
+int tc_rand_reader_next(tc_rand_reader *reader);
+int tc_rand_reader_example(const tc_rand_reader *reader, const tc_example **out);
+int tc_rand_reader_supervision_new(tc_rand_reader *reader, tc_supervision **out);
+int tc_rand_reader_take_example(tc_rand_reader *reader, tc_example **out);
+int tc_rand_reader_batch_keys(const tc_rand_reader *reader, int32_t batch, char *buf, int32_t cap);
+void tc_rand_reader_free(tc_rand_reader *reader);
+const char *tc_rand_reader_last_error(void);
+
 /* Replaces my_lib_supervision_free (src/my_lib.h:22). */
 void tc_supervision_free(tc_supervision *supervision);
 /* Replace my_lib_supervision_num_pdf / _num_sequence / _num_frame (src/my_lib.h:23-25). */
@@ -203,6 +236,27 @@ int tc_chain_objf_and_grad(tc_den_graph *graph, tc_supervision *supervision, con
                            int64_t xent_stride, float l2_regularize, float leaky_hmm_coefficient,
                            float xent_regularize, void *workspace, int64_t workspace_bytes, int device,
                            void *stream);
+
+/* ONE call per training step: everything torchain/functions.py:62-115 does around my_lib_ComputeChainObjfAndDeriv --
+ * the (B, C, T) -> (T*B, C) copy of `to2d` (functions.py:118-125), the objective, the reference's second call on
+ * xent_input when kaldi_way == 0 (functions.py:96-103), the cross-entropy objective, the loss value -objf / weight
+ * (functions.py:104) and the matrices in the form and layout backward() returns them (functions.py:106-115).
+ *   three_d != 0 : input / xent_input / grad / xent_grad are contiguous (B, C, T) tensors, B = num_sequences of the
+ *                  supervision, C = its label_dim, T = its frames_per_sequence;  else 2-D (T*B, C), input and xent_input
+ *                  with `row_stride`, grad and xent_grad contiguous.
+ *   grad          = -(derivative of the objective w.r.t. input);  xent_grad = -xent_regularize * xent_deriv
+ *                   (xent branch: xent_input != NULL and xent_regularize != 0, as in the reference)
+ *   results_dev3  : device float[3] {objf, l2_term, weight};  loss_dev1 (nullable): device float[1] = -objf / weight
+ *   xent_objf_dev : nullable device double[1] = scale * sum(xent_input * xent_deriv), scale = -xent_regularize for 2-D
+ *                   tensors and 1 for (B, C, T) tensors (the matrices it is formed from; the caller divides)
+ * Workspace: tc_chain_step_workspace_bytes(graph, B, T, three_d, xent branch).  No host synchronisation. */
+int64_t tc_chain_step_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence,
+                                      int three_d, int with_xent);
+int tc_chain_step(tc_den_graph *graph, tc_supervision *supervision, const float *input, const float *xent_input,
+                  int three_d, int64_t row_stride, float l2_regularize, float leaky_hmm_coefficient,
+                  float xent_regularize, int kaldi_way, float *grad, float *xent_grad, float *results_dev3,
+                  float *loss_dev1, double *xent_objf_dev, void *workspace, int64_t workspace_bytes, int device,
+                  void *stream);
 
 /* The benchmarked unit: [K] DenominatorComputation::Forward() + Backward(deriv_weight, deriv)
  * (direct use in the reference: src/chain-supervision-test.hpp:403-414).

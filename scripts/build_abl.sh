@@ -18,4 +18,4 @@ for f in $all; do
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_abl/lib_$name.so den_graph.o den_layout.o schedule_general.o schedule_owner.o supervision.o supervision_merge.o egs_reader.o self_test.o api.o $objs den_big_kernel.o num_kernels.o layout_kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_abl/lib_$name.so den_graph.o den_layout.o schedule_general.o schedule_owner.o supervision.o supervision_merge.o egs_reader.o rand_reader.o self_test.o api.o $objs den_big_kernel.o num_kernels.o layout_kernels.o

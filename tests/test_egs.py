@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from torchain_amd import egs, io, synth
 
@@ -162,17 +163,19 @@ def test_sequential_reader_delivers_every_example(tmp_path):
         assert sum(1 for _ in rd) == 4
 
 
-def test_rand_reader_batches_by_length(tmp_path):
+@pytest.mark.parametrize("native", [True, False])
+def test_rand_reader_batches_by_length(tmp_path, native):
+    """(native: the library's tc_rand_reader_* handle, the default; else the Python statement of the same reader)"""
     fst = synth.random_den_fst(40, 4, 24, seed=1)
     lengths = [5] * 7 + [8] * 4 + [11]
     keyed, ark, scp = _write_set(tmp_path, fst, lengths)
     io.print_key_length("scp:" + scp, scp + ".len")
     assert len(open(scp + ".len").read().split()) == 2 * len(lengths)
     for len_file in ("", str(tmp_path / "absent.len")):  # from the .len file / from the egs themselves
-        rd = io.RandExample(scp, seed=3, batchsize=3, len_file=len_file) if len_file == "" else None
+        rd = io.RandExample(scp, seed=3, batchsize=3, len_file=len_file, native=native) if len_file == "" else None
         if rd is None:
             os.rename(scp + ".len", scp + ".len.away")
-            rd = io.RandExample(scp, seed=3, batchsize=3)
+            rd = io.RandExample(scp, seed=3, batchsize=3, native=native)
             os.rename(scp + ".len.away", scp + ".len")
         assert rd.n_data == 12 and rd.n_batch == 3 + 2 + 1  # ceil(7/3) + ceil(4/3) + 1
         total = 0
@@ -183,10 +186,12 @@ def test_rand_reader_batches_by_length(tmp_path):
             assert rd.indexes.shape == (B, L) and rd.deriv_weights.shape == (B * L,)
             total += B
         assert total == 12
-    first = [tuple(b) for b in rd._key_batch]
+    order = (lambda: [tuple(rd.batch_keys(i)) for i in range(rd.n_batch)]) if native else (lambda: [tuple(b) for b in rd._key_batch])
+    first = order()
+    assert sorted(k for b in first for k in b) == sorted(k for k, _ in keyed)
     rd.reset()
     assert sum(1 for _ in rd) == 6
-    assert [tuple(b) for b in rd._key_batch] != first  # reshuffled
+    assert order() != first  # reshuffled
 
 
 def test_rand_reader_prefetches_batches_ahead(tmp_path):
@@ -196,7 +201,7 @@ def test_rand_reader_prefetches_batches_ahead(tmp_path):
     lengths = [5] * 7 + [8] * 4 + [11]
     keyed, ark, scp = _write_set(tmp_path, fst, lengths)
     io.print_key_length("scp:" + scp, scp + ".len")
-    a, b = io.RandExample(scp, seed=3, batchsize=3), io.RandExample(scp, seed=3, batchsize=3, prefetch=False)
+    a, b = io.RandExample(scp, seed=3, batchsize=3, native=False), io.RandExample(scp, seed=3, batchsize=3, prefetch=False, native=False)
     for epoch in range(2):
         n = 0
         while a.next():
@@ -210,6 +215,51 @@ def test_rand_reader_prefetches_batches_ahead(tmp_path):
         assert not b.next() and n == a.n_batch
         a.reset()
         b.reset()
+
+
+def test_native_rand_reader_handle_shards_by_rank_and_looks_ahead(tmp_path):
+    """``tc_rand_reader_*`` (the reference's ``my_lib_example_rand_reader_*``, src/my_lib.h:8-17): with look-ahead threads
+    it delivers what it delivers without them, in the same order, also across reset(); the minibatches are those
+    ``tc_example_read`` merges from the same keys; ``world`` ranks together see every batch of the epoch's list once
+    (up to the ``batches % world`` left out so that all ranks take the same number of steps), and one seed gives one
+    list."""
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    lengths = [5] * 9 + [8] * 6 + [11] * 2
+    keyed, ark, scp = _write_set(tmp_path, fst, lengths)
+    io.print_key_length("scp:" + scp, scp + ".len")
+    where = {key: (p, off) for key, p, off in egs.read_scp(scp)}
+    a, b = io.RandExample(scp, seed=5, batchsize=2, prefetch=4), io.RandExample(scp, seed=5, batchsize=2, prefetch=False)
+    for epoch in range(2):
+        assert a.n_batch == b.n_batch == 5 + 3 + 1 and a.n_data == 17
+        keys = [a.batch_keys(i) for i in range(a.n_batch)]
+        assert keys == [b.batch_keys(i) for i in range(b.n_batch)]
+        n = 0
+        while a.next():
+            assert b.next()
+            (ia, xa), sa = a.value()
+            (ib, xb), sb = b.value()
+            assert sa.shape == sb.shape and torch.equal(ia, ib) and torch.equal(xa, xb)
+            ref = egs.read_merged_native([where[k] for k in keys[n]])
+            assert same_fst(a._cur["outputs"][0]["supervision"], ref["outputs"][0]["supervision"])
+            np.testing.assert_array_equal(a._cur["inputs"][0]["features"], ref["inputs"][0]["features"])
+            n += 1
+        assert n == a.n_batch and not b.next() and not a.next()
+        with pytest.raises(ValueError):
+            a.supervision  # past the end: "null supervision ptr", as in the reference
+        a.reset()
+        b.reset()
+    # two ranks: the same list, every other batch each
+    whole = io.RandExample(scp, seed=9, batchsize=2, prefetch=False)
+    parts = [io.RandExample(scp, seed=9, batchsize=2, prefetch=2, rank=r, world=2) for r in range(2)]
+    full = [whole.batch_keys(i) for i in range(whole.n_batch)]
+    assert all(p.n_batch == len(full) // 2 for p in parts)
+    for r, p in enumerate(parts):
+        assert [p.batch_keys(i) for i in range(p.n_batch)] == full[r:2 * (len(full) // 2):2]
+        assert sum(1 for _ in p) == p.n_batch
+    with pytest.raises(ValueError):
+        io.RandExample(scp, seed=9, batchsize=2, native=False, rank=1, world=2)
+    with pytest.raises(egs.EgsFormatError):
+        io.RandExample(scp, seed=9, batchsize=2, rank=2, world=2)
 
 
 def test_native_merge_equals_the_numpy_statement_and_meets_its_time_bound():

@@ -172,3 +172,49 @@ def test_register_row_kernel_matches_the_default_kernel(oracle, kernel_family):
     acc = hip_den(fst, y, S, leaky=0.1, graph=graph, accumulate=True, init=0.25)
     plain = hip_den(fst, y, S, leaky=0.1, graph=graph)
     assert rel_err(acc["deriv"] - 0.25, plain["deriv"], floor=1.0) <= 1e-6
+
+
+@pytest.mark.parametrize("three_d", [True, False])
+@pytest.mark.parametrize("kaldi_way", [True, False])
+def test_one_call_step_equals_the_multi_call_wrappers(three_d, kaldi_way):
+    """``tc_chain_step`` (what ``chain_loss`` calls for CUDA float32 tensors) against ``_ChainLoss`` / ``_ChainLoss3d``
+    (four to six library calls): loss, results, xent objective and both gradients, bit for bit."""
+    from torchain_amd.functions import ChainResults, _ChainLoss, _ChainLoss3d, chain_loss
+    fst = synth.random_den_fst(300, 4, 96, seed=4)
+    S, T, P = 5, 11, 96
+    den = io.DenominatorGraph(fst, P)
+    sup = synth.random_supervision(fst, S, T, 3, seed=2, initial_probs=den.initial_probs())
+    hsup = io.Supervision.from_synth(sup)
+    y = torch.from_numpy(synth.random_nnet_output(S, T, P, seed=6)).cuda()
+    xe = torch.from_numpy(synth.random_nnet_output(S, T, P, seed=7)).cuda()
+    if three_d:
+        y = y.reshape(T, S, P).permute(1, 2, 0).contiguous()
+        xe = xe.reshape(T, S, P).permute(1, 2, 0).contiguous()
+    outs = []
+    for one_call in (True, False):
+        a, b = y.clone().requires_grad_(True), xe.clone().requires_grad_(True)
+        if one_call:
+            loss, res = chain_loss(a, den, hsup, 1e-4, 0.05, 0.1, b, kaldi_way)
+        else:
+            res = ChainResults()
+            loss = (_ChainLoss3d if three_d else _ChainLoss).apply(a, b, res, den, hsup, 1e-4, 0.05, 0.1, kaldi_way)
+        loss.backward()
+        outs.append((loss.detach().cpu(), res.data.clone(), res.xent_objf, a.grad.cpu(), b.grad.cpu()))
+    (l1, r1, x1, g1, xg1), (l2, r2, x2, g2, xg2) = outs
+    assert torch.equal(r1, r2) and torch.equal(g1, g2) and torch.equal(xg1, xg2)
+    assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l2)) and abs(x1 - x2) <= 1e-6 * abs(x2)
+    # without a xent branch, and a 2-D input whose rows are not contiguous
+    a = y.clone().requires_grad_(True)
+    loss, res = chain_loss(a, den, hsup, 1e-4, 0.05)
+    loss.backward()
+    res0 = ChainResults()
+    b = y.clone().requires_grad_(True)
+    (_ChainLoss3d if three_d else _ChainLoss).apply(b, None, res0, den, hsup, 1e-4, 0.05).backward()
+    assert torch.equal(res.data, res0.data) and torch.equal(a.grad, b.grad) and res.xent_objf is None
+    if not three_d:
+        wide = torch.zeros(S * T, P + 8, device="cuda")
+        wide[:, :P] = y
+        c = wide[:, :P].detach().requires_grad_(True)
+        loss, res2 = chain_loss(c, den, hsup, 1e-4, 0.05)
+        loss.backward()
+        assert torch.equal(res2.data, res.data) and torch.equal(c.grad, a.grad)

@@ -98,6 +98,25 @@ def _load():
     L.tc_from2d.argtypes = [vp, i64, i32, i32, i32, f32, vp, C.c_int, vp]
     L.tc_supervision_create.restype = C.c_int
     L.tc_supervision_create.argtypes = [C.POINTER(vp), f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.tc_rand_reader_new.restype = C.c_int
+    L.tc_rand_reader_new.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]
+    for name in ("tc_rand_reader_reset", "tc_rand_reader_num_batch", "tc_rand_reader_num_data", "tc_rand_reader_next"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [vp]
+    for name in ("tc_rand_reader_example", "tc_rand_reader_supervision_new", "tc_rand_reader_take_example"):
+        getattr(L, name).restype = C.c_int
+        getattr(L, name).argtypes = [vp, vp]
+    L.tc_rand_reader_batch_keys.restype = C.c_int
+    L.tc_rand_reader_batch_keys.argtypes = [vp, C.c_int32, C.c_char_p, C.c_int32]
+    L.tc_rand_reader_free.restype = None
+    L.tc_rand_reader_free.argtypes = [vp]
+    L.tc_rand_reader_last_error.restype = C.c_char_p
+    L.tc_rand_reader_last_error.argtypes = []
+    L.tc_chain_step_workspace_bytes.restype = C.c_int64
+    L.tc_chain_step_workspace_bytes.argtypes = [vp, C.c_int32, C.c_int32, C.c_int, C.c_int]
+    L.tc_chain_step.restype = C.c_int
+    L.tc_chain_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp,
+                                vp, vp, C.c_int64, C.c_int, vp]
     L.tc_supervision_free.restype = None
     L.tc_supervision_free.argtypes = [vp]
     for name in ("tc_supervision_num_pdf", "tc_supervision_num_sequence", "tc_supervision_num_frame"):

@@ -489,6 +489,102 @@ int tc_chain_objf_and_grad(tc_den_graph *g, tc_supervision *sup, const float *y,
                     l2_regularize, leaky, -1.0f, -xent_regularize, workspace, workspace_bytes, device, stream_v);
 }
 
+// ---- one call per training step --------------------------------------------------------------------------------
+// Workspace of tc_chain_step: [tc_chain_workspace_bytes | scratch of the xent objective | for (B, C, T) tensors the
+// frame-major copies of input and gradient (and of xent_input and its gradient)].
+namespace {
+struct StepWorkspace {
+  char *chain, *trace;
+  float *y2d, *g2d, *x2d, *xg2d;
+  size_t chain_bytes, total;
+};
+StepWorkspace carve_step(char *base, const tc_den_graph *g, int S, int T, int P, bool three_d, bool xent) {
+  StepWorkspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char *p = base ? base + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  w.chain_bytes = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), split_room(g, S), pair_room(g)).total;
+  w.chain = take(w.chain_bytes);
+  w.trace = take((size_t)trace_workspace_bytes());
+  const size_t mat = (size_t)S * T * P * sizeof(float);
+  w.y2d = three_d ? (float *)take(mat) : nullptr;
+  w.g2d = three_d ? (float *)take(mat) : nullptr;
+  w.x2d = three_d && xent ? (float *)take(mat) : nullptr;
+  w.xg2d = three_d && xent ? (float *)take(mat) : nullptr;
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+int64_t tc_chain_step_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T, int three_d, int with_xent) {
+  if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
+  return (int64_t)carve_step(nullptr, g, S, T, g->P, three_d != 0, with_xent != 0).total;
+}
+
+int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, const float *xent_input, int three_d,
+                  int64_t row_stride, float l2_regularize, float leaky, float xent_regularize, int kaldi_way,
+                  float *grad, float *xent_grad, float *results_dev3, float *loss_dev1, double *xent_objf_dev,
+                  void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
+  if (!g || !sup || !input || !grad || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
+  const bool use_xent = xent_input != nullptr && xent_regularize != 0.0f;
+  if (use_xent && !xent_grad) return TC_ERR_INVALID_ARGUMENT;
+  const int S = sup->S, T = sup->T, P = sup->P;
+  if (P != g->P) return TC_ERR_INVALID_ARGUMENT;
+  const int64_t rows = (int64_t)S * T;
+  if (!three_d && row_stride < P) return TC_ERR_INVALID_ARGUMENT;
+  const StepWorkspace w = carve_step((char *)workspace, g, S, T, P, three_d != 0, use_xent);
+  if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_v;
+  // frame-major views of the tensors: the caller's own for 2-D input, copies for (B, C, T) (torchain/functions.py:118-125)
+  const float *y = input, *xe = xent_input;
+  float *gr = grad, *xg = use_xent ? xent_grad : nullptr;
+  int64_t stride = row_stride, gstride = P;  // (2-D gradients are written as contiguous matrices)
+  int rc = TC_OK;
+  if (three_d) {
+    rc = tc_to2d(input, S, P, T, w.y2d, P, device, stream_v);
+    if (rc == TC_OK && use_xent) rc = tc_to2d(xent_input, S, P, T, w.x2d, P, device, stream_v);
+    if (rc != TC_OK) return rc;
+    y = w.y2d;
+    xe = w.x2d;
+    gr = w.g2d;
+    xg = use_xent ? w.xg2d : nullptr;
+    stride = P;
+  }
+  // 2-D: the matrices leave as the reference's backward returns them (-deriv, -xent_regularize * xent_deriv); 3-D: the
+  // sign and the scale ride on the way back through tc_from2d, so the 2-D scratch holds the plain derivatives
+  const float dscale = three_d ? 1.0f : -1.0f, xscale = three_d ? 1.0f : -xent_regularize;
+  rc = chain_objf(g, sup, y, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
+                  w.chain, (int64_t)w.chain_bytes, device, stream_v);
+  if (rc != TC_OK) return rc;
+  if (use_xent) {
+    // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the reference,
+    // torchain/functions.py:88-89) from the matrices at hand: xent_objf_dev receives it times `xscale`
+    if (xent_objf_dev) {
+      rc = tc_xent_objf(xe, rows, P, stride, xg, gstride, xent_objf_dev, w.trace, trace_workspace_bytes(), device, stream_v);
+      if (rc != TC_OK) return rc;
+    }
+    if (!kaldi_way) {  // the reference's second call, on xent_input, overwriting results and the MMI gradient (functions.py:96-103)
+      rc = chain_objf(g, sup, xe, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
+                      w.chain, (int64_t)w.chain_bytes, device, stream_v);
+      if (rc != TC_OK) return rc;
+    }
+  }
+  if (three_d) {
+    rc = tc_from2d(gr, P, S, P, T, -1.0f, grad, device, stream_v);
+    if (rc == TC_OK && use_xent) rc = tc_from2d(xg, P, S, P, T, -xent_regularize, xent_grad, device, stream_v);
+    if (rc != TC_OK) return rc;
+  }
+  if (loss_dev1) {
+    DeviceGuard guard(device);
+    if (!guard.ok) return TC_ERR_HIP;
+    rc = launch_step_loss(results_dev3, loss_dev1, stream);
+  }
+  return rc;
+}
+
 int tc_xent_objf(const float *xent_output, int64_t rows, int32_t cols, int64_t output_stride, const float *xent_deriv,
                  int64_t deriv_stride, double *objf_dev, void *workspace, int64_t workspace_bytes, int device,
                  void *stream_v) {

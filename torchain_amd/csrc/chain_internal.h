@@ -355,6 +355,7 @@ int launch_zero_on_fail(const int32_t *fail_flag, float *a, int64_t a_stride, fl
 int launch_den_reduce(const double *den_lp, const float *ab, const float *gs, int S, double *logprob_out,
                       int32_t *status_out, hipStream_t stream);
 int launch_sum_double(const double *in, int n, double scale, double *out, hipStream_t stream);
+int launch_step_loss(const float *results3, float *loss1, hipStream_t stream);
 int64_t trace_workspace_bytes();
 int launch_trace_mat_mat(const float *a, int64_t a_stride, const float *b, int64_t b_stride, int64_t rows, int cols,
                          double *partial, double *out, hipStream_t stream);

@@ -356,6 +356,15 @@ __global__ __launch_bounds__(256) void sum_double_kernel(const double *in, int n
   }
 }
 
+// tc_chain_step: loss = -objf / weight (the reference's input.new([results.loss]), torchain/functions.py:104) on the device
+__global__ void step_loss_kernel(const float *results3, float *loss1) { loss1[0] = -results3[0] / results3[2]; }
+
+int launch_step_loss(const float *results3, float *loss1, hipStream_t stream) {
+  hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1), 0, stream, results3, loss1);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
 int launch_sum_double(const double *in, int n, double scale, double *out, hipStream_t stream) {
   hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(256), 0, stream, in, n, scale, out);
   TC_HIP_CHECK(hipGetLastError());

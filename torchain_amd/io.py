@@ -329,11 +329,31 @@ class RandExample(Example):
     from the egs.  The shuffle uses NumPy's MT19937 seeded with ``seed``: the same generator as the reference's
     ``std::mt19937`` but not the same draw order as ``std::shuffle``, whose algorithm is not specified."""
 
-    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True):
+    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True, rank=0, world=1, native=True):
+        """``rank`` / ``world``: this process's share of a data-parallel job (every rank forms the same shuffled list of
+        minibatches from ``seed`` and takes every ``world``-th; all ranks get the same number).  ``native`` (default): the
+        whole reader -- bucketing, shuffle, look-ahead threads, merge, supervision handles -- is the library's
+        ``tc_rand_reader_*`` handle, as the reference's is ``my_lib_example_rand_reader_*`` (``src/my_lib.h:8-17``);
+        ``native=False`` keeps the Python statement of it below (NumPy's MT19937 shuffle, a thread pool), which needs
+        ``rank == 0, world == 1``."""
         assert os.path.exists(scp_path)
         self.scp_path = scp_path
         self.rspec = scp_path
         self.batchsize = int(batchsize)
+        self._native = None
+        if native:
+            handle = C.c_void_p()
+            depth = (8 if prefetch is True else int(prefetch)) if prefetch else 0
+            rc = lib.tc_rand_reader_new(os.fsencode(scp_path), int(seed), int(batchsize), os.fsencode(len_file or ""),
+                                        int(rank), int(world), depth, C.byref(handle))
+            if rc != 0:
+                raise _egs.EgsFormatError((lib.tc_rand_reader_last_error() or b"").decode() or "tc_rand_reader_new: %d" % rc)
+            self._native = handle
+            self._cur = None
+            self._have = False
+            return
+        if rank != 0 or world != 1:
+            raise ValueError("the Python reader does not shard: use native=True")
         # The next minibatches are prepared on background threads while the current one is in use (reading, parsing,
         # merging and building the supervision handle are library calls that release the interpreter lock): the
         # training thread finds its batch ready instead of re-opening and re-parsing every scp entry synchronously.
@@ -369,6 +389,10 @@ class RandExample(Example):
         self._rng.shuffle(self._key_batch)
 
     def reset(self):
+        if self._native is not None:
+            check(lib.tc_rand_reader_reset(self._native), "tc_rand_reader_reset")
+            self._cur, self._have = None, False
+            return
         self._drop_pending()
         self._pos = -1
         self._cur = None
@@ -395,20 +419,55 @@ class RandExample(Example):
             pass
         return merged
 
-    def __del__(self):
+    def __del__(self, _free=lib.tc_rand_reader_free):
         pool = getattr(self, "_pool", None)
         if pool is not None:
             pool.shutdown(wait=False)
+        handle = getattr(self, "_native", None)
+        if handle:
+            _free(handle)
+            self._native = None
 
     @property
     def n_batch(self):
+        if self._native is not None:
+            return lib.tc_rand_reader_num_batch(self._native)
         return len(self._key_batch)
 
     @property
     def n_data(self):
+        if self._native is not None:
+            return lib.tc_rand_reader_num_data(self._native)
         return self._n_data
 
+    def batch_keys(self, batch):
+        """The keys of this rank's minibatch ``batch`` of the current epoch (native reader)."""
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.tc_rand_reader_batch_keys(self._native, int(batch), buf, len(buf))
+        check(min(n, 0), "tc_rand_reader_batch_keys")
+        return buf.value.decode().split()
+
+    def _need(self):
+        if self._native is not None and self._cur is None and self._have:
+            # the minibatch the library holds, as the dict the numpy reader returns; the supervision handle the
+            # look-ahead thread built comes with it
+            sup = C.c_void_p()
+            check(lib.tc_rand_reader_supervision_new(self._native, C.byref(sup)), "tc_rand_reader_supervision_new")
+            handle = Supervision(sup)
+            eg = C.c_void_p()
+            check(lib.tc_rand_reader_take_example(self._native, C.byref(eg)), "tc_rand_reader_take_example")
+            self._cur = _egs._wrap_native(eg)
+            self._cur["_handle"] = handle
+        return super()._need()
+
     def next(self):
+        if self._native is not None:
+            rc = lib.tc_rand_reader_next(self._native)
+            self._cur = None
+            self._have = rc == 1
+            if rc < 0:
+                raise _egs.EgsFormatError((lib.tc_rand_reader_last_error() or b"").decode() or "tc_rand_reader_next: %d" % rc)
+            return rc == 1
         self._pos += 1
         if self._pos >= len(self._key_batch):
             self._cur = None
