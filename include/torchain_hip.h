@@ -166,6 +166,8 @@ int tc_example_output(const tc_example *example, int32_t j, const char **name, i
 typedef struct tc_rand_reader tc_rand_reader;
 int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char *len_file, int rank, int world,
                        int lookahead, tc_rand_reader **out);
+/* device >= 0: the look-ahead threads also stage every supervision they build for that GPU (tc_supervision_stage). */
+int tc_rand_reader_set_device(tc_rand_reader *reader, int device);
 int tc_rand_reader_reset(tc_rand_reader *reader);
 int tc_rand_reader_num_batch(const tc_rand_reader *reader);
 int tc_rand_reader_num_data(const tc_rand_reader *reader);
@@ -191,6 +193,9 @@ float tc_supervision_weight(const tc_supervision *supervision);
  * finished (event query, no synchronisation), so fresh supervisions every minibatch cost no hipMalloc / hipFree
  * after warm-up. */
 int tc_supervision_prepare(tc_supervision *supervision, int device, void *stream);
+/* The host half of that upload alone -- the tables into the pinned staging of a slot of `device`'s pool -- so that a
+ * reader's look-ahead thread can do it ahead of the training thread (tc_rand_reader_set_device); no stream is touched. */
+int tc_supervision_stage(tc_supervision *supervision, int device);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 

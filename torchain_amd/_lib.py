@@ -106,6 +106,10 @@ def _load():
     for name in ("tc_rand_reader_example", "tc_rand_reader_supervision_new", "tc_rand_reader_take_example"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp, vp]
+    L.tc_rand_reader_set_device.restype = C.c_int
+    L.tc_rand_reader_set_device.argtypes = [vp, C.c_int]
+    L.tc_supervision_stage.restype = C.c_int
+    L.tc_supervision_stage.argtypes = [vp, C.c_int]
     L.tc_rand_reader_batch_keys.restype = C.c_int
     L.tc_rand_reader_batch_keys.argtypes = [vp, C.c_int32, C.c_char_p, C.c_int32]
     L.tc_rand_reader_free.restype = None

@@ -261,6 +261,8 @@ struct NumDev {
   const float *arc_logw, *final_logw;
   float *stage = nullptr;  // [unique (frame, pdf) entries of all sequences]: posteriors in transit (launch_num_scatter)
   PoolSlot *slot = nullptr;
+  size_t upload_bytes = 0;  // of the slot's pinned staging, to be copied to the device
+  bool uploaded = false;    // the copy has been enqueued (tc_supervision_prepare); staged only: tc_supervision_stage
 };
 
 struct NumParams {

@@ -56,6 +56,7 @@ struct tc_rand_reader {
   std::map<int32_t, std::vector<int32_t>> by_length;  // frames_per_sequence -> entries (ascending lengths, scp order)
   std::mt19937 engine;
   int batchsize = 1, rank = 0, world = 1, lookahead = 0;
+  int device = -1;  // >= 0: look-ahead threads stage the supervisions they build for this GPU
   int64_t n_data = 0;
   std::vector<std::vector<int32_t>> batches;  // this rank's batches of the current epoch
   int64_t pos = -1;                            // the current batch (-1: before the first)
@@ -115,6 +116,7 @@ struct tc_rand_reader {
     r.rc = tc_example_output(r.example, 0, &name, &nidx, &idx, &dw, &weight, dims, &ab, &il, &aw, &nx, &fin);
     if (r.rc == TC_OK) r.rc = tc_supervision_create(&r.sup, weight, dims[0], dims[1], dims[2], dims[3], ab, il, aw, nx, fin);
     if (r.rc != TC_OK) r.error = "the minibatch's supervision does not build (tc_supervision_create)";
+    if (r.rc == TC_OK && device >= 0) (void)tc_supervision_stage(r.sup, device);  // (a failure shows at the first use)
     return r;
   }
 
@@ -237,6 +239,13 @@ int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char
 }
 
 void tc_rand_reader_free(tc_rand_reader *r) { delete r; }
+
+int tc_rand_reader_set_device(tc_rand_reader *r, int device) {
+  if (!r) return TC_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(r->mu);
+  r->device = device;
+  return TC_OK;
+}
 
 int tc_rand_reader_reset(tc_rand_reader *r) {
   if (!r) return TC_ERR_INVALID_ARGUMENT;

@@ -317,16 +317,11 @@ int32_t tc_supervision_num_sequence(const tc_supervision *s) { return s ? s->S :
 int32_t tc_supervision_num_frame(const tc_supervision *s) { return s ? s->T : 0; }
 float tc_supervision_weight(const tc_supervision *s) { return s ? s->weight : 0.f; }
 
-int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
-  if (!sup) return TC_ERR_INVALID_ARGUMENT;
-  hipStream_t stream = (hipStream_t)stream_v;
-  std::lock_guard<std::mutex> lock(sup->mu);
-  auto it = sup->dev.find(device);
-  if (it != sup->dev.end()) {
-    // uploaded earlier, possibly on another stream: order this stream behind the copy
-    TC_HIP_CHECK(hipStreamWaitEvent(stream, it->second.slot->ready, 0));
-    return TC_OK;
-  }
+// The host half of an upload: the supervision's tables into the pinned staging of a pool slot (2-3 MB of memcpy for 64
+// x 150 frames).  No stream is involved, so a reader's look-ahead thread can do it (tc_supervision_stage) and the
+// training thread's first use of the supervision only enqueues the copy.  Caller holds sup->mu.
+static int stage_locked(tc_supervision *sup, int device) {
+  if (sup->dev.count(device)) return TC_OK;
   NumTables &tb = sup->tab;
   struct Part { const void *src; size_t bytes; };
   const Part parts[] = {
@@ -359,16 +354,10 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   if (rc != TC_OK) return rc;
   for (int i = 0; i < nparts; ++i)
     if (parts[i].bytes) memcpy(slot->host + sup->blob_off[i], parts[i].src, parts[i].bytes);
-  hipError_t e = hipMemcpyAsync(slot->blob, slot->host, upload, hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipEventRecord(slot->ready, stream);
-  if (e == hipSuccess) e = hipEventRecord(slot->done, stream);  // (moved forward by every launch that reads the slot)
-  if (e != hipSuccess) {
-    g_last_hip_error = (int)e;
-    pool_release(device, slot);
-    return TC_ERR_HIP;
-  }
   NumDev d;
   d.slot = slot;
+  d.upload_bytes = upload;
+  d.uploaded = false;
   char *blob = slot->blob;
   auto P = [&](int i) { return (const int32_t *)(blob + sup->blob_off[i]); };
   d.seq_state_off = P(0); d.seq_arc_off = P(1); d.seq_uniq_off = P(2); d.level_begin = P(3);
@@ -378,6 +367,41 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   d.final_logw = (const float *)P(15);
   d.stage = (float *)(blob + stage_off);
   sup->dev[device] = d;
+  return TC_OK;
+}
+
+int tc_supervision_stage(tc_supervision *sup, int device) {
+  if (!sup) return TC_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(sup->mu);
+  return stage_locked(sup, device);
+}
+
+int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
+  if (!sup) return TC_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_v;
+  std::lock_guard<std::mutex> lock(sup->mu);
+  auto it = sup->dev.find(device);
+  if (it != sup->dev.end() && it->second.uploaded) {
+    // uploaded earlier, possibly on another stream: order this stream behind the copy
+    TC_HIP_CHECK(hipStreamWaitEvent(stream, it->second.slot->ready, 0));
+    return TC_OK;
+  }
+  if (it == sup->dev.end()) {
+    const int rc = stage_locked(sup, device);
+    if (rc != TC_OK) return rc;
+    it = sup->dev.find(device);
+  }
+  PoolSlot *slot = it->second.slot;
+  hipError_t e = hipMemcpyAsync(slot->blob, slot->host, it->second.upload_bytes, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipEventRecord(slot->ready, stream);
+  if (e == hipSuccess) e = hipEventRecord(slot->done, stream);  // (moved forward by every launch that reads the slot)
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    pool_release(device, slot);
+    sup->dev.erase(it);
+    return TC_ERR_HIP;
+  }
+  it->second.uploaded = true;
   return TC_OK;
 }
 

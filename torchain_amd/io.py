@@ -329,11 +329,12 @@ class RandExample(Example):
     from the egs.  The shuffle uses NumPy's MT19937 seeded with ``seed``: the same generator as the reference's
     ``std::mt19937`` but not the same draw order as ``std::shuffle``, whose algorithm is not specified."""
 
-    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True, rank=0, world=1, native=True):
+    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True, rank=0, world=1, native=True, device=None):
         """``rank`` / ``world``: this process's share of a data-parallel job (every rank forms the same shuffled list of
         minibatches from ``seed`` and takes every ``world``-th; all ranks get the same number).  ``native`` (default): the
         whole reader -- bucketing, shuffle, look-ahead threads, merge, supervision handles -- is the library's
         ``tc_rand_reader_*`` handle, as the reference's is ``my_lib_example_rand_reader_*`` (``src/my_lib.h:8-17``);
+        ``device`` is the GPU the batches are for (default: the current one, when there is one).
         ``native=False`` keeps the Python statement of it below (NumPy's MT19937 shuffle, a thread pool), which needs
         ``rank == 0, world == 1``."""
         assert os.path.exists(scp_path)
@@ -351,6 +352,12 @@ class RandExample(Example):
             self._native = handle
             self._cur = None
             self._have = False
+            # the GPU the minibatches are for (default: the current one): the look-ahead threads then also fill the pinned
+            # staging of each supervision's upload, which otherwise falls to the training thread's first use of it
+            if device is None and torch.cuda.is_available():
+                device = torch.cuda.current_device()
+            if device is not None:
+                check(lib.tc_rand_reader_set_device(handle, int(torch.device("cuda", device).index if not isinstance(device, int) else device)), "tc_rand_reader_set_device")
             return
         if rank != 0 or world != 1:
             raise ValueError("the Python reader does not shard: use native=True")
