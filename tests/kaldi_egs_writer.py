@@ -83,23 +83,29 @@ def compact_acceptor(sup):
     return out
 
 
-def supervision(sup, e2e_flag=False):
+def supervision(sup, e2e_flag=False, alignment_pdfs=None):
     out = _tok("<Supervision>") + _tok("<Weight>") + _basic("f", sup.weight)
     out += _tok("<NumSequences>") + _basic("i", sup.num_sequences) + _tok("<FramesPerSeq>") + _basic("i", sup.frames_per_sequence)
     out += _tok("<LabelDim>") + _basic("i", sup.label_dim)
     if e2e_flag:
         out += _tok("<End2End>") + b"F "
-    return out + compact_acceptor(sup) + _tok("</Supervision>")
+    out += compact_acceptor(sup)
+    if alignment_pdfs is not None:  # later Kaldi: WriteToken("<AlignmentPdfs>"), WriteIntegerVector (binary)
+        a = np.asarray(alignment_pdfs, np.int32)
+        out += _tok("<AlignmentPdfs>") + bytes([4]) + struct.pack("<i", len(a)) + a.tobytes()
+    return out + _tok("</Supervision>")
 
 
-def chain_example(eg, matrix_kind="FM", dw="DW2", e2e_flag=False):
+def chain_example(eg, matrix_kind="FM", dw="DW2", e2e_flag=False, alignment_pdfs=False):
     out = _tok("<Nnet3ChainEg>") + _tok("<NumInputs>") + _basic("i", len(eg["inputs"]))
     for io_ in eg["inputs"]:
         out += _tok("<NnetIo>") + _tok(io_["name"]) + index_vector(io_["indexes"]) + general_matrix(io_["features"], matrix_kind)
         out += _tok("</NnetIo>")
     out += _tok("<NumOutputs>") + _basic("i", len(eg["outputs"]))
     for o in eg["outputs"]:
-        out += _tok("<NnetChainSup>") + _tok(o["name"]) + index_vector(o["indexes"]) + supervision(o["supervision"], e2e_flag)
+        out += _tok("<NnetChainSup>") + _tok(o["name"]) + index_vector(o["indexes"])
+        sup = o["supervision"]
+        out += supervision(sup, e2e_flag, np.arange(sup.num_sequences * sup.frames_per_sequence) % sup.label_dim if alignment_pdfs else None)
         if dw == "DW2":
             out += _tok("<DW2>") + _tok("FV") + _basic("i", len(o["deriv_weights"])) + np.asarray(o["deriv_weights"], np.float32).tobytes()
         elif dw == "DW":

@@ -58,6 +58,25 @@ def test_example_round_trip(kind, tol, dw):
     assert same_fst(s, r)
 
 
+def test_alignment_pdfs_block_of_later_kaldi_is_skipped(tmp_path):
+    """Later Kaldi writes ``<AlignmentPdfs>`` + an integer vector behind the supervision's FST when the vector is not empty
+    ([K] chain-supervision.cc: Supervision::Write); the path does not use it.  Both readers skip it (ADVICE round 3: the
+    native one failed on it with a misleading "</Supervision>")."""
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    keyed = [("a%d" % i, make_example(fst, 7, seed=30 + i, n_seq=1)) for i in range(3)]
+    ark, scp = str(tmp_path / "al.ark"), str(tmp_path / "al.scp")
+    kw.write_ark(ark, keyed, scp_path=scp, alignment_pdfs=True, e2e_flag=True)
+    assert b"<AlignmentPdfs>" in open(ark, "rb").read()
+    plain = egs.read_chain_example(pyio.BytesIO(kw.chain_example(keyed[0][1])))
+    got = egs.read_chain_example(pyio.BytesIO(kw.chain_example(keyed[0][1], alignment_pdfs=True)))
+    assert same_fst(got["outputs"][0]["supervision"], plain["outputs"][0]["supervision"])
+    where = [(p, off) for _k, p, off in egs.read_scp(scp)]
+    merged = egs.read_merged_native(where)
+    ref = egs.merge_chain_examples([eg for _k, eg in keyed])
+    assert same_fst(merged["outputs"][0]["supervision"], ref["outputs"][0]["supervision"])
+    np.testing.assert_array_equal(merged["inputs"][0]["features"], ref["inputs"][0]["features"])
+
+
 def test_end2end_flag_across_a_read_buffer_boundary(tmp_path):
     """``BufferedReader.peek(n)`` may return a single byte: with the '<' of the newer-Kaldi ``<End2End>`` token as the
     last byte of an 8192-byte buffer block a two-byte look-ahead saw only '<', left the token unread and failed with

@@ -14,6 +14,7 @@
 * the opt-in register-row kernel (den_tied_rr.hip) against the default kernel and the oracle.
 Reference property tests these restate: ``src/chain-supervision-test.hpp:239-341``."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -218,3 +219,69 @@ def test_one_call_step_equals_the_multi_call_wrappers(three_d, kaldi_way):
         loss, res2 = chain_loss(c, den, hsup, 1e-4, 0.05)
         loss.backward()
         assert torch.equal(res2.data, res.data) and torch.equal(c.grad, a.grad)
+
+
+# ---- two ranks fed from the native reader ------------------------------------------------------------------------
+def _reader_worker(rank, world, port, scp, P, out_dir):
+    """One rank of a data-parallel epoch: its share of the shuffled minibatches from ``io.RandExample(rank=, world=)``
+    through ``parallel.chain_loss_data_parallel`` (both ranks on the test box's one GPU, the collective over gloo)."""
+    import os
+
+    import torch.distributed as dist
+
+    from torchain_amd import parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fst = synth.random_den_fst(40, 4, P, seed=1)
+        den = io.DenominatorGraph(fst, P)
+        rd = io.RandExample(scp, seed=11, batchsize=2, prefetch=2, rank=rank, world=world)
+        rows = []
+        for step, ((inp, aux), sup) in enumerate(rd):
+            B, T, _ = sup.shape
+            torch.manual_seed(1000 + step)  # (the same "model output" on both ranks would hide a mix-up: seed by step AND rank)
+            x = torch.randn(B, P, T, generator=torch.Generator().manual_seed(7 * step + rank)).cuda().requires_grad_(True)
+            loss, res = parallel.chain_loss_data_parallel(x, den, sup, 1e-4, 0.1)
+            loss.backward()
+            rows.append([float(v) for v in res.data] + [float(loss), B * T, float(x.grad.abs().sum())])
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.asarray(rows, np.float64))
+        with open(os.path.join(out_dir, "keys%d.txt" % rank), "w") as f:
+            for i in range(rd.n_batch):
+                f.write(" ".join(rd.batch_keys(i)) + "\n")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_fed_from_the_native_reader(tmp_path):
+    """the rank-aware data path.  Two processes read their shares of one epoch
+    (``tc_rand_reader_*`` with rank / world), run the data-parallel loss on them and must agree, step by step, on the
+    GLOBAL results -- whose weight is the sum of the two ranks' frames -- while together covering every minibatch of
+    the one-process list once."""
+    import socket
+    import sys
+
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_egs import _write_set
+
+    P = 24
+    fst = synth.random_den_fst(40, 4, P, seed=1)
+    lengths = [5] * 8 + [8] * 6 + [11] * 2
+    keyed, ark, scp = _write_set(tmp_path, fst, lengths)
+    io.print_key_length("scp:" + scp, scp + ".len")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_reader_worker, args=(2, port, scp, P, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(str(tmp_path / ("rank%d.npy" % k))) for k in range(2)]
+    assert r[0].shape == r[1].shape and r[0].shape[0] == 4  # 4 + 3 + 1 = 8 batches, four steps per rank
+    np.testing.assert_array_equal(r[0][:, :4], r[1][:, :4])  # objf, l2_term, weight, loss: global, identical on both ranks
+    np.testing.assert_array_equal(r[0][:, 2], r[0][:, 4] + r[1][:, 4])  # weight = frames of both ranks' batches (w = 1)
+    assert (r[0][:, 5] > 0).all() and (r[1][:, 5] > 0).all()
+    whole = io.RandExample(scp, seed=11, batchsize=2, prefetch=False)
+    full = [" ".join(whole.batch_keys(i)) for i in range(whole.n_batch)]
+    got = [open(str(tmp_path / ("keys%d.txt" % k))).read().split("\n")[:-1] for k in range(2)]
+    assert got[0] == full[0::2] and got[1] == full[1::2]

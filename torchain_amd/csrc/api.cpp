@@ -287,7 +287,10 @@ int tune_den_variant(tc_den_graph *g, int device) {
   if (stream) (void)hipStreamSynchronize(stream);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
-  if (stream) (void)hipStreamDestroy(stream);
+  if (stream) {
+    side_streams_forget(stream);  // (launch_den_mode made an entry for the temporary stream)
+    (void)hipStreamDestroy(stream);
+  }
   if (mem) (void)hipFree(mem);
   (void)hipGetLastError();  // (a failed scratch allocation is not the caller's error)
   return finish();

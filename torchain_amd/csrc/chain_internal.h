@@ -347,6 +347,7 @@ struct SideStreams {
   std::recursive_mutex enqueue;  // one caller at a time records / waits on the events (a wait binds to the latest record)
 };
 int side_streams(hipStream_t stream, SideStreams **out);  // den_graph.cpp
+void side_streams_forget(hipStream_t stream);              // ... before a caller stream is destroyed
 // CUs a denominator launch of S sequences occupies (two per sequence in the two-CU form, all for the streamed path)
 int den_cus_used(const DenParams &p, int num_cus);
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,

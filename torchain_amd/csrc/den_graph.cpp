@@ -35,9 +35,31 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes) {
 
 // One set of side streams and fork / join events per (device, CALLER stream): callers on different streams neither
 // share events (a wait binds to the latest record) nor serialise on one mutex.  Created on first use, all or nothing.
+static std::mutex g_side_mu;
+static std::map<std::pair<int, hipStream_t>, SideStreams> g_side_ctx;
+
+// A caller stream that is about to be destroyed (api.cpp: the tuning launches' temporary stream) takes its entry along:
+// the stream's value may be handed out again by the runtime, and the entry holds two streams and four events.
+void side_streams_forget(hipStream_t stream) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  auto it = g_side_ctx.find(std::make_pair(device, stream));
+  if (it == g_side_ctx.end()) return;
+  SideStreams &c = it->second;
+  for (hipStream_t x : {c.den_side, c.num_side})
+    if (x) {
+      (void)hipStreamSynchronize(x);
+      (void)hipStreamDestroy(x);
+    }
+  for (hipEvent_t x : {c.fork, c.join, c.num_fork, c.num_join})
+    if (x) (void)hipEventDestroy(x);
+  g_side_ctx.erase(it);
+}
+
 int side_streams(hipStream_t stream, SideStreams **out) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SideStreams> ctx;
+  std::mutex &mu = g_side_mu;
+  auto &ctx = g_side_ctx;
   int device = 0;
   TC_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mu);

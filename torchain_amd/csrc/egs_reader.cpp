@@ -263,7 +263,19 @@ void read_supervision(In &in, Sup *s) {
     if (in.boolean()) throw FormatError{"end-to-end (e2e) supervisions are outside this path"};
   }
   read_compact_acceptor(in, s);
-  in.expect("</Supervision>");
+  // later Kaldi: alignment pdfs of the supervision, written behind the FST when the vector is not empty
+  // ([K] Supervision::Write: WriteToken("<AlignmentPdfs>"), WriteIntegerVector).  The path does not use them: skipped.
+  std::string tok = in.token();
+  if (tok == "<AlignmentPdfs>") {
+    if (in.byte() != sizeof(int32_t)) throw FormatError{"<AlignmentPdfs>: element size"};
+    int32_t n = 0;
+    in.read(&n, sizeof(n));
+    if (n < 0 || (int64_t)n > (int64_t)s->S * s->T) throw FormatError{"<AlignmentPdfs>: size"};
+    std::vector<int32_t> skip((size_t)n);
+    in.read(skip.data(), (size_t)n * sizeof(int32_t));
+    tok = in.token();
+  }
+  if (tok != "</Supervision>") throw FormatError{"</Supervision>"};
 }
 
 struct Example {
@@ -324,6 +336,13 @@ void read_example(In &in, Example *eg) {
 int merge(const std::vector<Example> &egs, Example *m) {
   const Example &first = egs[0];
   if (first.out.empty()) return TC_ERR_BAD_FST;
+  // one output per example is what the path (and the reference: outputs[0], src/my_lib_example.cpp:75) handles: more are
+  // refused rather than silently dropped; an input's rows must be the rows its indexes name
+  for (const Example &eg : egs) {
+    if (eg.out.size() != 1) return TC_ERR_INVALID_ARGUMENT;
+    for (const Io &io : eg.in)
+      if ((size_t)io.rows != io.idx.size() / 3) return TC_ERR_BAD_FST;
+  }
   m->in.resize(first.in.size());
   for (size_t j = 0; j < first.in.size(); ++j) {
     Io &dst = m->in[j];

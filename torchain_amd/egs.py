@@ -220,7 +220,17 @@ def _read_supervision(r):
         if r.boolean():
             raise EgsFormatError("end-to-end (e2e) supervisions are outside this path (SURVEY.md section 8a caveat 3)")
     arc_begin, ilabel, w, nxt, final = _read_compact_acceptor(r)
-    r.expect("</Supervision>")
+    tok = r.token()
+    if tok == "<AlignmentPdfs>":  # later Kaldi, behind the FST when not empty ([K] WriteIntegerVector); unused here
+        if r.read(1)[0] != 4:
+            raise EgsFormatError("<AlignmentPdfs>: element size")
+        n = struct.unpack("<i", r.read(4))[0]
+        if n < 0 or n > S * T:
+            raise EgsFormatError("<AlignmentPdfs>: size")
+        r.read(4 * n)
+        tok = r.token()
+    if tok != "</Supervision>":
+        raise EgsFormatError("expected </Supervision>, got %s" % tok)
     return SupFst(float(weight), S, T, P, len(final), arc_begin, ilabel, w, nxt, final)
 
 
