@@ -39,8 +39,9 @@ def elementwise(got, ref, what, bounds=((1e-3, 1e-4), (1e-4, 1e-3))):
         assert worst <= tol, (what, "entries above %g: worst relative error %.3g > %g" % (floor, worst, tol))
 
 
-def test_kernel_choice_is_reproducible_and_can_be_fixed(oracle):
+def test_kernel_choice_is_reproducible_and_can_be_fixed(oracle, tmp_path, monkeypatch):
     """R1 (the graph whose choice the timing makes: the two-sequence kernel wins by 6-12 %)."""
+    monkeypatch.setenv("TORCHAIN_TUNING_CACHE", str(tmp_path / "tuning.json"))  # (an empty cache: the first prepare times)
     fst = synth.config_den_fst("R1")
     P = synth.CONFIGS["R1"]["P"]
     S, T = 192, 12

@@ -321,7 +321,11 @@ __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
       const int tn = t > 0 ? t - 1 : 0;
       const rsrc_t yrow = make_rsrc(p.y + ((int64_t)tn * S + s) * p.y_stride, row_bytes);
 #pragma unroll
+#ifdef TC_ABL_NOY2
+      for (int v = 0; v < PV; ++v) ynext[v] = mk4(0.25f) * (float)t;  // (ablation: what the backward pass's second read of y costs)
+#else
       for (int v = 0; v < PV; ++v) ynext[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+#endif
 #pragma unroll
       for (int j = 0; j < JV; ++j) areg[j] = j < planes ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
     }
