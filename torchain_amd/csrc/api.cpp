@@ -20,6 +20,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Workspace {
   float *big_expy, *big_beta, *big_small, *big_y;  // streamed path only
+  uint32_t *big_gam = nullptr;
   int big_exp_frames = 1;
   float *beta_hist, *fwd_norm, *bwd_norm;          // two-CU forms of small batches only (den_tied_split.hip, den_tied_mitm.hip)
   uint32_t *mitm_sync = nullptr;
@@ -48,10 +49,10 @@ bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <
 // history rows, the two roles' normalisers and the pairing words.
 bool pair_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.JV == kJvSmall; }
 
-// big_P != 0 selects the streamed path's layout: sequences padded to 64 lanes, [state][sequence] matrices
+// big_P != 0 selects the streamed path's layout: sequences padded to slabs of 16, [slab][state][16] matrices
 Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, bool split = false, bool pair = false) {
   Workspace w;
-  const int Sp = (S + 63) & ~63;
+  const int Sp = (S + kSlab - 1) / kSlab * kSlab;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char *p = base ? base + off : nullptr;
@@ -75,6 +76,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
   w.big_y = big_P ? (float *)take((size_t)Sp * big_H * sizeof(float)) : nullptr;
+  w.big_gam = big_P ? (uint32_t *)take((size_t)Sp * big_P * sizeof(uint32_t)) : nullptr;
   w.beta_hist = split ? (float *)take((size_t)(T + 1) * S * Hs * sizeof(float)) : nullptr;
   w.fwd_norm = split ? (float *)take((size_t)S * (T + 2) * sizeof(float)) : nullptr;
   w.bwd_norm = split ? (float *)take((size_t)S * (T + 1) * sizeof(float)) : nullptr;
@@ -131,10 +133,11 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   }
   p->big = d.big;
   p->big_expy = w.big_expy;
-  p->big_exp_stride = w.big_exp_frames > 1 ? (int64_t)((S + 63) & ~63) * g->P : 0;
+  p->big_exp_stride = w.big_exp_frames > 1 ? (int64_t)((S + kSlab - 1) / kSlab * kSlab) * g->P : 0;
   p->big_beta = w.big_beta;
   p->big_small = w.big_small;
   p->big_y = w.big_y;
+  p->big_gam = w.big_gam;
   p->beta_hist = w.beta_hist;
   p->fwd_norm = w.fwd_norm;
   p->bwd_norm = w.bwd_norm;
@@ -144,7 +147,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->pair_stamps = w.pair_stamps;
   p->pair_extra_slots = std::max(g->fwd.extra_slots, g->bwd.extra_slots);
   p->pair_choice = d.pair_choice > 0 ? 1 : 0;
-  p->big_Sp = (S + 63) & ~63;
+  p->big_Sp = (S + kSlab - 1) / kSlab * kSlab;
   p->big_sum_pi = g->big_sum_pi;
   p->tied_fs = tied ? d.tied_fs : nullptr;
   p->tied_w = tied ? d.tied_w : nullptr;

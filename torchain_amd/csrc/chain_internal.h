@@ -98,27 +98,45 @@ struct ScheduleDev {
   int32_t img_stride = 0, max_chunks = 0;
 };
 
-// ---- graphs too large for the on-chip layout ("streamed" path, den_big_kernel.hip) ------------------
-// alpha / beta live in HBM/L2 as [state][sequence] matrices (lanes run over sequences) and the
-// transitions are plain CSR lists of 16-byte records, wave-uniform, in three orders: by destination
-// (forward), by source (backward beta'), by pdf (backward gamma: one wave per pdf sums its arcs, so the
-// derivative needs no atomics and the result is order-deterministic).
-struct BigArc {
-  int32_t a, b;  // by destination: {src, pdf}; by source: {dst, pdf}; by pdf: {src, dst}
-  float w;
-  float pi;      // initial probability of the arc's SOURCE state (alpha' = alpha + leaky*pi*asum on the fly)
+// ---- graphs too large for the on-chip layout ("streamed" path, den_slab_kernel.hip) ------------------
+// alpha / beta live in HBM/L2 as [slab of 16 sequences][state][16] matrices (lanes run over sequences, one row of
+// a list per 16-lane group of a wave).  A LIST is a set of rows (states, or pdfs) with their entries: by destination
+// (forward), by source (backward beta'), and -- general graphs only -- by pdf (gamma: one group per pdf sums its
+// arcs, so the derivative needs no float atomics).  Rows are taken four at a time ("bundle"), sorted by length.
+constexpr int kSlab = 16;
+constexpr int kSlabBundlesPerBlock = 16;  // 64 rows per block of 256 threads
+struct SlabRow {       // 32 bytes: two 16-byte loads per lane
+  int32_t row;         // state (arc lists) or pdf (by-pdf list); -1: this group of the bundle has no row
+  int32_t n;           // entries of this row
+  int32_t f_off, s_off;  // tied graphs: 64 * the state's forward / special self-loop pdf, -1: none
+  float ws, pi;        // tied graphs: self-loop probability; every state list: initial probability
+  float K;             // tied graphs, by destination: sum over the in-arcs of w * pi(src)
+  float pad;
+};
+// entries: W dwords per step (tied arc lists {64 * other state, w}: W = 2; general lists {64 * a, 64 * b, w, pi}:
+// W = 4; by destination {src, pdf, w, pi(src)}, by source {dst, pdf, w, 1}, by pdf {src, dst, w, pi(src)}), a bundle's
+// steps in chunks of 16 / W: dword c of step i of row q at [chunk][16 q + W i + c].  Steps past a row's end: zeros.
+struct SlabListDev {
+  const SlabRow *rows = nullptr;   // [bundles][4]
+  const int2 *head = nullptr;      // [bundles] {first chunk, steps}
+  const uint32_t *rec = nullptr;   // [chunks + 1][64]
+  int32_t bundles = 0;
+};
+struct SlabListHost {
+  int W = 2;
+  std::vector<SlabRow> rows;
+  std::vector<int32_t> head;       // 2 per bundle
+  std::vector<uint32_t> rec;
+  int32_t bundles = 0;
 };
 
 struct BigDev {
-  const int32_t *in_begin = nullptr, *out_begin = nullptr, *pdf_begin = nullptr;
-  const BigArc *in_arc = nullptr, *out_arc = nullptr, *pdf_arc = nullptr;
+  SlabListDev in, out, pdf;
   // tied graphs (work-graph states): the arc lists hold the non-special arcs only and exp(y) is applied
-  // per state, so an arc costs ONE row gather per pass; gamma comes from per-state quantities through
-  // pdf_arc, here a by-pdf list of entries {state, (self-loop pdf + 1) * 2 | role, self-loop prob, pi}
-  // (role 0: the entry stands under the state's forward pdf, 1: under its self-loop pdf)
+  // per state, so an arc costs ONE row gather per pass; gamma comes from per-state quantities, added by the
+  // backward kernel to fixed-point accumulators
   int tied = 0;
-  const int32_t *tf = nullptr, *ts = nullptr;  // per state: forward / self-loop pdf (-1: none)
-  const float *tws = nullptr;                  // per state: special self-loop probability
+  const int32_t *f_off = nullptr;  // tied: per state, 64 * forward pdf (-1: none)
 };
 
 struct DenGraphDev {
@@ -165,12 +183,13 @@ struct DenParams {
   const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
   const float *tied_w;
   BigDev big;           // streamed path only
-  float *big_expy;      // [P][Sp]  exp(y_t) of the current frame, transposed; or [T][P][Sp], every frame (big_exp_stride)
+  float *big_expy;      // [slab][P][16]  exp(y_t) of the current frame, transposed; or [T][slab][P][16], every frame (big_exp_stride)
   int64_t big_exp_stride = 0;  // floats between consecutive frames of big_expy (0: one frame at a time)
-  float *big_beta;      // [2][H][Sp]
-  float *big_y;         // [H][Sp]  tied graphs: Y = beta_{t+1} * p_t(f), the backward gather source
-  float *big_small;     // per-sequence sums and per-block partials (den_big_kernel.hip: BigSmall)
-  int big_Sp;           // sequences rounded up to a multiple of 64
+  float *big_beta;      // [2][slab][H][16]
+  float *big_y;         // [slab][H][16]  tied graphs: Y = beta_{t+1} * p_t(f), the backward gather source
+  uint32_t *big_gam = nullptr;  // [slab][P][16]  tied graphs: the frame's gamma, unsigned fixed point (den_device.h: kGammaScale)
+  float *big_small;     // per-sequence sums and per-block partials (den_slab_kernel.hip: BigSmall)
+  int big_Sp;           // sequences rounded up to a multiple of 16 (kSlab)
   float big_sum_pi;     // sum of the initial probabilities
   long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
   // Two-CU form for small batches (den_tied_split.hip): the forward recursion writes its per-frame sums, the
@@ -218,8 +237,8 @@ struct tc_den_graph {
   bool layout_ok = false;
   // streamed path: chosen when neither on-chip layout fits (or TC_FORCE_BIG is set)
   bool big = false;
-  std::vector<int32_t> big_in_begin, big_out_begin, big_pdf_begin;
-  std::vector<tc::BigArc> big_in, big_out, big_pdf;
+  tc::SlabListHost big_in, big_out, big_pdf;
+  std::vector<int32_t> big_f_off;
   std::vector<int32_t> tied_f, tied_s;  // per work state: forward / special self-loop pdf, -1 if none
   float big_sum_pi = 0.f;
   std::mutex mu;

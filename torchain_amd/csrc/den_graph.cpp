@@ -95,62 +95,123 @@ int side_streams(hipStream_t stream, SideStreams **out) {
 static std::atomic<int> g_debug[kDbgCount];
 bool debug_flag(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed) != 0; }
 
-// CSR lists for the streamed path (chain_internal.h: BigArc)
+// ---- lists of the streamed path (chain_internal.h: SlabListHost) -------------------------------------------
+struct SlabEntry {
+  uint32_t d[4];
+};
+static uint32_t f2u(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+
+// entries[r]: row r's entries in list order; meta[r]: its SlabRow (n is filled in here); bundle_rows: four row
+// indices per bundle, -1 for none
+static void make_slab_list(int W, const std::vector<std::vector<SlabEntry>> &entries, const std::vector<SlabRow> &meta,
+                           const std::vector<int32_t> &bundle_rows, SlabListHost *out) {
+  const int spc = 16 / W;
+  out->W = W;
+  out->bundles = (int32_t)(bundle_rows.size() / 4);
+  out->rows.assign(bundle_rows.size(), SlabRow{-1, 0, -1, -1, 0.f, 0.f, 0.f, 0.f});
+  out->head.assign((size_t)out->bundles * 2, 0);
+  out->rec.clear();
+  size_t chunk = 0;
+  for (int32_t b = 0; b < out->bundles; ++b) {
+    int steps = 0;
+    for (int q = 0; q < 4; ++q)
+      if (bundle_rows[(size_t)b * 4 + q] >= 0) steps = std::max(steps, (int)entries[bundle_rows[(size_t)b * 4 + q]].size());
+    const int chunks = (steps + spc - 1) / spc;
+    out->head[(size_t)b * 2] = (int32_t)chunk;
+    out->head[(size_t)b * 2 + 1] = steps;
+    out->rec.resize((chunk + chunks) * 64, 0u);
+    for (int q = 0; q < 4; ++q) {
+      const int32_t r = bundle_rows[(size_t)b * 4 + q];
+      if (r < 0) continue;
+      SlabRow m = meta[r];
+      m.n = (int32_t)entries[r].size();
+      out->rows[(size_t)b * 4 + q] = m;
+      for (int i = 0; i < m.n; ++i)
+        for (int c = 0; c < W; ++c)
+          out->rec[(chunk + i / spc) * 64 + q * 16 + (i % spc) * W + c] = entries[r][i].d[c];
+    }
+    chunk += chunks;
+  }
+  out->rec.resize((chunk + 1) * 64, 0u);  // a spare chunk: the walk requests one chunk ahead
+}
+
+// rows sorted by length (longest first, stable), four at a time
+static std::vector<int32_t> bundles_by_length(const std::vector<std::vector<SlabEntry>> &entries) {
+  std::vector<int32_t> order(entries.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return entries[a].size() > entries[b].size(); });
+  while (order.size() % 4) order.push_back(-1);
+  if (order.empty()) order.assign(4, -1);
+  return order;
+}
+
+// by-pdf list: a block of the gamma kernel is a tile of 64 consecutive pdfs; its 16 bundles are sorted inside the tile
+static std::vector<int32_t> bundles_by_tile(const std::vector<std::vector<SlabEntry>> &entries, int P) {
+  std::vector<int32_t> out;
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    std::vector<int32_t> tile(64, -1);
+    for (int i = 0; i < 64 && p0 + i < P; ++i) tile[i] = p0 + i;
+    std::stable_sort(tile.begin(), tile.end(), [&](int32_t a, int32_t b) {
+      const size_t na = a >= 0 ? entries[a].size() + 1 : 0, nb = b >= 0 ? entries[b].size() + 1 : 0;
+      return na > nb;
+    });
+    out.insert(out.end(), tile.begin(), tile.end());
+  }
+  return out;
+}
+
 static void build_big(tc_den_graph *g) {
   const int H = g->H, P = g->P;
   const int64_t A = g->A;
-  auto csr = [&](int n, const std::vector<int32_t> &key, std::vector<int32_t> *begin, std::vector<BigArc> *out,
-                 const std::vector<int32_t> &fa, const std::vector<int32_t> &fb) {
-    begin->assign(n + 1, 0);
-    for (int64_t a = 0; a < A; ++a) (*begin)[key[a] + 1]++;
-    for (int i = 0; i < n; ++i) (*begin)[i + 1] += (*begin)[i];
-    out->assign(std::max<int64_t>(A, 1), BigArc{0, 0, 0.f, 0.f});
-    std::vector<int32_t> fill(begin->begin(), begin->end() - 1);
-    for (int64_t a = 0; a < A; ++a)  // FST arc order kept
-      (*out)[fill[key[a]]++] = BigArc{fa[a], fb[a], g->arc_prob[a], g->initial_probs[g->arc_src[a]]};
-  };
-  csr(H, g->arc_dst, &g->big_in_begin, &g->big_in, g->arc_src, g->arc_pdf);
-  csr(H, g->arc_src, &g->big_out_begin, &g->big_out, g->arc_dst, g->arc_pdf);
-  csr(P, g->arc_pdf, &g->big_pdf_begin, &g->big_pdf, g->arc_src, g->arc_dst);
+  std::vector<std::vector<SlabEntry>> in(H), outl(H), pdf(P);
+  for (int64_t a = 0; a < A; ++a) {  // FST arc order kept
+    const uint32_t s = (uint32_t)g->arc_src[a] * 64u, d = (uint32_t)g->arc_dst[a] * 64u, pd = (uint32_t)g->arc_pdf[a] * 64u;
+    const uint32_t w = f2u(g->arc_prob[a]), pis = f2u(g->initial_probs[g->arc_src[a]]);
+    in[g->arc_dst[a]].push_back(SlabEntry{{s, pd, w, pis}});
+    outl[g->arc_src[a]].push_back(SlabEntry{{d, pd, w, f2u(1.0f)}});
+    pdf[g->arc_pdf[a]].push_back(SlabEntry{{s, d, w, pis}});
+  }
+  std::vector<SlabRow> ms(H), mp(P);
+  for (int h = 0; h < H; ++h) ms[h] = SlabRow{h, 0, -1, -1, 0.f, g->initial_probs[h], 0.f, 0.f};
+  for (int i = 0; i < P; ++i) mp[i] = SlabRow{i, 0, -1, -1, 0.f, 0.f, 0.f, 0.f};
+  make_slab_list(4, in, ms, bundles_by_length(in), &g->big_in);
+  make_slab_list(4, outl, ms, bundles_by_length(outl), &g->big_out);
+  make_slab_list(4, pdf, mp, bundles_by_tile(pdf, P), &g->big_pdf);
+  g->big_f_off.assign(1, -1);
   float sum_pi = 0.f;
   for (int h = 0; h < H; ++h) sum_pi += g->initial_probs[h];
   g->big_sum_pi = sum_pi;
 }
 
-// Streamed path of a tied (work) graph: arc lists without the special self-loops, per-state pdfs, and the
-// by-pdf {state, role} entries gamma is assembled from (chain_internal.h: BigDev).
+// Streamed path of a tied (work) graph: arc lists without the special self-loops, per-state pdfs and self-loop
+// probabilities in the rows (chain_internal.h: BigDev).
 static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
-  const int H = g->work_H, P = g->P;
+  const int H = g->work_H;
   const int64_t A = (int64_t)g->work_src.size();
-  auto csr = [&](const std::vector<int32_t> &key, std::vector<int32_t> *begin, std::vector<BigArc> *out,
-                 const std::vector<int32_t> &other) {
-    begin->assign(H + 1, 0);
-    for (int64_t a = 0; a < A; ++a)
-      if (!special[a]) (*begin)[key[a] + 1]++;
-    for (int i = 0; i < H; ++i) (*begin)[i + 1] += (*begin)[i];
-    out->assign(std::max<int64_t>((*begin)[H], 1), BigArc{0, 0, 0.f, 0.f});
-    std::vector<int32_t> fill(begin->begin(), begin->end() - 1);
-    for (int64_t a = 0; a < A; ++a)
-      if (!special[a]) (*out)[fill[key[a]]++] = BigArc{other[a], g->work_pdf[a], g->work_prob[a], g->work_pi[g->work_src[a]]};
-  };
-  csr(g->work_dst, &g->big_in_begin, &g->big_in, g->work_src);
-  csr(g->work_src, &g->big_out_begin, &g->big_out, g->work_dst);
-  // entries by pdf: every state once under its forward pdf (role 0) and once under its special self-loop pdf (role 1)
-  g->big_pdf_begin.assign(P + 1, 0);
-  for (int h = 0; h < H; ++h) {
-    if (g->tied_f[h] >= 0) g->big_pdf_begin[g->tied_f[h] + 1]++;
-    if (g->tied_s[h] >= 0) g->big_pdf_begin[g->tied_s[h] + 1]++;
+  std::vector<std::vector<SlabEntry>> in(H), outl(H);
+  std::vector<float> K(H, 0.f);
+  for (int64_t a = 0; a < A; ++a) {
+    if (special[a]) continue;
+    const int32_t s = g->work_src[a], d = g->work_dst[a];
+    in[d].push_back(SlabEntry{{(uint32_t)s * 64u, f2u(g->work_prob[a]), 0u, 0u}});
+    outl[s].push_back(SlabEntry{{(uint32_t)d * 64u, f2u(g->work_prob[a]), 0u, 0u}});
+    K[d] += g->work_prob[a] * g->work_pi[s];
   }
-  for (int i = 0; i < P; ++i) g->big_pdf_begin[i + 1] += g->big_pdf_begin[i];
-  // an entry is a BigArc {state, (self-loop pdf + 1) * 2 | role, self-loop prob, pi(state)}: everything the
-  // gamma kernel needs about the state besides its rows, so no dependent table loads
-  g->big_pdf.assign(std::max(g->big_pdf_begin[P], 1), BigArc{0, 0, 0.f, 0.f});
-  std::vector<int32_t> fill(g->big_pdf_begin.begin(), g->big_pdf_begin.end() - 1);
+  std::vector<SlabRow> mi(H), mo(H);
+  g->big_f_off.assign(H, -1);
   for (int h = 0; h < H; ++h) {
-    const int32_t code = (g->tied_s[h] + 1) * 2;
-    if (g->tied_f[h] >= 0) g->big_pdf[fill[g->tied_f[h]]++] = BigArc{h, code | 0, g->tied_w[h], g->work_pi[h]};
-    if (g->tied_s[h] >= 0) g->big_pdf[fill[g->tied_s[h]]++] = BigArc{h, code | 1, g->tied_w[h], g->work_pi[h]};
+    const int32_t f = g->tied_f[h] >= 0 ? g->tied_f[h] * 64 : -1, sl = g->tied_s[h] >= 0 ? g->tied_s[h] * 64 : -1;
+    mi[h] = SlabRow{h, 0, f, sl, g->tied_w[h], g->work_pi[h], K[h], 0.f};
+    mo[h] = SlabRow{h, 0, f, sl, g->tied_w[h], g->work_pi[h], 0.f, 0.f};
+    g->big_f_off[h] = f;
   }
+  make_slab_list(2, in, mi, bundles_by_length(in), &g->big_in);
+  make_slab_list(2, outl, mo, bundles_by_length(outl), &g->big_out);
+  g->big_pdf = SlabListHost();
   float sum_pi = 0.f;
   for (int h = 0; h < H; ++h) sum_pi += g->work_pi[h];
   g->big_sum_pi = sum_pi;
@@ -521,23 +582,38 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
                             float *out) {
   if (!g || !gather || !pdf_factor || !out || direction < 0 || direction > 1) return TC_ERR_INVALID_ARGUMENT;
   const int H = g->H;
+  // streamed path: the lists are replayed the way the kernels read them (bundle, group of 16 lanes, chunk, step)
+  auto slab_sums = [&](const SlabListHost &L, auto term, std::vector<float> *sums) {
+    const int spc = 16 / L.W;
+    for (int32_t b = 0; b < L.bundles; ++b)
+      for (int q = 0; q < 4; ++q) {
+        const SlabRow &r = L.rows[(size_t)b * 4 + q];
+        if (r.row < 0) continue;
+        float sum = 0.f;
+        for (int i = 0; i < r.n; ++i) sum += term(&L.rec[((size_t)L.head[(size_t)b * 2] + i / spc) * 64 + q * 16 + (i % spc) * L.W]);
+        (*sums)[r.row] = sum;
+      }
+  };
+  auto u2f = [](uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+  };
   if (g->big && g->tied) {
     // work-graph states; a split state's forward value sits on its first copy, its backward value on all
-    const std::vector<int32_t> &begin = direction == 0 ? g->big_in_begin : g->big_out_begin;
-    const std::vector<BigArc> &arc = direction == 0 ? g->big_in : g->big_out;
+    const SlabListHost &L = direction == 0 ? g->big_in : g->big_out;
     auto pf = [&](int pdf) { return pdf >= 0 ? pdf_factor[pdf] : 0.f; };
-    std::vector<float> val(g->work_H, 0.f);
+    std::vector<float> val(g->work_H, 0.f), sums(g->work_H, 0.f);
     for (int h = 0; h < H; ++h)
       for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c)
         val[c] = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f) : gather[h] * pf(g->tied_f[c]);
+    slab_sums(L, [&](const uint32_t *e) { return u2f(e[1]) * val[e[0] / 64]; }, &sums);
     for (int h = 0; h < H; ++h) {
       float total = 0.f;
       for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
-        float sum = 0.f;
-        for (int a = begin[c]; a < begin[c + 1]; ++a) sum += arc[a].w * val[arc[a].a];
         const float own = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f) : gather[h];
         const float self = pf(g->tied_s[c]) * g->tied_w[c] * own;
-        const float v = direction == 0 ? pf(g->tied_f[c]) * sum + self : sum + self;
+        const float v = direction == 0 ? pf(g->tied_f[c]) * sums[c] + self : sums[c] + self;
         if (direction == 1) {
           total = v;
           break;
@@ -549,13 +625,10 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
     return TC_OK;
   }
   if (g->big) {
-    const std::vector<int32_t> &begin = direction == 0 ? g->big_in_begin : g->big_out_begin;
-    const std::vector<BigArc> &arc = direction == 0 ? g->big_in : g->big_out;
-    for (int h = 0; h < H; ++h) {
-      float sum = 0.f;
-      for (int a = begin[h]; a < begin[h + 1]; ++a) sum += arc[a].w * gather[arc[a].a] * pdf_factor[arc[a].b];
-      out[h] = sum;
-    }
+    std::vector<float> sums(H, 0.f);
+    slab_sums(direction == 0 ? g->big_in : g->big_out,
+              [&](const uint32_t *e) { return u2f(e[2]) * gather[e[0] / 64] * pdf_factor[e[1] / 64]; }, &sums);
+    for (int h = 0; h < H; ++h) out[h] = sums[h];
     return TC_OK;
   }
   if (!g->layout_ok) return TC_ERR_UNSUPPORTED;
@@ -687,16 +760,19 @@ static int upload_den_graph(tc_den_graph *g, int device) {
     const std::vector<int32_t> none_i(1, -1);
     const std::vector<float> none_f(1, 0.f);
     const bool tb = g->tied;
-    Part parts[] = {
-        {g->big_in_begin.data(), g->big_in_begin.size() * 4, 0}, {g->big_in.data(), g->big_in.size() * sizeof(BigArc), 0},
-        {g->big_out_begin.data(), g->big_out_begin.size() * 4, 0}, {g->big_out.data(), g->big_out.size() * sizeof(BigArc), 0},
-        {g->big_pdf_begin.data(), g->big_pdf_begin.size() * 4, 0},
-        {g->big_pdf.data(), g->big_pdf.size() * sizeof(BigArc), 0},
-        {pi_pad.data(), pi_pad.size() * 4, 0},
-        {tb ? g->tied_f.data() : none_i.data(), (tb ? g->tied_f.size() : 1) * 4, 0},
-        {tb ? g->tied_s.data() : none_i.data(), (tb ? g->tied_s.size() : 1) * 4, 0},
-        {tb ? g->tied_w.data() : none_f.data(), (tb ? g->tied_w.size() : 1) * 4, 0},
-    };
+    const SlabListHost *lists[3] = {&g->big_in, &g->big_out, &g->big_pdf};
+    const std::vector<SlabRow> no_rows(4, SlabRow{-1, 0, -1, -1, 0.f, 0.f, 0.f, 0.f});
+    const std::vector<int32_t> no_head(2, 0);
+    const std::vector<uint32_t> no_rec(64, 0u);
+    Part parts[11];
+    for (int l = 0; l < 3; ++l) {
+      const bool have = lists[l]->bundles > 0;
+      parts[3 * l] = Part{have ? (const void *)lists[l]->rows.data() : no_rows.data(), (have ? lists[l]->rows.size() : 4) * sizeof(SlabRow), 0};
+      parts[3 * l + 1] = Part{have ? (const void *)lists[l]->head.data() : no_head.data(), (have ? lists[l]->head.size() : 2) * 4, 0};
+      parts[3 * l + 2] = Part{have ? (const void *)lists[l]->rec.data() : no_rec.data(), (have ? lists[l]->rec.size() : 64) * 4, 0};
+    }
+    parts[9] = Part{pi_pad.data(), pi_pad.size() * 4, 0};
+    parts[10] = Part{g->big_f_off.data(), g->big_f_off.size() * 4, 0};
     size_t total = 0;
     for (auto &p : parts) {
       p.off = total;
@@ -716,19 +792,16 @@ static int upload_den_graph(tc_den_graph *g, int device) {
     }
     DenGraphDev d;
     d.blob = blob;
-    d.big.in_begin = (const int32_t *)(blob + parts[0].off);
-    d.big.in_arc = (const BigArc *)(blob + parts[1].off);
-    d.big.out_begin = (const int32_t *)(blob + parts[2].off);
-    d.big.out_arc = (const BigArc *)(blob + parts[3].off);
-    d.big.pdf_begin = (const int32_t *)(blob + parts[4].off);
-    d.big.pdf_arc = (const BigArc *)(blob + parts[5].off);
-    d.pi = (const float *)(blob + parts[6].off);
-    if (tb) {
-      d.big.tied = 1;
-      d.big.tf = (const int32_t *)(blob + parts[7].off);
-      d.big.ts = (const int32_t *)(blob + parts[8].off);
-      d.big.tws = (const float *)(blob + parts[9].off);
+    SlabListDev *dl[3] = {&d.big.in, &d.big.out, &d.big.pdf};
+    for (int l = 0; l < 3; ++l) {
+      dl[l]->rows = (const SlabRow *)(blob + parts[3 * l].off);
+      dl[l]->head = (const int2 *)(blob + parts[3 * l + 1].off);
+      dl[l]->rec = (const uint32_t *)(blob + parts[3 * l + 2].off);
+      dl[l]->bundles = lists[l]->bundles;
     }
+    d.pi = (const float *)(blob + parts[9].off);
+    d.big.tied = tb ? 1 : 0;
+    d.big.f_off = (const int32_t *)(blob + parts[10].off);
     g->dev[device] = d;
     return TC_OK;
   }

@@ -1,6 +1,6 @@
 // Fused denominator forward-backward for GENERAL graphs on gfx950 (any arc labelling); chain-structured
 // ("tied") graphs -- the benchmarked case -- take den_tied_kernel.hip, graphs beyond the on-chip layouts
-// den_big_kernel.hip.
+// den_slab_kernel.hip.
 //
 // What it computes: [K] DenominatorComputation::Forward() + Backward() (chain-denominator.cc), the
 // part of the reference's hot call (src/my_lib_chain.cpp:129-131) that the headline metric times.
@@ -452,7 +452,7 @@ static int launch_den_tied_split(const DenParams &p, int accumulate, hipStream_t
 }
 
 static bool split_wanted(const DenParams &p) {
-  return p.tied_fs && !p.big.in_begin && p.deriv && p.beta_hist && split_bwd_fits(p.L, p.T) && !debug_flag(kDbgNoPhaseSplit);
+  return p.tied_fs && !p.big.in.rows && p.deriv && p.beta_hist && split_bwd_fits(p.L, p.T) && !debug_flag(kDbgNoPhaseSplit);
 }
 
 // Two CUs per sequence that meet in the middle (den_tied_mitm.hip) instead of two pure recursions and a combining pass.
@@ -469,7 +469,7 @@ static bool mitm_wanted(const DenParams &p) {
 // Two sequences per workgroup, the pair's two recursions on two CUs (den_tied_pair.hip): batches the two-CU form of one
 // sequence does not cover.
 static bool pair_wanted(const DenParams &p, int num_cus) {
-  if (!p.tied_fs || p.big.in_begin || !p.deriv || !p.pair_norm || !p.pair_sync || !p.fwd.cells_pair) return false;
+  if (!p.tied_fs || p.big.in.rows || !p.deriv || !p.pair_norm || !p.pair_sync || !p.fwd.cells_pair) return false;
   if (debug_flag(kDbgNoPair) || !pair_fits(p.L, p.pair_extra_slots, p.T)) return false;
   if (debug_flag(kDbgForcePair)) return true;
   // Which of the two is faster depends on the graph (the two-sequence kernel shares the walk between its sequences and
@@ -479,7 +479,7 @@ static bool pair_wanted(const DenParams &p, int num_cus) {
 }
 
 int den_cus_used(const DenParams &p, int num_cus) {
-  if (p.big.in_begin) return num_cus;
+  if (p.big.in.rows) return num_cus;
   if (pair_wanted(p, num_cus)) return std::min(num_cus, 2 * ((p.S + 1) / 2));
   if (split_wanted(p) && 2 * p.S <= num_cus) return 2 * p.S;
   return p.S < num_cus ? p.S : num_cus;
@@ -487,7 +487,7 @@ int den_cus_used(const DenParams &p, int num_cus) {
 
 // accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
 int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
-  if (p.big.in_begin) return launch_den_big(p, accumulate, stream);  // graph beyond the on-chip layout
+  if (p.big.in.rows) return launch_den_big(p, accumulate, stream);  // graph beyond the on-chip layout
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
