@@ -11,7 +11,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(big_\w+|den_\w+)", r["Kernel_Name"])
+        m = re.search(r"(slab_\w+|big_\w+|den_\w+)", r["Kernel_Name"])
         k = m.group(1) if m else "other"
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1

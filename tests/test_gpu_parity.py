@@ -55,12 +55,13 @@ def test_ragged_small_shapes(oracle, H, deg, P, S, T):
     _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
 
 
-@pytest.mark.parametrize("force", ["force_streamed", "force_general"])
+@pytest.mark.parametrize("force", ["force_streamed", "force_streamed,slab_wide", "force_general"])
 @pytest.mark.parametrize("H,deg,P,S,T", [(1, 1, 1, 1, 2), (7, 3, 5, 1, 1), (130, 4, 77, 3, 9), (70, 3, 65, 65, 3)])
 def test_ragged_small_shapes_other_kernels(oracle, kernel_family, force, H, deg, P, S, T):
-    """The same odd sizes through the streamed kernels (sequence counts that are not a multiple of the 64
-    lanes included) and through the general on-chip kernel."""
-    kernel_family(force)
+    """The same odd sizes through the streamed kernels (sequence counts that are not a multiple of a slab's 16 or
+    32 sequences included) and through the general on-chip kernel."""
+    for key in force.split(","):
+        kernel_family(key)
     _check_full(oracle, synth.random_den_fst(H, deg, P, seed=H), S, T, l2=1e-4, leaky=0.05, paths=2)
 
 
@@ -124,11 +125,13 @@ def test_nearly_tied_graph_state_splitting(oracle):
     _check_full(oracle, synth.nearly_tied_den_fst(64, 4, 20, seed=6, fraction=0.3), 2, 9, l2=0.0, leaky=1e-5)
 
 
-def test_streamed_path_for_graphs_beyond_lds(oracle, kernel_family):
+@pytest.mark.parametrize("width", ["slab_narrow", "slab_wide"])
+def test_streamed_path_for_graphs_beyond_lds(oracle, kernel_family, width):
     """Graphs the on-chip layouts cannot hold (more than 16384 states here) take the streamed kernel
-    (alpha/beta in global memory); the same kernel forced onto small graphs, tied and general, must agree
-    with the oracle too, including Kaldi's accumulate form."""
+    (alpha/beta in global memory, slabs of 16 or 32 sequences); the same kernel forced onto small graphs, tied and
+    general, must agree with the oracle too, including Kaldi's accumulate form."""
     from torchain_amd import io
+    kernel_family(width)
     fst = synth.random_den_fst(20000, 3, 700, seed=31)
     g = io.DenominatorGraph(fst, fst.num_pdfs)
     assert g.stats()["tied"] == 2

@@ -56,7 +56,11 @@ def test_config3_and_config5_graphs_replay():
     check_graph(synth.config_den_fst("C5"), 1)
 
 
-def test_streamed_tables_replay(kernel_family):
+@pytest.mark.parametrize("width", ["slab_narrow", "slab_wide"])
+def test_streamed_tables_replay(kernel_family, width):
+    """The streamed path's lists (rows bundled four or two at a time for slabs of 16 / 32 sequences, entries in
+    chunks per bundle) replayed on the host against the definition."""
+    kernel_family(width)
     check_graph(synth.random_den_fst(20000, 3, 700, seed=31), 2)      # tied streamed tables
     kernel_family("force_streamed")
     check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 2)       # general streamed tables

@@ -99,31 +99,31 @@ struct ScheduleDev {
 };
 
 // ---- graphs too large for the on-chip layout ("streamed" path, den_slab_kernel.hip) ------------------
-// alpha / beta live in HBM/L2 as [slab of 16 sequences][state][16] matrices (lanes run over sequences, one row of
-// a list per 16-lane group of a wave).  A LIST is a set of rows (states, or pdfs) with their entries: by destination
+// alpha / beta live in HBM/L2 as [slab of G sequences][state][G] matrices, G = 16 or 32 per graph (lanes run over
+// sequences, one row of a list per group of G lanes of a wave).  A LIST is a set of rows (states, or pdfs) with their entries: by destination
 // (forward), by source (backward beta'), and -- general graphs only -- by pdf (gamma: one group per pdf sums its
-// arcs, so the derivative needs no float atomics).  Rows are taken four at a time ("bundle"), sorted by length.
-constexpr int kSlab = 16;
-constexpr int kSlabBundlesPerBlock = 16;  // 64 rows per block of 256 threads
+// arcs, so the derivative needs no float atomics).  Rows are taken 64 / G at a time ("bundle"), sorted by length.
+constexpr int kSlabRowsPerBlock = 64;  // rows of a list per block of 256 threads: G bundles
 struct SlabRow {       // 32 bytes: two 16-byte loads per lane
   int32_t row;         // state (arc lists) or pdf (by-pdf list); -1: this group of the bundle has no row
   int32_t n;           // entries of this row
-  int32_t f_off, s_off;  // tied graphs: 64 * the state's forward / special self-loop pdf, -1: none
+  int32_t f_off, s_off;  // tied graphs: 4 G * the state's forward / special self-loop pdf (byte offset of its row), -1: none
   float ws, pi;        // tied graphs: self-loop probability; every state list: initial probability
   float K;             // tied graphs, by destination: sum over the in-arcs of w * pi(src)
   float pad;
 };
-// entries: W dwords per step (tied arc lists {64 * other state, w}: W = 2; general lists {64 * a, 64 * b, w, pi}:
+// entries: W dwords per step (tied arc lists {4 G * other state, w}: W = 2; general lists {4 G * a, 4 G * b, w, pi}:
 // W = 4; by destination {src, pdf, w, pi(src)}, by source {dst, pdf, w, 1}, by pdf {src, dst, w, pi(src)}), a bundle's
-// steps in chunks of 16 / W: dword c of step i of row q at [chunk][16 q + W i + c].  Steps past a row's end: zeros.
+// steps in chunks of 16 / W: dword c of step i of row q at [chunk][16 q + W i + c], 64 / G rows per chunk.  Steps past
+// a row's end: zeros.
 struct SlabListDev {
-  const SlabRow *rows = nullptr;   // [bundles][4]
+  const SlabRow *rows = nullptr;   // [bundles][64 / G]
   const int2 *head = nullptr;      // [bundles] {first chunk, steps}
-  const uint32_t *rec = nullptr;   // [chunks + 1][64]
+  const uint32_t *rec = nullptr;   // [chunks + 1][64 / G][16]
   int32_t bundles = 0;
 };
 struct SlabListHost {
-  int W = 2;
+  int W = 2, G = 16;
   std::vector<SlabRow> rows;
   std::vector<int32_t> head;       // 2 per bundle
   std::vector<uint32_t> rec;
@@ -132,11 +132,12 @@ struct SlabListHost {
 
 struct BigDev {
   SlabListDev in, out, pdf;
+  int G = 16;            // sequences per slab
   // tied graphs (work-graph states): the arc lists hold the non-special arcs only and exp(y) is applied
   // per state, so an arc costs ONE row gather per pass; gamma comes from per-state quantities, added by the
   // backward kernel to fixed-point accumulators
   int tied = 0;
-  const int32_t *f_off = nullptr;  // tied: per state, 64 * forward pdf (-1: none)
+  const int32_t *f_off = nullptr;  // tied: per state, 4 G * forward pdf (-1: none)
 };
 
 struct DenGraphDev {
@@ -187,9 +188,9 @@ struct DenParams {
   int64_t big_exp_stride = 0;  // floats between consecutive frames of big_expy (0: one frame at a time)
   float *big_beta;      // [2][slab][H][16]
   float *big_y;         // [slab][H][16]  tied graphs: Y = beta_{t+1} * p_t(f), the backward gather source
-  uint32_t *big_gam = nullptr;  // [slab][P][16]  tied graphs: the frame's gamma, unsigned fixed point (den_device.h: kGammaScale)
+  uint32_t *big_gam = nullptr;  // [slab][P][G]  tied graphs: the frame's gamma, unsigned fixed point (den_device.h: kGammaScale)
   float *big_small;     // per-sequence sums and per-block partials (den_slab_kernel.hip: BigSmall)
-  int big_Sp;           // sequences rounded up to a multiple of 16 (kSlab)
+  int big_Sp;           // sequences rounded up to a multiple of the slab width (big.G)
   float big_sum_pi;     // sum of the initial probabilities
   long long *stamps;    // diagnostic builds only (-DTC_PHASE_STAMPS): per-phase cycle totals, else unused
   // Two-CU form for small batches (den_tied_split.hip): the forward recursion writes its per-frame sums, the
@@ -238,6 +239,7 @@ struct tc_den_graph {
   // streamed path: chosen when neither on-chip layout fits (or TC_FORCE_BIG is set)
   bool big = false;
   tc::SlabListHost big_in, big_out, big_pdf;
+  int big_G = 16;  // sequences per slab: 32 when a slab's slice of the state matrix fits an XCD's L2 (den_graph.cpp)
   std::vector<int32_t> big_f_off;
   std::vector<int32_t> tied_f, tied_s;  // per work state: forward / special self-loop pdf, -1 if none
   float big_sum_pi = 0.f;
@@ -388,7 +390,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgSlabWide, kDbgSlabNarrow, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

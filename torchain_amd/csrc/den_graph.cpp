@@ -107,49 +107,50 @@ static uint32_t f2u(float f) {
 
 // entries[r]: row r's entries in list order; meta[r]: its SlabRow (n is filled in here); bundle_rows: four row
 // indices per bundle, -1 for none
-static void make_slab_list(int W, const std::vector<std::vector<SlabEntry>> &entries, const std::vector<SlabRow> &meta,
+static void make_slab_list(int W, int G, const std::vector<std::vector<SlabEntry>> &entries, const std::vector<SlabRow> &meta,
                            const std::vector<int32_t> &bundle_rows, SlabListHost *out) {
-  const int spc = 16 / W;
+  const int spc = 16 / W, NG = 64 / G, CH = NG * 16;
   out->W = W;
-  out->bundles = (int32_t)(bundle_rows.size() / 4);
+  out->G = G;
+  out->bundles = (int32_t)(bundle_rows.size() / NG);
   out->rows.assign(bundle_rows.size(), SlabRow{-1, 0, -1, -1, 0.f, 0.f, 0.f, 0.f});
   out->head.assign((size_t)out->bundles * 2, 0);
   out->rec.clear();
   size_t chunk = 0;
   for (int32_t b = 0; b < out->bundles; ++b) {
     int steps = 0;
-    for (int q = 0; q < 4; ++q)
-      if (bundle_rows[(size_t)b * 4 + q] >= 0) steps = std::max(steps, (int)entries[bundle_rows[(size_t)b * 4 + q]].size());
+    for (int q = 0; q < NG; ++q)
+      if (bundle_rows[(size_t)b * NG + q] >= 0) steps = std::max(steps, (int)entries[bundle_rows[(size_t)b * NG + q]].size());
     const int chunks = (steps + spc - 1) / spc;
     out->head[(size_t)b * 2] = (int32_t)chunk;
     out->head[(size_t)b * 2 + 1] = steps;
-    out->rec.resize((chunk + chunks) * 64, 0u);
-    for (int q = 0; q < 4; ++q) {
-      const int32_t r = bundle_rows[(size_t)b * 4 + q];
+    out->rec.resize((chunk + chunks) * CH, 0u);
+    for (int q = 0; q < NG; ++q) {
+      const int32_t r = bundle_rows[(size_t)b * NG + q];
       if (r < 0) continue;
       SlabRow m = meta[r];
       m.n = (int32_t)entries[r].size();
-      out->rows[(size_t)b * 4 + q] = m;
+      out->rows[(size_t)b * NG + q] = m;
       for (int i = 0; i < m.n; ++i)
         for (int c = 0; c < W; ++c)
-          out->rec[(chunk + i / spc) * 64 + q * 16 + (i % spc) * W + c] = entries[r][i].d[c];
+          out->rec[(chunk + i / spc) * CH + q * 16 + (i % spc) * W + c] = entries[r][i].d[c];
     }
     chunk += chunks;
   }
-  out->rec.resize((chunk + 1) * 64, 0u);  // a spare chunk: the walk requests one chunk ahead
+  out->rec.resize((chunk + 1) * CH, 0u);  // a spare chunk: the walk requests one chunk ahead
 }
 
-// rows sorted by length (longest first, stable), four at a time
-static std::vector<int32_t> bundles_by_length(const std::vector<std::vector<SlabEntry>> &entries) {
+// rows sorted by length (longest first, stable), 64 / G at a time
+static std::vector<int32_t> bundles_by_length(const std::vector<std::vector<SlabEntry>> &entries, int G) {
   std::vector<int32_t> order(entries.size());
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return entries[a].size() > entries[b].size(); });
-  while (order.size() % 4) order.push_back(-1);
-  if (order.empty()) order.assign(4, -1);
+  while (order.size() % (64 / G)) order.push_back(-1);
+  if (order.empty()) order.assign(64 / G, -1);
   return order;
 }
 
-// by-pdf list: a block of the gamma kernel is a tile of 64 consecutive pdfs; its 16 bundles are sorted inside the tile
+// by-pdf list: a block of the gamma kernel is a tile of 64 consecutive pdfs; its bundles are sorted inside the tile
 static std::vector<int32_t> bundles_by_tile(const std::vector<std::vector<SlabEntry>> &entries, int P) {
   std::vector<int32_t> out;
   for (int p0 = 0; p0 < P; p0 += 64) {
@@ -165,11 +166,12 @@ static std::vector<int32_t> bundles_by_tile(const std::vector<std::vector<SlabEn
 }
 
 static void build_big(tc_den_graph *g) {
-  const int H = g->H, P = g->P;
+  const int H = g->H, P = g->P, G = g->big_G;
+  const uint32_t rb = 4u * G;  // bytes per row
   const int64_t A = g->A;
   std::vector<std::vector<SlabEntry>> in(H), outl(H), pdf(P);
   for (int64_t a = 0; a < A; ++a) {  // FST arc order kept
-    const uint32_t s = (uint32_t)g->arc_src[a] * 64u, d = (uint32_t)g->arc_dst[a] * 64u, pd = (uint32_t)g->arc_pdf[a] * 64u;
+    const uint32_t s = (uint32_t)g->arc_src[a] * rb, d = (uint32_t)g->arc_dst[a] * rb, pd = (uint32_t)g->arc_pdf[a] * rb;
     const uint32_t w = f2u(g->arc_prob[a]), pis = f2u(g->initial_probs[g->arc_src[a]]);
     in[g->arc_dst[a]].push_back(SlabEntry{{s, pd, w, pis}});
     outl[g->arc_src[a]].push_back(SlabEntry{{d, pd, w, f2u(1.0f)}});
@@ -178,9 +180,9 @@ static void build_big(tc_den_graph *g) {
   std::vector<SlabRow> ms(H), mp(P);
   for (int h = 0; h < H; ++h) ms[h] = SlabRow{h, 0, -1, -1, 0.f, g->initial_probs[h], 0.f, 0.f};
   for (int i = 0; i < P; ++i) mp[i] = SlabRow{i, 0, -1, -1, 0.f, 0.f, 0.f, 0.f};
-  make_slab_list(4, in, ms, bundles_by_length(in), &g->big_in);
-  make_slab_list(4, outl, ms, bundles_by_length(outl), &g->big_out);
-  make_slab_list(4, pdf, mp, bundles_by_tile(pdf, P), &g->big_pdf);
+  make_slab_list(4, G, in, ms, bundles_by_length(in, G), &g->big_in);
+  make_slab_list(4, G, outl, ms, bundles_by_length(outl, G), &g->big_out);
+  make_slab_list(4, G, pdf, mp, bundles_by_tile(pdf, P), &g->big_pdf);
   g->big_f_off.assign(1, -1);
   float sum_pi = 0.f;
   for (int h = 0; h < H; ++h) sum_pi += g->initial_probs[h];
@@ -190,27 +192,28 @@ static void build_big(tc_den_graph *g) {
 // Streamed path of a tied (work) graph: arc lists without the special self-loops, per-state pdfs and self-loop
 // probabilities in the rows (chain_internal.h: BigDev).
 static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
-  const int H = g->work_H;
+  const int H = g->work_H, G = g->big_G;
+  const uint32_t rb = 4u * G;  // bytes per row
   const int64_t A = (int64_t)g->work_src.size();
   std::vector<std::vector<SlabEntry>> in(H), outl(H);
   std::vector<float> K(H, 0.f);
   for (int64_t a = 0; a < A; ++a) {
     if (special[a]) continue;
     const int32_t s = g->work_src[a], d = g->work_dst[a];
-    in[d].push_back(SlabEntry{{(uint32_t)s * 64u, f2u(g->work_prob[a]), 0u, 0u}});
-    outl[s].push_back(SlabEntry{{(uint32_t)d * 64u, f2u(g->work_prob[a]), 0u, 0u}});
+    in[d].push_back(SlabEntry{{(uint32_t)s * rb, f2u(g->work_prob[a]), 0u, 0u}});
+    outl[s].push_back(SlabEntry{{(uint32_t)d * rb, f2u(g->work_prob[a]), 0u, 0u}});
     K[d] += g->work_prob[a] * g->work_pi[s];
   }
   std::vector<SlabRow> mi(H), mo(H);
   g->big_f_off.assign(H, -1);
   for (int h = 0; h < H; ++h) {
-    const int32_t f = g->tied_f[h] >= 0 ? g->tied_f[h] * 64 : -1, sl = g->tied_s[h] >= 0 ? g->tied_s[h] * 64 : -1;
+    const int32_t f = g->tied_f[h] >= 0 ? g->tied_f[h] * (int32_t)rb : -1, sl = g->tied_s[h] >= 0 ? g->tied_s[h] * (int32_t)rb : -1;
     mi[h] = SlabRow{h, 0, f, sl, g->tied_w[h], g->work_pi[h], K[h], 0.f};
     mo[h] = SlabRow{h, 0, f, sl, g->tied_w[h], g->work_pi[h], 0.f, 0.f};
     g->big_f_off[h] = f;
   }
-  make_slab_list(2, in, mi, bundles_by_length(in), &g->big_in);
-  make_slab_list(2, outl, mo, bundles_by_length(outl), &g->big_out);
+  make_slab_list(2, G, in, mi, bundles_by_length(in, G), &g->big_in);
+  make_slab_list(2, G, outl, mo, bundles_by_length(outl, G), &g->big_out);
   g->big_pdf = SlabListHost();
   float sum_pi = 0.f;
   for (int h = 0; h < H; ++h) sum_pi += g->work_pi[h];
@@ -298,8 +301,17 @@ int build_schedules(tc_den_graph *g) {
     g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
     if (g->layout_ok) return TC_OK;
   }
-  // the per-frame working set does not fit LDS: stream it
+  // the per-frame working set does not fit LDS: stream it.  Slabs of 16 or 32 sequences: measured on 10-arc-per-state
+  // graphs at 256 sequences (profiles/r04_ablations.txt), 32 wins from about 24000 states on (28000: 20.7 vs 22.7 ms,
+  // 40000: 28.4 vs 30.5) although its slice no longer fits L2 -- fewer, longer waves per frame and half the atomics;
+  // below that the kernels are short and the narrow slabs' larger grids win (8192 states: 8.7 vs 10.2 ms).
   g->big = true;
+  {
+    const int64_t states = g->tied ? g->work_H : g->H;
+    g->big_G = states >= 24000 ? 32 : 16;
+    if (debug_flag(kDbgSlabWide)) g->big_G = 32;
+    if (debug_flag(kDbgSlabNarrow)) g->big_G = 16;
+  }
   g->layout_ok = false;
   g->fwd = ScheduleHost();
   g->bwd = ScheduleHost();
@@ -319,7 +331,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "reg_rows"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "reg_rows", "slab_wide", "slab_narrow"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -584,13 +596,13 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   const int H = g->H;
   // streamed path: the lists are replayed the way the kernels read them (bundle, group of 16 lanes, chunk, step)
   auto slab_sums = [&](const SlabListHost &L, auto term, std::vector<float> *sums) {
-    const int spc = 16 / L.W;
+    const int spc = 16 / L.W, NG = 64 / L.G, CH = NG * 16;
     for (int32_t b = 0; b < L.bundles; ++b)
-      for (int q = 0; q < 4; ++q) {
-        const SlabRow &r = L.rows[(size_t)b * 4 + q];
+      for (int q = 0; q < NG; ++q) {
+        const SlabRow &r = L.rows[(size_t)b * NG + q];
         if (r.row < 0) continue;
         float sum = 0.f;
-        for (int i = 0; i < r.n; ++i) sum += term(&L.rec[((size_t)L.head[(size_t)b * 2] + i / spc) * 64 + q * 16 + (i % spc) * L.W]);
+        for (int i = 0; i < r.n; ++i) sum += term(&L.rec[((size_t)L.head[(size_t)b * 2] + i / spc) * CH + q * 16 + (i % spc) * L.W]);
         (*sums)[r.row] = sum;
       }
   };
@@ -607,7 +619,7 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
     for (int h = 0; h < H; ++h)
       for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c)
         val[c] = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f) : gather[h] * pf(g->tied_f[c]);
-    slab_sums(L, [&](const uint32_t *e) { return u2f(e[1]) * val[e[0] / 64]; }, &sums);
+    slab_sums(L, [&](const uint32_t *e) { return u2f(e[1]) * val[e[0] / (4 * L.G)]; }, &sums);
     for (int h = 0; h < H; ++h) {
       float total = 0.f;
       for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
@@ -627,7 +639,7 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   if (g->big) {
     std::vector<float> sums(H, 0.f);
     slab_sums(direction == 0 ? g->big_in : g->big_out,
-              [&](const uint32_t *e) { return u2f(e[2]) * gather[e[0] / 64] * pdf_factor[e[1] / 64]; }, &sums);
+              [&](const uint32_t *e) { return u2f(e[2]) * gather[e[0] / (4 * g->big_G)] * pdf_factor[e[1] / (4 * g->big_G)]; }, &sums);
     for (int h = 0; h < H; ++h) out[h] = sums[h];
     return TC_OK;
   }
@@ -801,6 +813,7 @@ static int upload_den_graph(tc_den_graph *g, int device) {
     }
     d.pi = (const float *)(blob + parts[9].off);
     d.big.tied = tb ? 1 : 0;
+    d.big.G = g->big_G;
     d.big.f_off = (const int32_t *)(blob + parts[10].off);
     g->dev[device] = d;
     return TC_OK;
