@@ -119,7 +119,7 @@ struct SlabRow {       // 32 bytes: two 16-byte loads per lane
 struct SlabListDev {
   const SlabRow *rows = nullptr;   // [bundles][64 / G]
   const int2 *head = nullptr;      // [bundles] {first chunk, steps}
-  const uint32_t *rec = nullptr;   // [chunks + 1][64 / G][16]
+  const uint32_t *rec = nullptr;   // [chunks + 3][64 / G][16]
   int32_t bundles = 0;
 };
 struct SlabListHost {

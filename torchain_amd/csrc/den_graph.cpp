@@ -137,7 +137,7 @@ static void make_slab_list(int W, int G, const std::vector<std::vector<SlabEntry
     }
     chunk += chunks;
   }
-  out->rec.resize((chunk + 1) * CH, 0u);  // a spare chunk: the walk requests one chunk ahead
+  out->rec.resize((chunk + 3) * CH, 0u);  // spare chunks: the walk requests a pair of chunks ahead
 }
 
 // rows sorted by length (longest first, stable), 64 / G at a time
@@ -775,13 +775,13 @@ static int upload_den_graph(tc_den_graph *g, int device) {
     const SlabListHost *lists[3] = {&g->big_in, &g->big_out, &g->big_pdf};
     const std::vector<SlabRow> no_rows(4, SlabRow{-1, 0, -1, -1, 0.f, 0.f, 0.f, 0.f});
     const std::vector<int32_t> no_head(2, 0);
-    const std::vector<uint32_t> no_rec(64, 0u);
+    const std::vector<uint32_t> no_rec(256, 0u);
     Part parts[11];
     for (int l = 0; l < 3; ++l) {
       const bool have = lists[l]->bundles > 0;
       parts[3 * l] = Part{have ? (const void *)lists[l]->rows.data() : no_rows.data(), (have ? lists[l]->rows.size() : 4) * sizeof(SlabRow), 0};
       parts[3 * l + 1] = Part{have ? (const void *)lists[l]->head.data() : no_head.data(), (have ? lists[l]->head.size() : 2) * 4, 0};
-      parts[3 * l + 2] = Part{have ? (const void *)lists[l]->rec.data() : no_rec.data(), (have ? lists[l]->rec.size() : 64) * 4, 0};
+      parts[3 * l + 2] = Part{have ? (const void *)lists[l]->rec.data() : no_rec.data(), (have ? lists[l]->rec.size() : 256) * 4, 0};
     }
     parts[9] = Part{pi_pad.data(), pi_pad.size() * 4, 0};
     parts[10] = Part{g->big_f_off.data(), g->big_f_off.size() * 4, 0};

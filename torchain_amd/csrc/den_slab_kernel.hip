@@ -133,33 +133,44 @@ struct Lane {
   __device__ __forceinline__ explicit Lane(uint32_t l) : lane(l), q(l / G), j(l % G), j4((l % G) * 4) {}
 };
 
-// Walks bundle `b` of list L: body.run<N>(rec) consumes steps 0..N-1 of a chunk (W dwords per step, 16 / W steps
-// per chunk; a chunk is 16 dwords per row of the bundle).  The next chunk's records are requested before the
-// current one is consumed (the list ends with a spare chunk).  (Non-temporal loads of the records were measured:
-// 31.0 -> 37.2 ms on the 40000-state graph.)
+// Walks bundle `b` of list L: body.run<N>(rec0, rec1) consumes steps 0..N-1 of a PAIR of chunks (W dwords per step,
+// 16 / W steps per chunk; a chunk is 16 dwords per row of the bundle), all N gathers requested before the first
+// product -- a list of ten entries is one round trip, not a chunk of eight and a tail of two.  The records of the
+// next pair are requested before the current one is consumed (the list ends with two spare chunks).
+// (Non-temporal loads of the records were measured: 31.0 -> 37.2 ms on the 40000-state graph.)
+template <int SPC, int I, class Body>
+__device__ __forceinline__ void walk_tail(int n, uint32_t rec0, uint32_t rec1, Body &body) {
+  if constexpr (I < 2 * SPC) {
+    if (n == I)
+      body.template run<I>(rec0, rec1);
+    else
+      walk_tail<SPC, I + 1>(n, rec0, rec1, body);
+  }
+}
 template <int G, int W, class Body>
 __device__ __forceinline__ void walk(const SlabListDev &L, int b, const Lane<G> &ln, Body &body) {
   constexpr int SPC = 16 / W, CH = (64 / G) * 16;
   const int2 hd = L.head[b];
   int n = hd.y;
   const uint32_t *r = L.rec + (size_t)hd.x * CH + ln.q * 16 + (ln.lane & 15);
-  uint32_t rec = *r;
-  for (; n >= SPC; n -= SPC) {
-    r += CH;
-    const uint32_t nxt = *r;
-    body.template run<SPC>(rec);
-    rec = nxt;
+  uint32_t rec0 = r[0], rec1 = r[CH];
+  for (; n >= 2 * SPC; n -= 2 * SPC) {
+    r += 2 * CH;
+    const uint32_t nx0 = r[0], nx1 = r[CH];
+    body.template run<2 * SPC>(rec0, rec1);
+    rec0 = nx0;
+    rec1 = nx1;
   }
-  switch (n) {
-    case 1: body.template run<1>(rec); break;
-    case 2: body.template run<2>(rec); break;
-    case 3: body.template run<3>(rec); break;
-    case 4: if constexpr (SPC > 4) body.template run<4>(rec); break;
-    case 5: if constexpr (SPC > 4) body.template run<5>(rec); break;
-    case 6: if constexpr (SPC > 4) body.template run<6>(rec); break;
-    case 7: if constexpr (SPC > 4) body.template run<7>(rec); break;
-    default: break;
-  }
+  if (n > 0) walk_tail<SPC, 1>(n, rec0, rec1, body);
+}
+
+// record dword D of a step I of a pair of chunks (compile-time selection of the chunk's register)
+template <int SPC, int W, int I, int D>
+__device__ __forceinline__ uint32_t step_dword(uint32_t rec0, uint32_t rec1) {
+  if constexpr (I < SPC)
+    return rowb<W * I + D>(rec0);
+  else
+    return rowb<W * (I - SPC) + D>(rec1);
 }
 
 // sum += w * A[off]            entries {off, w}: tied graphs, both directions
@@ -168,15 +179,15 @@ struct GatherSum {
   uint32_t j4;
   float sum;
   template <int N>
-  __device__ __forceinline__ void run(uint32_t rec) {
+  __device__ __forceinline__ void run(uint32_t rec0, uint32_t rec1) {
     float g[N];
     static_for<0, N>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      g[i] = ld(A, rowb<2 * i>(rec) + j4);
+      g[i] = ld(A, step_dword<8, 2, i, 0>(rec0, rec1) + j4);
     });
     static_for<0, N>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      sum += rowbf<2 * i + 1>(rec) * g[i];
+      sum += __uint_as_float(step_dword<8, 2, i, 1>(rec0, rec1)) * g[i];
     });
   }
 };
@@ -187,16 +198,17 @@ struct GatherSum2 {
   uint32_t j4;
   float ca, cb, sum;
   template <int N>
-  __device__ __forceinline__ void run(uint32_t rec) {
+  __device__ __forceinline__ void run(uint32_t rec0, uint32_t rec1) {
     float ga[N], gb[N];
     static_for<0, N>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      ga[i] = ld(A, rowb<4 * i>(rec) + j4);
-      gb[i] = ld(B, rowb<4 * i + 1>(rec) + j4);
+      ga[i] = ld(A, step_dword<4, 4, i, 0>(rec0, rec1) + j4);
+      gb[i] = ld(B, step_dword<4, 4, i, 1>(rec0, rec1) + j4);
     });
     static_for<0, N>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      sum += rowbf<4 * i + 2>(rec) * (ga[i] + ca * rowbf<4 * i + 3>(rec)) * (gb[i] + cb);
+      sum += __uint_as_float(step_dword<4, 4, i, 2>(rec0, rec1)) *
+             (ga[i] + ca * __uint_as_float(step_dword<4, 4, i, 3>(rec0, rec1))) * (gb[i] + cb);
     });
   }
 };
