@@ -207,7 +207,8 @@ int tc_supervision_stage(tc_supervision *supervision, int device);
  *   on-chip graphs          4 (T + 1) S Hs                     the alpha history  (1.27 GB at 256 x 150 x 8192)
  *     tied, Hs <= 8192      + 4 S Hs + ~80 (T + 2) S bytes      one more row, the two-sequence form's normalisers
  *     tied, S <= 128        + 4 (T + 1) S Hs                    the second history of the two-CU form
- *   graphs beyond LDS       4 (T + 1) S' H + 8 S' H + 4 S' P    S' = S rounded up to 64 (streamed path)
+ *   graphs beyond LDS       4 (T + 1) S' H + 12 S' H + 8 S' P   S' = S rounded up to whole slabs of 16 sequences (32 from
+ *                                                              24000 states on): the streamed path's [slab][state][G] matrices
  *                           + 4 T S' P if that is <= 1 GB       exp(y) of every frame, transposed once (else per frame)
  * plus a few KB of per-sequence scalars. */
 int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);
@@ -348,6 +349,7 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "force_general"  (1: never use the tied-graph kernel)      "force_streamed" (1: alpha/beta in HBM, as for graphs
  *   "no_split"       (1: do not tied-ify nearly tied graphs)                     beyond the on-chip layouts)
  *   "no_pdf_banks", "no_bank_search" (1: skip those placement passes)   "sched_trace" (1: builder statistics on stderr)
+ *   "slab_wide" / "slab_narrow" (1: the streamed path cuts the batch into slabs of 32 / 16 sequences whatever the graph's size)
  * Read at launch (one relaxed atomic load):
  *   "no_phase_split" (1: batches of at most 128 sequences of tied on-chip graphs take the fused kernel instead of
  *                     running forward and backward recursion on two CUs at once)
