@@ -21,6 +21,20 @@ int main(int argc, char **argv) {
     if (rc == 0) { ++ok; tc_den_graph_free(h); } else ++bad;
   };
   run(data);
+  // the accepted variants also through the streamed path's list builder, both slab widths, tied and general
+  const char *modes[][3] = {{"force_streamed", "slab_narrow", nullptr}, {"force_streamed", "slab_wide", nullptr},
+                            {"force_streamed", "force_general", "slab_wide"}};
+  for (auto &m : modes) {
+    for (const char *k : m) if (k) tc_debug_set(k, 1);
+    srand(7);
+    for (int i = 0; i < 300; ++i) {
+      std::vector<unsigned char> v = data;
+      const size_t pos = (size_t)rand() % v.size();
+      v[pos] ^= (unsigned char)(1 + rand() % 255);
+      run(v);
+    }
+    for (const char *k : m) if (k) tc_debug_set(k, 0);
+  }
   for (size_t n = 0; n < data.size(); n += (data.size() > 3000 ? 53 : 1)) run(std::vector<unsigned char>(data.begin(), data.begin() + n));
   srand(2);
   for (int i = 0; i < 1500; ++i) {

@@ -44,6 +44,44 @@ int main(int argc, char **argv) {
     }
     run(a, l, n, ww, ff, s, t, p);
   }
-  printf("ok %d refused %d\n", ok, bad);
+  printf("create: ok %d refused %d\n", ok, bad);
+  // tc_supervision_append: the valid acceptor twice (its own frame count per piece), corrupted the same way -- chains
+  // with dead ends, cycles, arcs out of range, non-final last states; output arrays of exactly the documented capacity
+  ok = bad = 0;
+  const int frames = S * T;
+  for (int i = 0; i < 4000; ++i) {
+    std::vector<int32_t> a = ab, l = il, n = nx;
+    std::vector<float> ww = w, ff = fin;
+    const int what = rand() % 5, k = 1 + rand() % 3;
+    if (i > 0)
+      for (int j = 0; j < k; ++j) switch (what) {
+        case 0: n[rand() % n.size()] = (rand() % (ns + 6)) - 3; break;
+        case 1: ff[rand() % ff.size()] = (rand() % 2) ? 0.f : __builtin_inff(); break;
+        case 2: { const int x = rand() % n.size(), y = rand() % n.size(); std::swap(n[x], n[y]); } break;
+        case 3: { const size_t ix = rand() % a.size(); a[ix] += (rand() % 7) - 3; if (ix + 1 == a.size() && a[ix] > na) a[ix] = na; } break;
+        case 4: n[rand() % n.size()] = rand() % ns; break;  // stays in range: dead ends and short cuts
+      }
+    const int32_t pns[2] = {ns, ns}, pnf[2] = {frames + (what == 3 ? 0 : 0), frames};
+    std::vector<int32_t> A, L, N;
+    std::vector<float> W, F;
+    for (int piece = 0; piece < 2; ++piece) {
+      const std::vector<int32_t> &pa = piece ? ab : a, &pl = piece ? il : l, &pn = piece ? nx : n;
+      const std::vector<float> &pw = piece ? w : ww, &pf = piece ? fin : ff;
+      A.insert(A.end(), pa.begin(), pa.end());
+      L.insert(L.end(), pl.begin(), pl.end());
+      N.insert(N.end(), pn.begin(), pn.end());
+      W.insert(W.end(), pw.begin(), pw.end());
+      F.insert(F.end(), pf.begin(), pf.end());
+    }
+    const int64_t cap_states = 2 * (int64_t)ns, cap_arcs = 2 * (int64_t)na + (int64_t)ns * na;
+    std::vector<int32_t> ob(cap_states + 1), ol(cap_arcs), on(cap_arcs);
+    std::vector<float> ow(cap_arcs), of(cap_states);
+    int32_t out_ns = 0;
+    int64_t out_na = 0;
+    const int rc = tc_supervision_append(2, pns, pnf, A.data(), L.data(), W.data(), N.data(), F.data(), cap_states, cap_arcs,
+                                         &out_ns, &out_na, ob.data(), ol.data(), ow.data(), on.data(), of.data());
+    if (rc == 0) ++ok; else ++bad;
+  }
+  printf("append: ok %d refused %d\n", ok, bad);
   return 0;
 }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Development aid (CPU): tc_supervision_create (csrc/supervision.cpp) under AddressSanitizer and UBSan over 4000 corrupted
+# Development aid (CPU): tc_supervision_create and tc_supervision_append (csrc/supervision.cpp, supervision_merge.cpp) under
+# AddressSanitizer and UBSan over 4000 corrupted
 # copies of a valid merged supervision (offsets, labels, next states, weights, final weights, S and T off by a few).
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
