@@ -46,11 +46,14 @@ def _case(oracle, rng, big_mode):
     # earlier rounds keep their inputs
     pair = seed % 3 == 0 and not force
     mitm = seed % 3 == 1 and not force  # ... and another third the two-CU form that meets in the middle (from 2 frames on)
+    wide = seed % 2 == 1                # the streamed path (forced, or taken by the large graphs): slabs of 32 / 16 sequences
     for key in ("force_streamed", "force_general"):
         lib.tc_debug_set(key.encode(), 1 if key == force else 0)
     lib.tc_debug_set(b"no_phase_split", 1 if fused else 0)
     lib.tc_debug_set(b"force_pair", 1 if pair else 0)
     lib.tc_debug_set(b"force_mitm", 1 if mitm else 0)
+    lib.tc_debug_set(b"slab_wide", 1 if wide else 0)
+    lib.tc_debug_set(b"slab_narrow", 0 if wide else 1)
     try:
         g = oracle.DenGraph(fst)
         sup = synth.random_supervision(fst, S, T, 2, seed=seed + 1, initial_probs=g.initial_probs())
@@ -59,7 +62,7 @@ def _case(oracle, rng, big_mode):
         out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True)
         kern = io.DenominatorGraph(fst, fst.num_pdfs).stats()["tied"]
     finally:
-        for key in ("force_streamed", "force_general", "no_phase_split", "force_pair", "force_mitm"):
+        for key in ("force_streamed", "force_general", "no_phase_split", "force_pair", "force_mitm", "slab_wide", "slab_narrow"):
             lib.tc_debug_set(key.encode(), 0)
     res = out["results"]
     # objf = num - den is a difference of two log-probs of size ~S*T: when the numerator covers the whole
