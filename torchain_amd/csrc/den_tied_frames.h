@@ -378,6 +378,14 @@ struct TiedSeq {
     return tot;
   }
 
+  // B_{t}, the owned states' values after pure frame t, to its history row (the last pure frame has no walk behind it)
+  __device__ __forceinline__ void backward_store_row(int t) {
+    const rsrc_t brow = make_rsrc(bhist + (int64_t)t * hist_step, 4u * Hs);
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (j < planes) bst4(brow, own16 + j * kPlane, bown[j]);
+  }
+
   // ================================================================================================== backward
   // ---- [K] BetaDashLastFrame, Beta(T): beta'_T(h) = b_T on the real states (1 / tot: Kaldi's scale; 1: a pure recursion
   // with normalisers of its own), beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h).  The LDS regions now hold Y
@@ -486,13 +494,23 @@ struct TiedSeq {
     age_prio_on(wave);
     bool dstored = false;
     const RowCommit brc{aACC + 256u * (uint32_t)(K * wave), bsec, K};
+    // (PURE: the history row of B_{t+1}, still in this thread's registers, leaves the same way; row T went out in
+    // backward_begin, the last pure frame's row goes out in backward_store_row)
     walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
-      if (!PURE && kDeferDeriv && t < t_top - 1 && !dstored && (RESB > 0 ? i == bstore_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
+      if ((PURE ? t < T - 1 : kDeferDeriv && t < t_top - 1) && !dstored &&
+          (RESB > 0 ? i == bstore_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
         dstored = true;
-        const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)(t + 1) * S + s) * p.deriv_stride, row_bytes);
+        if (PURE) {
+          const rsrc_t brow_up = make_rsrc(bhist + (int64_t)(t + 1) * hist_step, 4u * Hs);
 #pragma unroll
-        for (int v = 0; v < PV; ++v)
-          if (4 * ((int)tid + kThreads * v) < Ps) row_st(drow, own16 + v * kPlane, p.d_vec, lds4(pb_next + own16 + v * kPlane));
+          for (int j = 0; j < JV; ++j)
+            if (j < planes) bst4(brow_up, own16 + j * kPlane, bown[j]);
+        } else {
+          const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)(t + 1) * S + s) * p.deriv_stride, row_bytes);
+#pragma unroll
+          for (int v = 0; v < PV; ++v)
+            if (4 * ((int)tid + kThreads * v) < Ps) row_st(drow, own16 + v * kPlane, p.d_vec, lds4(pb_next + own16 + v * kPlane));
+        }
       }
     } TC_WALK_PASS);
     __builtin_amdgcn_s_setprio(0);
@@ -625,7 +643,6 @@ struct TiedSeq {
       __syncthreads();
     }
     // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
-    const rsrc_t brow = make_rsrc(bhist + (int64_t)t * hist_step, PURE ? 4u * Hs : 0u);  // (gamma frames: stores vanish)
 #pragma unroll
     for (int j = 0; j < JV; ++j)
       if (j < planes) {
@@ -637,7 +654,6 @@ struct TiedSeq {
           lds4_st_at(own16, kA0 + j * kPlane, yv);
         else
           lds4_st(kA0 + own16 + j * kPlane, yv);
-        if (PURE) bst4(brow, own16 + j * kPlane, b);  // B_t for the partner (rows M..T-1)
         if (!PURE && ALPHA_LDS) lds4_st(aAL + own16 + j * kPlane, areg[j]);
       }
 #pragma unroll

@@ -112,6 +112,7 @@ __device__ __forceinline__ void mitm_backward(const DenParams &p, const MitmPara
   q.template backward_begin<true>(1.0f);
   // ---- first phase: frames T-1..M, rows B_T..B_M stored
   for (int t = T - 1; t >= M; --t) q.template backward_frame<true>(t, 0);
+  if (M < T) q.backward_store_row(M);  // (rows T-1..M+1 left under the walks; row T in backward_begin)
   publish(mq.sync + 4 + 2 * s + 1, q.tid);
   const bool partner_ok = await(mq.sync + 4 + 2 * s, q.tid, mq.aScr + 4u);
   {
