@@ -16,7 +16,7 @@
 //                               fused kernel's per-state formulas -- every frame independent, all CUs busy.
 // c_t is formed in double from the logs of the stored normalisers (no invariant is assumed: the two checks of
 // [K] BetaGeneralFrameDebug(0) still measure how well the two recursions agree).
-#include "den_tied_device.h"
+#include "den_tied_frames.h"
 
 namespace tc {
 
@@ -43,163 +43,21 @@ __device__ __forceinline__ void block_sum2_a(float &v1, float &v2, uint32_t red,
 }
 
 // ---- the backward recursion alone -------------------------------------------------------------------
-// LDS: [exp(y) buffer | gather source A0 | row sums ACC | second exp(y) buffer | red] -- the fused kernel's regions
-// without gamma and alpha'_{t+1}, so graphs that get the fused kernel's tight layout fit here with both exp(y)
-// buffers (split_bwd_layout below).
+// den_tied_frames.h's pure backward frame (normalisers of its own, no gamma) over all T frames.  LDS: [exp(y) buffer |
+// gather source A0 | row sums ACC | second exp(y) buffer | red] -- the fused kernel's regions without gamma and
+// alpha'_{t+1} (the second exp(y) buffer sits where the fused layout has gamma), so graphs that get the fused kernel's
+// tight layout fit here with both exp(y) buffers (split_bwd_layout below).
 template <int JV, int PV, int RESB>
 __global__ __launch_bounds__(kThreads) void den_tied_bwd_kernel(const DenParams p) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x;
-  const int H = p.H, P = p.P, S = p.S, T = p.T;
-  const int Hs = p.L.Hs, Ps = p.L.Ps;
-  const int planes = Hs / (4 * kThreads);
-  const int K = Hs / kThreads;
-  const uint32_t own16 = 16u * tid, lane16 = 16u * lane;
-  constexpr uint32_t kPB = 0u;
-  constexpr uint32_t kA0 = PV * 16u * kThreads;
-  const uint32_t aACC = 4u * (uint32_t)p.L.off_acc;
-  const uint32_t vrow = aACC + 256u * (uint32_t)(K * wave) + 4u * lane;
-  const uint32_t aRed = 4u * (uint32_t)p.L.off_red;
-  const uint32_t tab_bytes = 4u * (uint32_t)(Hs + 4), row_bytes = 4u * (uint32_t)P;
-  const rsrc_t r_pi = make_rsrc(p.pi, tab_bytes), r_fs = make_rsrc(p.tied_fs, tab_bytes), r_ws = make_rsrc(p.tied_w, tab_bytes);
-  const float leaky = p.leaky;
-  const int64_t hist_step = (int64_t)S * Hs;
-  float *const bhist = p.beta_hist + (int64_t)s * Hs;  // row t lives at bhist + t * hist_step
-  float *const norm = p.bwd_norm + (int64_t)s * (T + 1);
-  const float inv_h = 1.0f / (float)H;
-
-  uint32_t pb_cur = kPB, pb_next = 4u * (uint32_t)p.L.off_p2;
-  const int2 brange = p.bwd.wave_range[wave];
-  const int bnch = __builtin_amdgcn_readfirstlane(brange.y) / kChunk;
-  const rsrc_t bbase = make_rsrc(reinterpret_cast<const char *>(p.bwd.cells) +
-                                     (int64_t)(__builtin_amdgcn_readfirstlane(brange.x) / kChunk) * (3 * 64 * 16),
-                                 (uint32_t)(bnch + 2) * (3 * 64 * 16));
-  const uint32_t bmask = wave_masks(p.bwd, wave, lane);
-  const int bfx0 = p.bwd.nfix ? p.bwd.fix_begin[tid] : 0, bfx1 = p.bwd.nfix ? p.bwd.fix_begin[tid + 1] : 0;
-  const RowCommit brc{aACC + 256u * (uint32_t)(K * wave), aACC + 256u * (uint32_t)(K * kWaves + p.bwd.extra_first[wave]), K};
-  Chunk6 bres[RESB > 0 ? RESB : 1];
-#pragma unroll
-  for (int i = 0; i < RESB; ++i) load_chunk(bres[i], bbase, lane16, i);
-
-  // B'_T = 1 on the real states, B_T = B'_T + leaky * sum(pi)
-  float part = 0.f;
+  TiedSeq<JV, PV, true, false, 0, RESB, true> q(p, (int)blockIdx.x, 0);
+  const int T = q.T;
+  q.template backward_begin<true>(1.0f);  // B'_T = 1 on the real states, B_T = B'_T + leaky * sum(pi): row T
+  for (int t = T - 1; t >= 0; --t) q.template backward_frame<true>(t, 0);  // rows T-1..1 leave under the walks
+  // row 0 holds B'_0 = B_0 - leaky sum (the alpha'.beta' check of [K] BetaGeneralFrameDebug(0) needs it; gamma_0 needs B_1)
+  const rsrc_t hist_0 = make_rsrc(q.bhist, 4u * q.Hs);
 #pragma unroll
   for (int j = 0; j < JV; ++j)
-    if (j < planes) part += hsum(leaky * bld4(r_pi, own16, j * kPlane));
-  float bsum = block_sum_a(part, aRed + 8u * kWaves, wave, lane);
-  f4 bown[JV];
-  f4 ynext[PV];
-  {
-    const rsrc_t hist_T = make_rsrc(bhist + (int64_t)T * hist_step, 4u * Hs);
-    const rsrc_t yrow = make_rsrc(p.y + ((int64_t)(T - 1) * S + s) * p.y_stride, row_bytes);
-#pragma unroll
-    for (int j = 0; j < JV; ++j) {
-      bown[j] = mk4(0.f);
-      if (j < planes) {
-        const int h0 = 4 * ((int)tid + kThreads * j);
-        const float b = 1.0f + bsum;
-        bown[j] = f4{h0 < H ? b : 0.f, h0 + 1 < H ? b : 0.f, h0 + 2 < H ? b : 0.f, h0 + 3 < H ? b : 0.f};
-        bst4(hist_T, own16 + j * kPlane, bown[j]);
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < PV; ++v) {
-      const int i0 = 4 * ((int)tid + kThreads * v);
-      if (i0 < Ps) lds4_st(pb_cur + 4u * i0, exp4(row_ld(yrow, own16 + v * kPlane, p.y_vec)));
-    }
-    __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = B_T(g) * p_{T-1}(f(g))
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (j < planes) {
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        lds4_st(kA0 + own16 + j * kPlane,
-                f4{bown[j].x * ldsf(pb_cur + (fs.x & 0xffffu)), bown[j].y * ldsf(pb_cur + (fs.y & 0xffffu)),
-                   bown[j].z * ldsf(pb_cur + (fs.z & 0xffffu)), bown[j].w * ldsf(pb_cur + (fs.w & 0xffffu))});
-      }
-  }
-  const int store_slot = RESB >= 4 ? wave >> 2 : RESB >= 2 ? wave >> 3 : 0;
-#ifdef TC_PHASE_STAMPS
-  long long wst_unused[3] = {0, 0, 0}, *wst = wst_unused;  // (the walk's sub-stamps: kept by the fused kernel only)
-#endif
-  for (int t = T - 1; t >= 0; --t) {
-    Chunk6 q0;
-    load_chunk(q0, bbase, lane16, RESB);
-    __syncthreads();  // Y_t and exp(y_t) ready
-    {
-      const int tn = t > 0 ? t - 1 : 0;
-      const rsrc_t yrow = make_rsrc(p.y + ((int64_t)tn * S + s) * p.y_stride, row_bytes);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) ynext[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
-    }
-    age_prio_on(wave);
-    // (the history row of B_{t+1}, still in this thread's registers, leaves under the walk like the forward
-    // phase's alpha' rows do: a CU takes a 1 KB store only every ~60 cycles)
-    bool stored = false;
-    walk<kA0, RESB>(bres, q0, bbase, lane16, bnch, bmask, brc, [&](int i) {
-      if (t < T - 1 && !stored && (RESB > 0 ? i == store_slot : (i == kWalkEnd || i == -1 - (wave >> 2)))) {
-        stored = true;
-        const rsrc_t hist_up = make_rsrc(bhist + (int64_t)(t + 1) * hist_step, 4u * Hs);
-#pragma unroll
-        for (int j = 0; j < JV; ++j)
-          if (j < planes) bst4(hist_up, own16 + j * kPlane, bown[j]);
-      }
-    } TC_WALK_PASS);
-    __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int v = 0; v < PV; ++v) {
-      const int i0 = 4 * ((int)tid + kThreads * v);
-      if (i0 < Ps) lds4_st(pb_next + 4u * i0, exp4(ynext[v]));
-    }
-    for (int e = bfx0; e < bfx1; ++e) fold_row(p.bwd.fix[e], vrow, aACC, Hs, K);  // (secondary rows: same wave, no barrier)
-    f4 u4v[JV];
-    uint32_t fpk[JV][2];
-    float part_n = 0.f, part_b = 0.f;
-#pragma unroll
-    for (int j = 0; j < JV; ++j) {
-      u4v[j] = mk4(0.f);
-      if (j < planes) {
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f4 ws = bld4(r_ws, own16, j * kPlane);
-        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
-        f4 a = own_rows(vrow, j);
-        a.x = fmaf(ldsf(pb_cur + (fs.x >> 16)) * ws.x, bown[j].x, a.x);
-        a.y = fmaf(ldsf(pb_cur + (fs.y >> 16)) * ws.y, bown[j].y, a.y);
-        a.z = fmaf(ldsf(pb_cur + (fs.z >> 16)) * ws.z, bown[j].z, a.z);
-        a.w = fmaf(ldsf(pb_cur + (fs.w >> 16)) * ws.w, bown[j].w, a.w);
-        u4v[j] = a;
-        fpk[j][0] = (fs.x & 0xffffu) | (fs.y << 16);
-        fpk[j][1] = (fs.z & 0xffffu) | (fs.w << 16);
-        part_n += hsum(a);
-        part_b += hsum(cp * a);
-      }
-    }
-    block_sum2_a(part_n, part_b, aRed, wave, lane);  // its barrier also ends every wave's gathers of Y_t
-    const float n_t = part_n * inv_h;
-    const float inv_n = __builtin_amdgcn_rcpf(n_t);
-    bsum = part_b * inv_n;
-    if (tid == 0) norm[t] = 1.0f / inv_n;  // the normaliser actually applied
-    if (t == 0) {
-      // row 0 holds B'_0 (the alpha'.beta' check of [K] BetaGeneralFrameDebug(0) needs it; gamma_0 needs B_1)
-      const rsrc_t hist_0 = make_rsrc(bhist, 4u * Hs);
-#pragma unroll
-      for (int j = 0; j < JV; ++j)
-        if (j < planes) bst4(hist_0, own16 + j * kPlane, u4v[j] * inv_n);
-      break;  // (row 1 left under this frame's walk, or is row T)
-    }
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (j < planes) {
-        const f4 b = u4v[j] * inv_n + bsum;
-        bown[j] = b;
-        lds4_st(kA0 + own16 + j * kPlane,
-                f4{b.x * ldsf(pb_next + (fpk[j][0] & 0xffffu)), b.y * ldsf(pb_next + (fpk[j][0] >> 16)),
-                   b.z * ldsf(pb_next + (fpk[j][1] & 0xffffu)), b.w * ldsf(pb_next + (fpk[j][1] >> 16))});
-      }
-    const uint32_t tmp = pb_cur;
-    pb_cur = pb_next;
-    pb_next = tmp;
-  }
+    if (j < q.planes) bst4(hist_0, q.own16 + j * kPlane, q.bown[j] - q.bsum);
 }
 
 // ---- gamma and the derivative from the two histories ----------------------------------------------------
