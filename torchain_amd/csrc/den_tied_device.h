@@ -399,4 +399,16 @@ constexpr uint32_t kPlane = 16u * kThreads;  // bytes between a thread's float4s
 
 }  // namespace
 
+// every <JV, PV> instantiation of the tied kernels: CALL(JV, PV) for the layout's pair (den_layout.cpp)
+#define TC_TIED_DISPATCH(CALL)                            \
+  if (JV == kJvSmall && PV == kPvSmall) return CALL(kJvSmall, kPvSmall); \
+  if (JV == kJvSmall && PV == kPvMid) return CALL(kJvSmall, kPvMid);     \
+  if (JV == kJvSmall && PV == kPvLarge) return CALL(kJvSmall, kPvLarge); \
+  if (JV == kJvMid && PV == kPvSmall) return CALL(kJvMid, kPvSmall);     \
+  if (JV == kJvMid && PV == kPvMid) return CALL(kJvMid, kPvMid);         \
+  if (JV == kJvMid && PV == kPvLarge) return CALL(kJvMid, kPvLarge);     \
+  if (JV == kJvLarge && PV == kPvSmall) return CALL(kJvLarge, kPvSmall); \
+  if (JV == kJvLarge && PV == kPvMid) return CALL(kJvLarge, kPvMid);     \
+  if (JV == kJvLarge && PV == kPvLarge) return CALL(kJvLarge, kPvLarge);
+
 }  // namespace tc

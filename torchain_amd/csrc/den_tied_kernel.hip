@@ -99,22 +99,13 @@ int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream) {
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
-#define TC_DISPATCH(J, V) \
-  if (JV == J && PV == V) return launch_jp<J, V>(p, accumulate, lds, stream);
+#define TC_CALL(J, V) launch_jp<J, V>(p, accumulate, lds, stream)
 #ifdef TC_ONLY_C3
-  TC_DISPATCH(kJvSmall, kPvSmall)
+  if (JV == kJvSmall && PV == kPvSmall) return TC_CALL(kJvSmall, kPvSmall);
 #else
-  TC_DISPATCH(kJvSmall, kPvSmall)
-  TC_DISPATCH(kJvSmall, kPvMid)
-  TC_DISPATCH(kJvSmall, kPvLarge)
-  TC_DISPATCH(kJvMid, kPvSmall)
-  TC_DISPATCH(kJvMid, kPvMid)
-  TC_DISPATCH(kJvMid, kPvLarge)
-  TC_DISPATCH(kJvLarge, kPvSmall)
-  TC_DISPATCH(kJvLarge, kPvMid)
-  TC_DISPATCH(kJvLarge, kPvLarge)
+  TC_TIED_DISPATCH(TC_CALL)
 #endif
-#undef TC_DISPATCH
+#undef TC_CALL
   return TC_ERR_UNSUPPORTED;
 }
 

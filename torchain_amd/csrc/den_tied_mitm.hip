@@ -223,18 +223,9 @@ int launch_den_tied_mitm(const DenParams &p, uint32_t *sync, int accumulate, hip
   q.aScr = (uint32_t)layout_lds_bytes(p.L, p.T);
   TC_HIP_CHECK(hipMemsetAsync(sync, 0, mitm_sync_bytes(p.S), stream));
   const int JV = p.L.JV, PV = p.L.PV;
-#define TC_DISPATCH(J, V) \
-  if (JV == J && PV == V) return launch_mitm_jp<J, V>(p, q, accumulate, lds, stream);
-  TC_DISPATCH(kJvSmall, kPvSmall)
-  TC_DISPATCH(kJvSmall, kPvMid)
-  TC_DISPATCH(kJvSmall, kPvLarge)
-  TC_DISPATCH(kJvMid, kPvSmall)
-  TC_DISPATCH(kJvMid, kPvMid)
-  TC_DISPATCH(kJvMid, kPvLarge)
-  TC_DISPATCH(kJvLarge, kPvSmall)
-  TC_DISPATCH(kJvLarge, kPvMid)
-  TC_DISPATCH(kJvLarge, kPvLarge)
-#undef TC_DISPATCH
+#define TC_CALL(J, V) launch_mitm_jp<J, V>(p, q, accumulate, lds, stream)
+  TC_TIED_DISPATCH(TC_CALL)
+#undef TC_CALL
   return TC_ERR_UNSUPPORTED;
 }
 

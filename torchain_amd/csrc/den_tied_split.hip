@@ -230,17 +230,6 @@ int launch_combine_jp(const DenParams &p, int accumulate, int groups, hipStream_
 
 }  // namespace
 
-#define TC_SPLIT_DISPATCH(CALL)                            \
-  if (JV == kJvSmall && PV == kPvSmall) return CALL(kJvSmall, kPvSmall); \
-  if (JV == kJvSmall && PV == kPvMid) return CALL(kJvSmall, kPvMid);     \
-  if (JV == kJvSmall && PV == kPvLarge) return CALL(kJvSmall, kPvLarge); \
-  if (JV == kJvMid && PV == kPvSmall) return CALL(kJvMid, kPvSmall);     \
-  if (JV == kJvMid && PV == kPvMid) return CALL(kJvMid, kPvMid);         \
-  if (JV == kJvMid && PV == kPvLarge) return CALL(kJvMid, kPvLarge);     \
-  if (JV == kJvLarge && PV == kPvSmall) return CALL(kJvLarge, kPvSmall); \
-  if (JV == kJvLarge && PV == kPvMid) return CALL(kJvLarge, kPvMid);     \
-  if (JV == kJvLarge && PV == kPvLarge) return CALL(kJvLarge, kPvLarge);
-
 // The backward-only kernel's LDS: the fused layout's exp(y), A0 and ACC regions as they are (compile-time bases),
 // then the second exp(y) buffer and the reduction scratch.  Returns the bytes, or 0 if it does not fit.
 size_t split_bwd_layout(DenLayout *L) {
@@ -263,7 +252,7 @@ int launch_den_tied_backward_only(const DenParams &p0, hipStream_t stream) {
   if (lds == 0) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
 #define TC_CALL_BWD(J, V) launch_bwd_jp<J, V>(p, lds, stream)
-  TC_SPLIT_DISPATCH(TC_CALL_BWD)
+  TC_TIED_DISPATCH(TC_CALL_BWD)
 #undef TC_CALL_BWD
   return TC_ERR_UNSUPPORTED;
 }
@@ -274,7 +263,7 @@ int launch_den_tied_combine(const DenParams &p, int accumulate, int num_cus, hip
   int groups = (2 * num_cus + p.S - 1) / p.S;
   groups = groups < 1 ? 1 : groups > p.T ? p.T : groups;
 #define TC_CALL_CMB(J, V) launch_combine_jp<J, V>(p, accumulate, groups, stream)
-  TC_SPLIT_DISPATCH(TC_CALL_CMB)
+  TC_TIED_DISPATCH(TC_CALL_CMB)
 #undef TC_CALL_CMB
   return TC_ERR_UNSUPPORTED;
 }
