@@ -107,8 +107,7 @@ struct TiedSeq {
   f4 ycur[PV], ynext[PV];
   f4 bown[JV];  // beta_{t+1} / B_{t+1} of the owned states (the LDS gather source holds Y instead)
 #ifdef TC_PHASE_STAMPS
-  long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long *wst = st_acc + 5;
+  long long st_prev, st_acc[8];
 #endif
 
   __device__ __forceinline__ TiedSeq(const DenParams &pp, int seq, int meet)
@@ -221,6 +220,9 @@ struct TiedSeq {
   // frame t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
   template <bool GAMMA>
   __device__ __forceinline__ void forward_frame(int t) {
+#ifdef TC_PHASE_STAMPS
+    long long *const wst = st_acc + 5;  // (the walk's sub-stamps)
+#endif
     TC_STAMP(0)
     Chunk6 q0;
     load_chunk(q0, fbase, lane16, RESF);  // (past a short stream: readable padding, never processed)
@@ -463,6 +465,9 @@ struct TiedSeq {
   // Returns true after frame 0 (the two checks written; nothing follows).
   template <bool PURE>
   __device__ __forceinline__ bool backward_frame(int t, int t_top) {
+#ifdef TC_PHASE_STAMPS
+    long long *const wst = st_acc + 5;
+#endif
     TC_STAMP(0)
     Chunk6 q0;
     load_chunk(q0, bbase, lane16, RESB);
