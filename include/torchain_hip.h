@@ -208,7 +208,7 @@ int tc_supervision_stage(tc_supervision *supervision, int device);
  *     tied, Hs <= 8192      + 4 S Hs + ~80 (T + 2) S bytes      one more row, the two-sequence form's normalisers
  *     tied, S <= 128        + 4 (T + 1) S Hs                    the second history of the two-CU form
  *   graphs beyond LDS       4 (T + 1) S' H + 12 S' H + 8 S' P   S' = S rounded up to whole slabs of 16 sequences (32 from
- *                                                              24000 states on): the streamed path's [slab][state][G] matrices
+ *                                                              28000 states on): the streamed path's [slab][state][G] matrices
  *                           + 4 T S' P if that is <= 1 GB       exp(y) of every frame, transposed once (else per frame)
  * plus a few KB of per-sequence scalars. */
 int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);

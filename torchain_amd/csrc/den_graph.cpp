@@ -301,14 +301,15 @@ int build_schedules(tc_den_graph *g) {
     g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
     if (g->layout_ok) return TC_OK;
   }
-  // the per-frame working set does not fit LDS: stream it.  Slabs of 16 or 32 sequences: measured on 10-arc-per-state
-  // graphs at 256 sequences (profiles/r04_ablations.txt), 32 wins from about 24000 states on (28000: 20.7 vs 22.7 ms,
-  // 40000: 28.4 vs 30.5) although its slice no longer fits L2 -- fewer, longer waves per frame and half the atomics;
+  // the per-frame working set does not fit LDS: stream it.  Slabs of 16 or 32 sequences: measured at 256 sequences
+  // (profiles/r04_ablations.txt), 32 wins on large graphs although its slice no longer fits L2 -- fewer, longer waves
+  // per frame and half the atomics (10-arc-per-state graphs of 28000 states: 20.7 vs 22.7 ms, 40000: 28.4 vs 30.5);
+  // at 20000 states the two are equal, a 24000-state phone-LM-structured graph prefers 16 (19.1 vs 20.5 ms), and
   // below that the kernels are short and the narrow slabs' larger grids win (8192 states: 8.7 vs 10.2 ms).
   g->big = true;
   {
     const int64_t states = g->tied ? g->work_H : g->H;
-    g->big_G = states >= 24000 ? 32 : 16;
+    g->big_G = states >= 28000 ? 32 : 16;
     if (debug_flag(kDbgSlabWide)) g->big_G = 32;
     if (debug_flag(kDbgSlabNarrow)) g->big_G = 16;
   }

@@ -339,6 +339,8 @@ CONFIGS = {
     "X1": dict(S=256, T=150, P=2928, H=14000, degree=15, leaky=0.1, l2=5e-5),
     # beyond the on-chip layouts: the streamed (sequence-minor) kernels
     "X2": dict(S=256, T=150, P=4096, H=40000, degree=10, leaky=0.1, l2=5e-5),
+    # ... and a phone-LM-structured graph of that size class: 24000 states, 312000 arcs, in-degrees up to the hundreds
+    "R4": dict(S=256, T=150, P=2928, H=None, leaky=0.1, l2=5e-5, phone_lm=dict(num_histories=2000, branching=12)),
 }
 
 
