@@ -8,7 +8,7 @@
 // recursion is a grid-wide dependency).
 //
 // Layout (round 4; rounds 1-3 kept [state][64 sequences] matrices and one state per wave): sequences are cut
-// into SLABS of G = 16 or 32 (per graph: the widest whose slice fits an XCD's L2, den_graph.cpp), and every per-frame
+// into SLABS of G = 16 or 32 (per graph, by measured size classes: den_graph.cpp build_schedules), and every per-frame
 // matrix is [slab][row][G] -- a state's (pdf's) values for the slab's sequences are one 64- or 128-byte segment.
 // Why: a frame's arc sums gather A * S * 4 bytes (410 MB at 400 k arcs x 256 sequences) from a matrix that is re-read degree times; an XCD's L2 is 4 MB, and with 64-wide rows the
 // slice of the matrix one XCD works on was 10 MB at 40 k states, so every gathered row came from the Infinity
