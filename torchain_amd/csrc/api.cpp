@@ -43,6 +43,7 @@ int hist_states(const tc_den_graph *g) {
 int big_p(const tc_den_graph *g) { return g->big ? g->P : 0; }
 int big_h(const tc_den_graph *g) { return g->big ? (g->tied ? g->work_H : g->H) : 0; }  // tied: work-graph states
 int big_g(const tc_den_graph *g) { return g->big ? g->big_G : 16; }
+int big_hb(const tc_den_graph *g) { return g->big ? g->big_hb : 0; }
 // Batches the tied on-chip kernel may run as two CUs per sequence get room for the second history.  (Whether
 // they do is decided at launch: device size, layout for this T, diagnostic switch.)
 bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq; }
@@ -51,7 +52,7 @@ bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <
 bool pair_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.JV == kJvSmall; }
 
 // big_P != 0 selects the streamed path's layout: sequences padded to slabs of 16, [slab][state][16] matrices
-Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, int big_G = 16, bool split = false, bool pair = false) {
+Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, int big_G = 16, int big_hb = 0, bool split = false, bool pair = false) {
   Workspace w;
   const int Sp = (S + big_G - 1) / big_G * big_G;
   size_t off = 0;
@@ -75,7 +76,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)1 << 30) ? T : 1;
   w.big_expy = big_P ? (float *)take((size_t)w.big_exp_frames * Sp * big_P * sizeof(float)) : nullptr;
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
-  w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_H, big_P, T, Sp) * sizeof(float)) : nullptr;
+  w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_hb, big_P, T, Sp) * sizeof(float)) : nullptr;
   w.big_y = big_P ? (float *)take((size_t)Sp * big_H * sizeof(float)) : nullptr;
   w.big_gam = big_P ? (uint32_t *)take((size_t)Sp * big_P * sizeof(uint32_t)) : nullptr;
   w.beta_hist = split ? (float *)take((size_t)(T + 1) * S * Hs * sizeof(float)) : nullptr;
@@ -253,7 +254,7 @@ int tune_den_variant(tc_den_graph *g, int device) {
   if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || num_cus < 2)
     return finish();
   const int S = num_cus & ~1, T = kTuneFrames, P = g->P;
-  const Workspace w0 = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), split_room(g, S), pair_room(g));
+  const Workspace w0 = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
   const size_t ybytes = (size_t)S * T * P * sizeof(float);
   char *mem = nullptr;
   hipStream_t stream = nullptr;
@@ -266,7 +267,7 @@ int tune_den_variant(tc_den_graph *g, int device) {
     float *y = (float *)mem, *deriv = (float *)(mem + ybytes);
     char *wsp = mem + 2 * ybytes;
     wsp += (256 - ((uintptr_t)wsp & 255)) & 255;
-    const Workspace w = carve(wsp, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), split_room(g, S), pair_room(g));
+    const Workspace w = carve(wsp, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
     DenParams p[2];
     for (int variant = 0; variant < 2 && ok; ++variant) {
       d.pair_choice = variant;
@@ -353,7 +354,7 @@ uint64_t tc_den_graph_hash(const tc_den_graph *g) {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), split_room(g, S), pair_room(g)).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g)).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -362,7 +363,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), split_room(g, S), pair_room(g));
+  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -408,7 +409,7 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), big_g(g), split_room(g, sup->S), pair_room(g));
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, sup->S), pair_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -513,7 +514,7 @@ StepWorkspace carve_step(char *base, const tc_den_graph *g, int S, int T, int P,
     off += align256(bytes);
     return p;
   };
-  w.chain_bytes = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), split_room(g, S), pair_room(g)).total;
+  w.chain_bytes = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g)).total;
   w.chain = take(w.chain_bytes);
   w.trace = take((size_t)trace_workspace_bytes());
   const size_t mat = (size_t)S * T * P * sizeof(float);

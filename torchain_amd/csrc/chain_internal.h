@@ -133,6 +133,8 @@ struct SlabListHost {
 struct BigDev {
   SlabListDev in, out, pdf;
   int G = 16;            // sequences per slab
+  int in_blocks = 0, out_blocks = 0;  // blocks (of G bundles) of the two state lists; hb = the larger: rows of the per-block partials
+  int hb = 0;
   // tied graphs (work-graph states): the arc lists hold the non-special arcs only and exp(y) is applied
   // per state, so an arc costs ONE row gather per pass; gamma comes from per-state quantities, added by the
   // backward kernel to fixed-point accumulators
@@ -239,6 +241,7 @@ struct tc_den_graph {
   // streamed path: chosen when neither on-chip layout fits (or TC_FORCE_BIG is set)
   bool big = false;
   tc::SlabListHost big_in, big_out, big_pdf;
+  int big_hb = 0;  // blocks of the longer state list (tc::BigDev::hb)
   int big_G = 16;  // sequences per slab: 32 when a slab's slice of the state matrix fits an XCD's L2 (den_graph.cpp)
   std::vector<int32_t> big_f_off;
   std::vector<int32_t> tied_f, tied_s;  // per work state: forward / special self-loop pdf, -1 if none
@@ -355,7 +358,7 @@ size_t mitm_sync_bytes(int S);
 int pair_norm_stride(int T);
 size_t pair_sync_bytes(int S);
 inline size_t pair_stamp_bytes(int T) { return ((size_t)2 * kWaves * (T + 2) * 8 * 8 + 255) & ~(size_t)255; }
-int64_t big_small_floats(int H, int P, int T, int Sp);
+int64_t big_small_floats(int hb, int P, int T, int Sp);
 int launch_num(const NumParams &p, hipStream_t stream);
 int launch_num_scatter(const NumParams &p, hipStream_t stream);
 // Side streams and fork / join events per (device, caller stream) (made on first use; the hot path only records and waits):

@@ -105,8 +105,11 @@ static uint32_t f2u(float f) {
   return u;
 }
 
-// entries[r]: row r's entries in list order; meta[r]: its SlabRow (n is filled in here); bundle_rows: four row
-// indices per bundle, -1 for none
+// entries[r]: row r's entries in list order; meta[r]: its SlabRow (n is filled in here); bundle_rows: 64 / G row indices
+// per bundle, -1 for none.  A bundle {r, -2, -2, ...} holds the ONE long row r ("hub"): its entries are dealt round-robin
+// to the bundle's groups (entry i: group i mod NG, step i / NG), the kernels add the groups' sums (groups_sum) and only
+// group 0 carries the row -- a row of several hundred entries (the popular states of a phone-LM graph) then takes
+// 1 / NG of the steps, and it is a frame's longest dependent chain.
 static void make_slab_list(int W, int G, const std::vector<std::vector<SlabEntry>> &entries, const std::vector<SlabRow> &meta,
                            const std::vector<int32_t> &bundle_rows, SlabListHost *out) {
   const int spc = 16 / W, NG = 64 / G, CH = NG * 16;
@@ -118,36 +121,64 @@ static void make_slab_list(int W, int G, const std::vector<std::vector<SlabEntry
   out->rec.clear();
   size_t chunk = 0;
   for (int32_t b = 0; b < out->bundles; ++b) {
+    const int32_t *br = &bundle_rows[(size_t)b * NG];
+    const bool shared = NG > 1 && br[1] == -2;
     int steps = 0;
-    for (int q = 0; q < NG; ++q)
-      if (bundle_rows[(size_t)b * NG + q] >= 0) steps = std::max(steps, (int)entries[bundle_rows[(size_t)b * NG + q]].size());
+    if (shared) {
+      steps = ((int)entries[br[0]].size() + NG - 1) / NG;
+    } else {
+      for (int q = 0; q < NG; ++q)
+        if (br[q] >= 0) steps = std::max(steps, (int)entries[br[q]].size());
+    }
     const int chunks = (steps + spc - 1) / spc;
     out->head[(size_t)b * 2] = (int32_t)chunk;
-    out->head[(size_t)b * 2 + 1] = steps;
+    out->head[(size_t)b * 2 + 1] = shared ? (int32_t)((uint32_t)steps | 0x80000000u) : steps;
     out->rec.resize((chunk + chunks) * CH, 0u);
-    for (int q = 0; q < NG; ++q) {
-      const int32_t r = bundle_rows[(size_t)b * NG + q];
-      if (r < 0) continue;
-      SlabRow m = meta[r];
-      m.n = (int32_t)entries[r].size();
-      out->rows[(size_t)b * NG + q] = m;
-      for (int i = 0; i < m.n; ++i)
-        for (int c = 0; c < W; ++c)
-          out->rec[(chunk + i / spc) * CH + q * 16 + (i % spc) * W + c] = entries[r][i].d[c];
+    auto put = [&](int q, int i, const SlabEntry &e) {
+      for (int c = 0; c < W; ++c) out->rec[(chunk + i / spc) * CH + q * 16 + (i % spc) * W + c] = e.d[c];
+    };
+    if (shared) {
+      const int32_t r = br[0];
+      const int n = (int)entries[r].size();
+      for (int q = 0; q < NG; ++q) {
+        SlabRow m = q == 0 ? meta[r] : SlabRow{-1, 0, -1, -1, 0.f, 0.f, 0.f, 0.f};
+        m.n = (n - q + NG - 1) / NG;
+        out->rows[(size_t)b * NG + q] = m;
+      }
+      for (int i = 0; i < n; ++i) put(i % NG, i / NG, entries[r][i]);
+    } else {
+      for (int q = 0; q < NG; ++q) {
+        const int32_t r = br[q];
+        if (r < 0) continue;
+        SlabRow m = meta[r];
+        m.n = (int32_t)entries[r].size();
+        out->rows[(size_t)b * NG + q] = m;
+        for (int i = 0; i < m.n; ++i) put(q, i, entries[r][i]);
+      }
     }
     chunk += chunks;
   }
   out->rec.resize((chunk + 3) * CH, 0u);  // spare chunks: the walk requests a pair of chunks ahead
 }
 
-// rows sorted by length (longest first, stable), 64 / G at a time
+// rows sorted by length (longest first, stable), 64 / G at a time; rows of kSlabHubLen entries or more get a bundle of
+// their own
+constexpr size_t kSlabHubLen = 48;
 static std::vector<int32_t> bundles_by_length(const std::vector<std::vector<SlabEntry>> &entries, int G) {
+  const int NG = 64 / G;
   std::vector<int32_t> order(entries.size());
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return entries[a].size() > entries[b].size(); });
-  while (order.size() % (64 / G)) order.push_back(-1);
-  if (order.empty()) order.assign(64 / G, -1);
-  return order;
+  std::vector<int32_t> out;
+  size_t i = 0;
+  for (; NG > 1 && i < order.size() && entries[order[i]].size() >= kSlabHubLen; ++i) {
+    out.push_back(order[i]);
+    for (int q = 1; q < NG; ++q) out.push_back(-2);
+  }
+  for (; i < order.size(); ++i) out.push_back(order[i]);
+  while (out.size() % NG) out.push_back(-1);
+  if (out.empty()) out.assign(NG, -1);
+  return out;
 }
 
 // by-pdf list: a block of the gamma kernel is a tile of 64 consecutive pdfs; its bundles are sorted inside the tile
@@ -320,6 +351,7 @@ int build_schedules(tc_den_graph *g) {
     build_big_tied(g, special);
   else
     build_big(g);
+  g->big_hb = (std::max(g->big_in.bundles, g->big_out.bundles) + g->big_G - 1) / g->big_G;
   return TC_OK;
 }
 
@@ -598,14 +630,21 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   // streamed path: the lists are replayed the way the kernels read them (bundle, group of 16 lanes, chunk, step)
   auto slab_sums = [&](const SlabListHost &L, auto term, std::vector<float> *sums) {
     const int spc = 16 / L.W, NG = 64 / L.G, CH = NG * 16;
-    for (int32_t b = 0; b < L.bundles; ++b)
+    for (int32_t b = 0; b < L.bundles; ++b) {
+      const bool shared = L.head[(size_t)b * 2 + 1] < 0;  // one long row dealt to the groups: the kernels add the groups' sums
+      float gsum[4] = {0.f, 0.f, 0.f, 0.f};
       for (int q = 0; q < NG; ++q) {
         const SlabRow &r = L.rows[(size_t)b * NG + q];
-        if (r.row < 0) continue;
+        if (r.row < 0 && !shared) continue;
         float sum = 0.f;
         for (int i = 0; i < r.n; ++i) sum += term(&L.rec[((size_t)L.head[(size_t)b * 2] + i / spc) * CH + q * 16 + (i % spc) * L.W]);
-        (*sums)[r.row] = sum;
+        if (shared)
+          gsum[q] = sum;
+        else
+          (*sums)[r.row] = sum;
       }
+      if (shared) (*sums)[L.rows[(size_t)b * NG].row] = NG == 4 ? (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]) : gsum[0] + gsum[1];
+    }
   };
   auto u2f = [](uint32_t u) {
     float f;
@@ -815,6 +854,9 @@ static int upload_den_graph(tc_den_graph *g, int device) {
     d.pi = (const float *)(blob + parts[9].off);
     d.big.tied = tb ? 1 : 0;
     d.big.G = g->big_G;
+    d.big.in_blocks = (g->big_in.bundles + g->big_G - 1) / g->big_G;  // a block = 64 rows' worth of bundles = G bundles
+    d.big.out_blocks = (g->big_out.bundles + g->big_G - 1) / g->big_G;
+    d.big.hb = g->big_hb;
     d.big.f_off = (const int32_t *)(blob + parts[10].off);
     g->dev[device] = d;
     return TC_OK;

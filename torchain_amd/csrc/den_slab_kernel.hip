@@ -60,12 +60,11 @@ struct BigSmall {
   float *part_y2;    // [slab][pdf tiles][G]  running sum of y^2 per tile of 64 pdfs
 };
 
-__host__ __device__ inline int slab_state_blocks(int H) { return (H + kSlabRowsPerBlock - 1) / kSlabRowsPerBlock; }
 __host__ __device__ inline int slab_pdf_tiles(int P) { return (P + 63) / 64; }
 
 __host__ __device__ inline BigSmall big_small(const DenParams &p) {
   const int64_t Sp = p.big_Sp;
-  const int64_t hb = slab_state_blocks(p.H), pb = slab_pdf_tiles(p.P);
+  const int64_t hb = p.big.hb, pb = slab_pdf_tiles(p.P);
   BigSmall s;
   float *q = p.big_small;
   s.asum = q;
@@ -147,11 +146,21 @@ __device__ __forceinline__ void walk_tail(int n, uint32_t rec0, uint32_t rec1, B
       walk_tail<SPC, I + 1>(n, rec0, rec1, body);
   }
 }
+// Sum over the row groups of a wave (every lane gets the total of its sequence): a bundle that holds ONE long row, its
+// entries dealt round-robin to the groups (den_graph.cpp: hub rows), ends with it.  Fixed order of the adds.
+template <int G>
+__device__ __forceinline__ float groups_sum(float v) {
+  if constexpr (G == 16) v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Returns whether the bundle is such a shared row (sign bit of its step count).
 template <int G, int W, class Body>
-__device__ __forceinline__ void walk(const SlabListDev &L, int b, const Lane<G> &ln, Body &body) {
+__device__ __forceinline__ bool walk(const SlabListDev &L, int b, const Lane<G> &ln, Body &body) {
   constexpr int SPC = 16 / W, CH = (64 / G) * 16;
   const int2 hd = L.head[b];
-  int n = hd.y;
+  int n = hd.y & 0x7fffffff;
   const uint32_t *r = L.rec + (size_t)hd.x * CH + ln.q * 16 + (ln.lane & 15);
   uint32_t rec0 = r[0], rec1 = r[CH];
   for (; n >= 2 * SPC; n -= 2 * SPC) {
@@ -162,6 +171,8 @@ __device__ __forceinline__ void walk(const SlabListDev &L, int b, const Lane<G> 
     rec1 = nx1;
   }
   if (n > 0) walk_tail<SPC, 1>(n, rec0, rec1, body);
+  if (hd.y < 0) body.sum = groups_sum<G>(body.sum);
+  return hd.y < 0;
 }
 
 // record dword D of a step I of a pair of chunks (compile-time selection of the chunk's register)
@@ -345,9 +356,9 @@ __device__ __forceinline__ float slab_colsum(const float *part, int rows, float 
 template <int G>
 __global__ __launch_bounds__(kRT) void slab_asum_kernel(const DenParams p, int t) {
   __shared__ float red[kRT];
-  const int slab = blockIdx.x, hb = slab_state_blocks(p.H);
+  const int slab = blockIdx.x, hb = p.big.hb;
   const BigSmall sm = big_small(p);
-  const float tot = slab_colsum<G>(sm.part_a + (int64_t)slab * hb * G, hb, red, threadIdx.x);
+  const float tot = slab_colsum<G>(sm.part_a + (int64_t)slab * hb * G, p.big.in_blocks, red, threadIdx.x);
   if (threadIdx.x < G) sm.asum[(int64_t)t * p.big_Sp + slab * G + threadIdx.x] = tot;
 }
 
@@ -390,13 +401,13 @@ __global__ __launch_bounds__(kBT) void slab_beta_init_kernel(const DenParams p) 
 template <int G>
 __global__ __launch_bounds__(kRT) void slab_bsum_kernel(const DenParams p, int t) {
   __shared__ float red[kRT];
-  const int slab = blockIdx.x, hb = slab_state_blocks(p.H), pb = slab_pdf_tiles(p.P), tid = threadIdx.x;
+  const int slab = blockIdx.x, hb = p.big.hb, nb = p.big.out_blocks, pb = slab_pdf_tiles(p.P), tid = threadIdx.x;
   const BigSmall sm = big_small(p);
   const int s = slab * G + tid;
-  const float b = slab_colsum<G>(sm.part_a + (int64_t)slab * hb * G, hb, red, tid);
+  const float b = slab_colsum<G>(sm.part_a + (int64_t)slab * hb * G, nb, red, tid);
   if (tid < G) sm.bsum[(t & 1) * p.big_Sp + s] = b;
   if (t == 0) {
-    const float ab = slab_colsum<G>(sm.part_ab + (int64_t)slab * hb * G, hb, red, tid);
+    const float ab = slab_colsum<G>(sm.part_ab + (int64_t)slab * hb * G, nb, red, tid);
     const float gs = slab_colsum<G>(sm.part_g + (int64_t)slab * pb * G, pb, red, tid);
     if (tid < G && s < p.S) {
       p.seq_ab[s] = ab;
@@ -440,8 +451,8 @@ __global__ __launch_bounds__(kBT) void slab_fwd_tied_kernel(const DenParams p, i
   __shared__ float red[4][64];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Lane<G> ln(threadIdx.x & 63);
-  const int Sp = p.big_Sp, slabs = Sp / G, hb = slab_state_blocks(p.H);
-  const SlabBlock sb = slab_block(hb, slabs);
+  const int Sp = p.big_Sp, slabs = Sp / G, hb = p.big.hb;
+  const SlabBlock sb = slab_block(p.big.in_blocks, slabs);
   if (!sb.ok) return;
   const BigSmall sm = big_small(p);
   const int s = sb.slab * G + (int)ln.j;
@@ -509,8 +520,8 @@ __global__ __launch_bounds__(kBT) void slab_bwd_tied_kernel(const DenParams p, i
   __shared__ float red[2][4][64];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Lane<G> ln(threadIdx.x & 63);
-  const int Sp = p.big_Sp, slabs = Sp / G, hb = slab_state_blocks(p.H);
-  const SlabBlock sb = slab_block(hb, slabs);
+  const int Sp = p.big_Sp, slabs = Sp / G, hb = p.big.hb;
+  const SlabBlock sb = slab_block(p.big.out_blocks, slabs);
   if (!sb.ok) return;
   const BigSmall sm = big_small(p);
   const int s = sb.slab * G + (int)ln.j;
@@ -615,8 +626,8 @@ __global__ __launch_bounds__(kBT) void slab_fwd_kernel(const DenParams p, int t)
   __shared__ float red[4][64];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Lane<G> ln(threadIdx.x & 63);
-  const int Sp = p.big_Sp, slabs = Sp / G, hb = slab_state_blocks(p.H);
-  const SlabBlock sb = slab_block(hb, slabs);
+  const int Sp = p.big_Sp, slabs = Sp / G, hb = p.big.hb;
+  const SlabBlock sb = slab_block(p.big.in_blocks, slabs);
   if (!sb.ok) return;
   const BigSmall sm = big_small(p);
   const int s = sb.slab * G + (int)ln.j;
@@ -650,8 +661,8 @@ __global__ __launch_bounds__(kBT) void slab_bwd_kernel(const DenParams p, int t)
   __shared__ float red[2][4][64];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Lane<G> ln(threadIdx.x & 63);
-  const int Sp = p.big_Sp, slabs = Sp / G, hb = slab_state_blocks(p.H);
-  const SlabBlock sb = slab_block(hb, slabs);
+  const int Sp = p.big_Sp, slabs = Sp / G, hb = p.big.hb;
+  const SlabBlock sb = slab_block(p.big.out_blocks, slabs);
   if (!sb.ok) return;
   const BigSmall sm = big_small(p);
   const int s = sb.slab * G + (int)ln.j;
@@ -737,9 +748,10 @@ template <int G>
 int launch_slab(const DenParams &p, int accumulate, hipStream_t stream) {
   const int Sp = p.big_Sp, slabs = Sp / G;
   const dim3 blk(kBT);
-  const int hb = slab_state_blocks(p.H), pb = slab_pdf_tiles(p.P);
+  const int pb = slab_pdf_tiles(p.P);
   const dim3 g_exp((pb + 3) / 4, slabs);
-  const int g_states = slab_grid(hb, slabs), g_pdfs = slab_grid(pb, slabs), g_y = slab_grid((p.H + 63) / 64, slabs);
+  const int g_in = slab_grid(p.big.in_blocks, slabs), g_out = slab_grid(p.big.out_blocks, slabs);
+  const int g_pdfs = slab_grid(pb, slabs), g_y = slab_grid((p.H + 63) / 64, slabs);
   const int fill_blocks = (int)std::min<int64_t>(4096, ((int64_t)p.H * Sp + kBT - 1) / kBT);
   const bool tied = p.big.tied != 0;
   const bool exp_all = p.big_exp_stride != 0;
@@ -748,9 +760,9 @@ int launch_slab(const DenParams &p, int accumulate, hipStream_t stream) {
   for (int t = 1; t <= p.T; ++t) {
     if (!exp_all) hipLaunchKernelGGL(slab_exp_kernel<G>, g_exp, blk, 0, stream, p, t - 1, t, 1);
     if (tied)
-      hipLaunchKernelGGL(slab_fwd_tied_kernel<G>, dim3(g_states), blk, 0, stream, p, t);
+      hipLaunchKernelGGL(slab_fwd_tied_kernel<G>, dim3(g_in), blk, 0, stream, p, t);
     else
-      hipLaunchKernelGGL(slab_fwd_kernel<G>, dim3(g_states), blk, 0, stream, p, t);
+      hipLaunchKernelGGL(slab_fwd_kernel<G>, dim3(g_in), blk, 0, stream, p, t);
     hipLaunchKernelGGL(slab_asum_kernel<G>, dim3(slabs), dim3(kRT), 0, stream, p, t);
   }
   hipLaunchKernelGGL(slab_total_kernel<G>, dim3((Sp + kBT - 1) / kBT), blk, 0, stream, p);
@@ -760,13 +772,13 @@ int launch_slab(const DenParams &p, int accumulate, hipStream_t stream) {
       if (!exp_all) hipLaunchKernelGGL(slab_exp_kernel<G>, g_exp, blk, 0, stream, p, t, t + 1, 0);
       if (tied) {
         hipLaunchKernelGGL(slab_y_kernel<G>, dim3(g_y), blk, 0, stream, p, t);
-        hipLaunchKernelGGL(slab_bwd_tied_kernel<G>, dim3(g_states), blk, 0, stream, p, t);
+        hipLaunchKernelGGL(slab_bwd_tied_kernel<G>, dim3(g_out), blk, 0, stream, p, t);
         if (accumulate)
           hipLaunchKernelGGL((slab_gamma_out_kernel<G, true>), dim3(g_pdfs), blk, 0, stream, p, t);
         else
           hipLaunchKernelGGL((slab_gamma_out_kernel<G, false>), dim3(g_pdfs), blk, 0, stream, p, t);
       } else {
-        hipLaunchKernelGGL(slab_bwd_kernel<G>, dim3(g_states), blk, 0, stream, p, t);
+        hipLaunchKernelGGL(slab_bwd_kernel<G>, dim3(g_out), blk, 0, stream, p, t);
         if (accumulate)
           hipLaunchKernelGGL((slab_gamma_kernel<G, true>), dim3(g_pdfs), blk, 0, stream, p, t);
         else
@@ -782,8 +794,8 @@ int launch_slab(const DenParams &p, int accumulate, hipStream_t stream) {
 }  // namespace
 
 // floats of p.big_small for this problem size (api.cpp sizes the workspace with it)
-int64_t big_small_floats(int H, int P, int T, int Sp) {
-  const int64_t hb = slab_state_blocks(H), pb = slab_pdf_tiles(P);
+int64_t big_small_floats(int hb, int P, int T, int Sp) {
+  const int64_t pb = slab_pdf_tiles(P);
   return ((int64_t)(T + 1) + 2 + 1 + 2 * hb + 2 * pb) * Sp;
 }
 
