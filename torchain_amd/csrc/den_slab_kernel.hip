@@ -328,11 +328,11 @@ __global__ __launch_bounds__(kBT) void slab_alpha0_kernel(const DenParams p) {
     for (int s = threadIdx.x; s < p.big_Sp; s += kBT) sm.asum[s] = p.big_sum_pi;
 }
 
-// sums part[rows][G] over the rows in a fixed order: kRT / G groups of G lanes stride over the rows, then one
-// group adds the partial sums.  Returns the total in threads 0..G-1.
-template <int G>
+// sums part[rows][G] over the rows in a fixed order: NT / G groups of G lanes stride over the rows, then one
+// group adds the partial sums (NT threads, red: NT floats).  Returns the total in threads 0..G-1.
+template <int G, int NT = kRT>
 __device__ __forceinline__ float slab_colsum(const float *part, int rows, float *red, int tid) {
-  constexpr int NG = kRT / G;
+  constexpr int NG = NT / G;
   const int r0 = tid / G, j = tid % G;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int r = r0;
@@ -592,11 +592,20 @@ __global__ __launch_bounds__(kBT) void slab_bwd_tied_kernel(const DenParams p, i
 }
 
 // the frame's gamma accumulators -> derivative rows (and cleared for the next frame)
+// Blocks behind the grid of pdf tiles (frames t > 0: launch_slab) take the frame's other small job, bsum_t of one slab
+// each -- one dependent launch less per frame.
 template <int G, bool ACCUM>
-__global__ __launch_bounds__(kBT) void slab_gamma_out_kernel(const DenParams p, int t) {
+__global__ __launch_bounds__(kBT) void slab_gamma_out_kernel(const DenParams p, int t, int tile_blocks) {
   __shared__ float tile[64][G + 1];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, tid = threadIdx.x;
   const int slabs = p.big_Sp / G, pb = slab_pdf_tiles(p.P);
+  if ((int)blockIdx.x >= tile_blocks) {
+    const int slab = (int)blockIdx.x - tile_blocks, hb = p.big.hb;
+    const BigSmall sm = big_small(p);
+    const float b = slab_colsum<G, kBT>(sm.part_a + (int64_t)slab * hb * G, p.big.out_blocks, &tile[0][0], tid);
+    if (tid < G) sm.bsum[(t & 1) * p.big_Sp + slab * G + tid] = b;
+    return;
+  }
   const SlabBlock sb = slab_block(pb, slabs);
   if (!sb.ok) return;
   const int p0 = sb.blk * 64;
@@ -773,10 +782,13 @@ int launch_slab(const DenParams &p, int accumulate, hipStream_t stream) {
       if (tied) {
         hipLaunchKernelGGL(slab_y_kernel<G>, dim3(g_y), blk, 0, stream, p, t);
         hipLaunchKernelGGL(slab_bwd_tied_kernel<G>, dim3(g_out), blk, 0, stream, p, t);
+        // (frame 0's column sums also need this launch's gamma sums: their own launch below)
+        const int extra = t > 0 ? slabs : 0;
         if (accumulate)
-          hipLaunchKernelGGL((slab_gamma_out_kernel<G, true>), dim3(g_pdfs), blk, 0, stream, p, t);
+          hipLaunchKernelGGL((slab_gamma_out_kernel<G, true>), dim3(g_pdfs + extra), blk, 0, stream, p, t, g_pdfs);
         else
-          hipLaunchKernelGGL((slab_gamma_out_kernel<G, false>), dim3(g_pdfs), blk, 0, stream, p, t);
+          hipLaunchKernelGGL((slab_gamma_out_kernel<G, false>), dim3(g_pdfs + extra), blk, 0, stream, p, t, g_pdfs);
+        if (t > 0) continue;
       } else {
         hipLaunchKernelGGL(slab_bwd_kernel<G>, dim3(g_out), blk, 0, stream, p, t);
         if (accumulate)
