@@ -31,6 +31,19 @@ struct In {
   void read(void *dst, size_t n) {
     if (n && fread_unlocked(dst, 1, n, f) != n) throw FormatError{"unexpected end of file"};
   }
+  // n elements into v, growing v as the data arrives: a size field in a damaged or crafted header can make the reader
+  // allocate no more than the bytes that are really there (+ one step)
+  template <class T>
+  void read_grow(std::vector<T> *v, size_t n) {
+    const size_t step_max = ((size_t)16 << 20) / sizeof(T);
+    v->clear();
+    for (size_t done = 0; done < n;) {
+      const size_t step = n - done < step_max ? n - done : step_max;
+      v->resize(done + step);
+      read(v->data() + done, step * sizeof(T));
+      done += step;
+    }
+  }
   int peek() {
     const int c = getc_unlocked(f);
     if (c != EOF) std::ungetc(c, f);
@@ -97,7 +110,8 @@ void read_index_vector(In &in, std::vector<int32_t> *out) {
   in.expect("<I1V>");
   const int32_t size = in.basic<int32_t>();
   if (size < 0 || size > (1 << 26)) throw FormatError{"bad index vector size"};
-  out->resize((size_t)size * 3);
+  out->clear();
+  out->reserve((size_t)(size < (1 << 20) ? size : (1 << 20)) * 3);  // (grows with the elements that are really there)
   int32_t n = 0, t = 0, x = 0;
   for (int32_t i = 0; i < size; ++i) {
     const int8_t c = (int8_t)in.byte();
@@ -115,29 +129,31 @@ void read_index_vector(In &in, std::vector<int32_t> *out) {
       t = in.basic<int32_t>();
       x = in.basic<int32_t>();
     }
-    (*out)[3 * (size_t)i] = n;
-    (*out)[3 * (size_t)i + 1] = t;
-    (*out)[3 * (size_t)i + 2] = x;
+    out->push_back(n);
+    out->push_back(t);
+    out->push_back(x);
   }
 }
 
 void read_general_matrix(In &in, Io *io) {
   const std::string tok = in.token();
+  // (the raw bytes are read first, in steps: the float matrix is allocated for data that exists)
   auto dims = [&](int32_t rows, int32_t cols) {
     if (rows < 0 || cols < 0 || (int64_t)rows * cols > ((int64_t)1 << 31)) throw FormatError{"bad matrix size"};
     io->rows = rows;
     io->cols = cols;
-    io->feat.resize((size_t)rows * cols);
+    return (size_t)rows * cols;
   };
   if (tok == "FM" || tok == "DM") {
     const int32_t rows = in.basic<int32_t>(), cols = in.basic<int32_t>();
-    dims(rows, cols);
+    const size_t n = dims(rows, cols);
     if (tok == "FM") {
-      in.read(io->feat.data(), io->feat.size() * sizeof(float));
+      in.read_grow(&io->feat, n);
     } else {
-      std::vector<double> d(io->feat.size());
-      in.read(d.data(), d.size() * sizeof(double));
-      for (size_t i = 0; i < d.size(); ++i) io->feat[i] = (float)d[i];
+      std::vector<double> d;
+      in.read_grow(&d, n);
+      io->feat.resize(n);
+      for (size_t i = 0; i < n; ++i) io->feat[i] = (float)d[i];
     }
     return;
   }
@@ -147,14 +163,14 @@ void read_general_matrix(In &in, Io *io) {
       int32_t rows, cols;
     } h;
     in.read(&h, 16);
-    dims(h.rows, h.cols);
-    const size_t n = io->feat.size();
+    const size_t n = dims(h.rows, h.cols);
     if (tok == "CM") {
       // per column four uint16 percentiles (0, 25, 75, 100), then column-major bytes
-      std::vector<uint16_t> hdr((size_t)4 * h.cols);
-      in.read(hdr.data(), hdr.size() * 2);
-      std::vector<uint8_t> b(n);
-      in.read(b.data(), n);
+      std::vector<uint16_t> hdr;
+      in.read_grow(&hdr, (size_t)4 * h.cols);
+      std::vector<uint8_t> b;
+      in.read_grow(&b, n);
+      io->feat.resize(n);
       for (int32_t c = 0; c < h.cols; ++c) {
         float p[4];
         for (int k = 0; k < 4; ++k) p[k] = h.min_value + h.range * (float)hdr[4 * (size_t)c + k] / 65535.0f;
@@ -171,12 +187,14 @@ void read_general_matrix(In &in, Io *io) {
         }
       }
     } else if (tok == "CM2") {
-      std::vector<uint16_t> u(n);
-      in.read(u.data(), n * 2);
+      std::vector<uint16_t> u;
+      in.read_grow(&u, n);
+      io->feat.resize(n);
       for (size_t i = 0; i < n; ++i) io->feat[i] = h.min_value + h.range * (float)u[i] / 65535.0f;
     } else {
-      std::vector<uint8_t> u(n);
-      in.read(u.data(), n);
+      std::vector<uint8_t> u;
+      in.read_grow(&u, n);
+      io->feat.resize(n);
       for (size_t i = 0; i < n; ++i) io->feat[i] = h.min_value + h.range * (float)u[i] / 255.0f;
     }
     return;
@@ -211,8 +229,8 @@ void read_compact_acceptor(In &in, Sup *s) {
     throw FormatError{"supervision FST must be an unaligned compact_acceptor over StdArc starting at state 0"};
   if (flags & 3) throw FormatError{"symbol tables inside a supervision FST are not supported"};
   if (nstates < 0 || nstates > (1 << 28)) throw FormatError{"bad FST state count"};
-  std::vector<uint32_t> states((size_t)nstates + 1);
-  in.read(states.data(), states.size() * 4);
+  std::vector<uint32_t> states;
+  in.read_grow(&states, (size_t)nstates + 1);
   const size_t ncomp = nstates > 0 ? states[(size_t)nstates] : 0;
   if (ncomp > ((size_t)1 << 30)) throw FormatError{"bad FST element count"};
   struct Elem {
@@ -220,8 +238,8 @@ void read_compact_acceptor(In &in, Sup *s) {
     float weight;
     int32_t next;
   };
-  std::vector<Elem> comp(ncomp);
-  in.read(comp.data(), ncomp * sizeof(Elem));
+  std::vector<Elem> comp;
+  in.read_grow(&comp, ncomp);
   s->nstates = (int32_t)nstates;
   s->fin.assign((size_t)nstates, std::numeric_limits<float>::infinity());
   s->ab.assign((size_t)nstates + 1, 0);
@@ -311,8 +329,8 @@ void read_example(In &in, Example *eg) {
       int32_t n;
       in.read(&n, 4);
       if (n < 0 || n > (1 << 26)) throw FormatError{"bad <DW> size"};
-      std::vector<uint8_t> b((size_t)n);
-      in.read(b.data(), (size_t)n);
+      std::vector<uint8_t> b;
+      in.read_grow(&b, (size_t)n);
       o.dw.resize((size_t)n);
       for (int32_t i = 0; i < n; ++i) o.dw[(size_t)i] = (float)b[(size_t)i] / 255.0f;
       in.expect("</NnetChainSup>");
@@ -320,8 +338,7 @@ void read_example(In &in, Example *eg) {
       in.expect("FV");
       const int32_t n = in.basic<int32_t>();
       if (n < 0 || n > (1 << 26)) throw FormatError{"bad <DW2> size"};
-      o.dw.resize((size_t)n);
-      in.read(o.dw.data(), (size_t)n * 4);
+      in.read_grow(&o.dw, (size_t)n);
       in.expect("</NnetChainSup>");
     } else if (tok == "</NnetChainSup>") {
       o.dw.assign(o.idx.size() / 3, 1.0f);
