@@ -429,3 +429,23 @@ def test_native_reader_time_bound(tmp_path):
         best = min(best, time.perf_counter() - t0)
     assert got["outputs"][0]["supervision"].num_sequences == 64 and got["inputs"][0]["features"].shape == (64 * 458, 40)
     assert best <= 0.015, "native read + merge of 64 x 150 frames took %.1f ms" % (best * 1e3)
+
+
+def test_native_reader_allocates_for_the_data_that_is_there(tmp_path):
+    """A size field of a damaged or crafted example must not drive the allocation (a feature matrix header
+    may claim 2^31 floats, an FST 2^28 states): the reader's buffers grow with the bytes it really reads, so such a file
+    is refused after a few megabytes -- measured here as the process's peak memory."""
+    import resource
+    import struct
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    good = b"\0B" + kw.chain_example(make_example(fst, 5, seed=3))
+    at = good.index(b"FM ") + 3  # [K] WriteBasicType: size byte 4 + int32 rows, size byte 4 + int32 cols
+    assert good[at] == 4 and good[at + 5] == 4
+    huge = good[:at] + b"\x04" + struct.pack("<i", 1 << 16) + b"\x04" + struct.pack("<i", 1 << 15) + good[at + 10:]
+    path = str(tmp_path / "huge")
+    open(path, "wb").write(huge)
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with pytest.raises(egs.EgsFormatError):
+        egs.read_merged_native([(path, 0)])
+    grown_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before) / 1024.0
+    assert grown_mb < 256, "the reader grew by %.0f MB for a %d-byte file" % (grown_mb, len(huge))
