@@ -358,6 +358,8 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
  *   "no_mitm" / "force_mitm" (two CUs per sequence: never / always the form that meets in the middle instead of
  *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
+ *   "exp_per_frame"  (1: the streamed path transposes exp(y) one frame at a time, as it does when all frames would take
+ *                     more than 1 GB of workspace)
  *   "reg_rows"       (1: den_tied_rr.hip -- row sums of the arc walks in registers, one more chunk of every wave's stream
  *                     in LDS -- where it fits: graphs without hub states, 8 states and 4 pdfs per thread, aligned rows.
  *                     Measured slower than the default kernel at C3; kept selectable for that record)

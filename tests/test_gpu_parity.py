@@ -126,6 +126,25 @@ def test_nearly_tied_graph_state_splitting(oracle):
 
 
 @pytest.mark.parametrize("width", ["slab_narrow", "slab_wide"])
+def test_streamed_path_one_frame_of_exp_at_a_time(oracle, kernel_family, width):
+    """Beyond 1 GB of transposed exp(y) the streamed path keeps one frame of it and recomputes it in the backward pass;
+    forced here at test sizes (tied and general graphs, Kaldi's accumulate form)."""
+    kernel_family(width)
+    kernel_family("force_streamed")
+    kernel_family("exp_per_frame")
+    _check_full(oracle, synth.random_den_fst(300, 5, 100, seed=32), 3, 11, l2=1e-4, leaky=0.05)
+    _check_full(oracle, synth.skewed_tied_den_fst(400, 7000, 150, seed=8), 2, 9, l2=0.0, leaky=0.1)
+    fst2 = synth.skewed_den_fst(300, 6000, 120, seed=4)
+    _check_full(oracle, fst2, 4, 9, l2=1e-3, leaky=0.1)
+    S, T = 3, 8
+    y = synth.random_nnet_output(S, T, fst2.num_pdfs, seed=9)
+    ref = oracle.den_forward_backward(oracle.DenGraph(fst2), y, S, leaky=0.05, deriv_weight=1.0)
+    out = hip_den(fst2, y, S, leaky=0.05, deriv_weight=1.0, accumulate=True, init=0.5)
+    assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"]) and out["status"] == 0
+    assert rel_err(out["deriv"] - 0.5, ref["deriv"]) <= REL
+
+
+@pytest.mark.parametrize("width", ["slab_narrow", "slab_wide"])
 def test_streamed_path_for_graphs_beyond_lds(oracle, kernel_family, width):
     """Graphs the on-chip layouts cannot hold (more than 16384 states here) take the streamed kernel
     (alpha/beta in global memory, slabs of 16 or 32 sequences); the same kernel forced onto small graphs, tied and

@@ -73,7 +73,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   // streamed path: exp(y) of every frame, transposed once and used by both passes, when that is at most 1 GB
   // (else one frame at a time, recomputed by the backward pass: 2-7 % slower, measured; the cap keeps the workspace
   // of exactly the largest graphs from growing by gigabytes -- include/torchain_hip.h states the sizes)
-  w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)1 << 30) ? T : 1;
+  w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)1 << 30) && !debug_flag(kDbgExpPerFrame) ? T : 1;
   w.big_expy = big_P ? (float *)take((size_t)w.big_exp_frames * Sp * big_P * sizeof(float)) : nullptr;
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_hb, big_P, T, Sp) * sizeof(float)) : nullptr;
