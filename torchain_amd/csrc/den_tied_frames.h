@@ -168,7 +168,6 @@ struct TiedSeq {
           const f4 yv = row_ld(yrow, own16 + v * kPlane, p.y_vec);
           y2 += hsum(yv * yv);
           lds4_st(kPB + 4u * i0, exp4(yv));
-          if (MITM) lds4_st(aGM + 4u * i0, mk4(0.f));  // GAMMA frames: gamma starts at zero
         }
       }
     }
@@ -194,10 +193,10 @@ struct TiedSeq {
     fsec = aACC + 256u * (uint32_t)(K * kWaves + p.fwd.extra_first[wave]);
 #pragma unroll
     for (int i = 0; i < RESF; ++i) load_chunk(fres[i], fbase, lane16, i);
-    // The fused kernel's forward phase does not use the gamma / alpha'_{t+1} / second exp(y) regions: when they hold
+    // A forward phase without gamma does not use the gamma / alpha'_{t+1} / second exp(y) regions: when they hold
     // the two per-state tables (C3: exactly), each thread parks its own entries there and the per-state pass reads
-    // them at LDS latency instead of waiting for L2 every frame.
-    tabs_lds = !MITM && (p.L.off_red - p.L.off_g) >= 2 * Hs;
+    // them at LDS latency instead of waiting for L2 every frame.  (GAMMA frames: forward_unpark first.)
+    tabs_lds = (p.L.off_red - p.L.off_g) >= 2 * Hs;
     aFS = aGM;
     aWS = aGM + 4u * (uint32_t)Hs;
     if (tabs_lds) {
@@ -356,6 +355,17 @@ struct TiedSeq {
       if (MITM) fn[t] = asum;
     }
     inv_prev = __builtin_amdgcn_rcpf(asum);
+  }
+
+  // before the first GAMMA frame: the parked tables give the gamma region back, gamma starts at zero (the caller's
+  // next barrier publishes it)
+  __device__ __forceinline__ void forward_unpark() {
+    tabs_lds = false;
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * ((int)tid + kThreads * v);
+      if (i0 < Ps) lds4_st(aGM + 4u * i0, mk4(0.f));
+    }
   }
 
   // alpha'_t, still in the gather buffer, to its history row (the last frame of a forward phase has no walk behind it)

@@ -82,6 +82,7 @@ __device__ __forceinline__ void mitm_forward(const DenParams &p, const MitmParam
   q.forward_store_row(M);
   publish(mq.sync + 4 + 2 * s, q.tid);
   const bool partner_ok = await(mq.sync + 4 + 2 * s + 1, q.tid, mq.aScr + 4u);
+  q.forward_unpark();  // (await's barrier is behind every wave's last table read; the block sum below publishes the zeros)
   {
     // c_M = 1 / sum_g alpha_M(g) B_M(g);  c^_{M+1} = c_M asum_M / n_M;  B_{M+1} for the next frame
     const rsrc_t bM = make_rsrc(q.bhist + (int64_t)M * q.hist_step, 4u * q.Hs);
