@@ -19,13 +19,18 @@ graph = io.DenominatorGraph(fst, P)
 sup = io.Supervision.from_synth(synth.random_supervision(fst, S, T, 3, seed=7, initial_probs=graph.initial_probs()))
 x = torch.randn(S, P, T, device=dev) if layout3d else torch.randn(S * T, P, device=dev)
 x.requires_grad_(True)
+# XENT=1: with the cross-entropy regulariser of the reference recipe (xent_regularize 0.1, a second output of the net)
+xent = os.environ.get("XENT", "") not in ("", "0")
+kaldi_way = os.environ.get("KALDI_WAY", "1") not in ("", "0")
+xe = torch.randn_like(x).requires_grad_(True) if xent else None
 
 
 def step():
-    loss, res = chain_loss(x, graph, sup, l2_regularize=cfg.get("l2", 0.0), leaky_hmm_coefficient=cfg["leaky"])
+    loss, res = chain_loss(x, graph, sup, l2_regularize=cfg.get("l2", 0.0), leaky_hmm_coefficient=cfg["leaky"],
+                           xent_regularize=0.1 if xent else 0.0, xent_input=xe, kaldi_way=kaldi_way)
     # (the gradient as the model's backward would receive it: loss.backward() into a leaf adds a 629 MB copy or
     # accumulate pass per step that is not part of the path)
-    torch.autograd.grad(loss, x)
+    torch.autograd.grad(loss, [x, xe] if xent else x)
     return res
 
 

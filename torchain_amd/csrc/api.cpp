@@ -28,7 +28,7 @@ struct Workspace {
   uint32_t *pair_sync = nullptr;
   long long *pair_stamps = nullptr;                // ... its diagnostic builds (-DTC_PAIR_STAMPS): raw cycle stamps
   float *alpha_hist;
-  double *den_lp, *num_lp, *y2;
+  double *den_lp, *num_lp, *y2, *xent_lp;
   float *ab, *gs;
   int32_t *fail;
   double *scalar;
@@ -65,6 +65,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair ? 2 : 1)) * S * Hs * sizeof(float));
   w.den_lp = (double *)take((size_t)S * 8);
   w.num_lp = (double *)take((size_t)S * 8);
+  w.xent_lp = (double *)take((size_t)S * 8);
   w.y2 = (double *)take((size_t)S * 8);
   w.ab = (float *)take((size_t)S * 4);
   w.gs = (float *)take((size_t)S * 4);
@@ -402,10 +403,13 @@ int tc_num_forward_backward(tc_supervision *sup, const float *y, int64_t rows, i
 }  // extern "C"
 
 // deriv_scale = 1: the reference's outputs.  deriv_scale = -1: what its backward returns (tc_chain_objf_and_grad).
+// xent_out / xent_objf_dev (tc_chain_step): the cross-entropy output and where sum(xent_out * xent) goes -- formed from
+// the numerator's posteriors as they are written, not from the dense matrices
 static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
                       int64_t y_stride, float *results_dev3, float *deriv, int64_t deriv_stride, float *xent,
                       int64_t xent_stride, float l2_regularize, float leaky, float deriv_scale, float xent_scale,
-                      void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
+                      void *workspace, int64_t workspace_bytes, int device, void *stream_v,
+                      const float *xent_out = nullptr, int64_t xent_out_stride = 0, double *xent_objf_dev = nullptr) {
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
@@ -427,20 +431,33 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   if (rc != TC_OK) return rc;
   np.deriv_scale = deriv_scale;
   np.xent_scale = xent_scale;
+  if (xent && xent_out && xent_objf_dev) {
+    np.xent_out = xent_out;
+    np.xent_out_stride = xent_out_stride;
+    np.seq_xent = w.xent_lp;
+  }
 
+  SideStreams *ss = nullptr;
+  rc = side_streams(stream, &ss);
+  if (rc != TC_OK) return rc;
   if (xent) {
-    if (xent_stride == cols)
+    // xent_deriv is zero outside the numerator's posteriors.  The denominator kernels that write every row of deriv
+    // anyway write these zero rows with them (under their arc walks, where stores cost next to nothing); the others get
+    // a memset in front: 629 MB at C3, 0.13 ms.
+    if (deriv && den_zeroes_xent(dp, ss->num_cus)) {
+      dp.xent_zero = xent;
+      dp.xent_stride = xent_stride;
+      dp.x_vec = (cols % 4 == 0 && xent_stride % 4 == 0 && aligned16(xent)) ? 1 : 0;
+    } else if (xent_stride == cols) {
       TC_HIP_CHECK(hipMemsetAsync(xent, 0, (size_t)rows * cols * sizeof(float), stream));
-    else
+    } else {
       TC_HIP_CHECK(hipMemset2DAsync(xent, (size_t)xent_stride * 4, 0, (size_t)cols * 4, (size_t)rows, stream));
+    }
   }
   // denominator first: it writes every element of deriv (-w*gamma_den - w*l2*y); the numerator then
   // adds its sparse posteriors.  [K] runs the numerator first; the sum is the same.
   // When the denominator leaves CUs idle (small batches) the numerator's recursion runs beside it on a side
   // stream, leaving its posteriors in the supervision's staging area; the scatter follows the denominator.
-  SideStreams *ss = nullptr;
-  rc = side_streams(stream, &ss);
-  if (rc != TC_OK) return rc;
   if ((deriv || xent) && den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
     std::lock_guard<std::recursive_mutex> lock(ss->enqueue);
     np.staged = 1;
@@ -474,6 +491,10 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   rc = launch_finalize(w.den_lp, w.num_lp, w.y2, w.ab, w.gs, sup->S, sup->T, wgt, l2_regularize, deriv != nullptr,
                        results_dev3, w.fail, stream);
   if (rc != TC_OK) return rc;
+  if (np.seq_xent) {
+    rc = launch_xent_total(w.xent_lp, sup->S, w.fail, xent_objf_dev, stream);
+    if (rc != TC_OK) return rc;
+  }
   return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_stride, y, y_stride,
                              deriv_scale * (wgt * l2_regularize), rows, cols, stream);
 }
@@ -564,16 +585,14 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   // 2-D: the matrices leave as the reference's backward returns them (-deriv, -xent_regularize * xent_deriv); 3-D: the
   // sign and the scale ride on the way back through tc_from2d, so the 2-D scratch holds the plain derivatives
   const float dscale = three_d ? 1.0f : -1.0f, xscale = three_d ? 1.0f : -xent_regularize;
+  // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the reference,
+  // torchain/functions.py:88-89): xent_objf_dev receives it times `xscale`, summed by the numerator over the entries it
+  // writes (tc_xent_objf is the dense statement of the same sum)
   rc = chain_objf(g, sup, y, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
-                  w.chain, (int64_t)w.chain_bytes, device, stream_v);
+                  w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent ? xe : nullptr, stride,
+                  use_xent ? xent_objf_dev : nullptr);
   if (rc != TC_OK) return rc;
   if (use_xent) {
-    // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the reference,
-    // torchain/functions.py:88-89) from the matrices at hand: xent_objf_dev receives it times `xscale`
-    if (xent_objf_dev) {
-      rc = tc_xent_objf(xe, rows, P, stride, xg, gstride, xent_objf_dev, w.trace, trace_workspace_bytes(), device, stream_v);
-      if (rc != TC_OK) return rc;
-    }
     if (!kaldi_way) {  // the reference's second call, on xent_input, overwriting results and the MMI gradient (functions.py:96-103)
       rc = chain_objf(g, sup, xe, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
                       w.chain, (int64_t)w.chain_bytes, device, stream_v);

@@ -182,6 +182,12 @@ struct DenParams {
   int S, T, H, P;
   float leaky, deriv_weight, l2_scale;
   int y_vec, d_vec;     // rows 16-byte aligned -> float4 path
+  // The cross-entropy output's derivative is zero outside the numerator's posteriors: kernels that write every
+  // derivative row anyway (den_tied_frames.h) also write its zero rows, so that the objective call needs no memset of
+  // the whole matrix in front of them (629 MB at C3: 0.13 ms).  Null: the caller has zeroed it.
+  float *xent_zero = nullptr;
+  int64_t xent_stride = 0;
+  int x_vec = 0;
   DenLayout L;
   const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
   const float *tied_w;
@@ -304,6 +310,12 @@ struct NumParams {
   // non-zero: the kernel leaves weight * posterior in t.stage instead of adding it to deriv / writing xent, so that
   // it can run beside the denominator (which writes every element of deriv); launch_num_scatter finishes the job
   int staged = 0;
+  // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) has as many non-zero terms as xent_deriv has: the
+  // kernel that writes xent_deriv's entries multiplies each by its xent_output element and leaves the sequence's sum
+  // (double) in seq_xent -- instead of a pass over both dense matrices (1.26 GB at C3).  Null: not wanted.
+  const float *xent_out = nullptr;
+  int64_t xent_out_stride = 0;
+  double *seq_xent = nullptr;  // [S]
   int lds_states, lds_arcs, lds_uniq;
 };
 
@@ -374,6 +386,7 @@ int side_streams(hipStream_t stream, SideStreams **out);  // den_graph.cpp
 void side_streams_forget(hipStream_t stream);              // ... before a caller stream is destroyed
 // CUs a denominator launch of S sequences occupies (two per sequence in the two-CU form, all for the streamed path)
 int den_cus_used(const DenParams &p, int num_cus);
+bool den_zeroes_xent(const DenParams &p, int num_cus);  // whether the kernel launch_den_mode will take honours xent_zero
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
                     int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,
                     hipStream_t stream);
@@ -382,6 +395,7 @@ int launch_zero_on_fail(const int32_t *fail_flag, float *a, int64_t a_stride, fl
 int launch_den_reduce(const double *den_lp, const float *ab, const float *gs, int S, double *logprob_out,
                       int32_t *status_out, hipStream_t stream);
 int launch_sum_double(const double *in, int n, double scale, double *out, hipStream_t stream);
+int launch_xent_total(const double *in, int n, const int32_t *fail_flag, double *out, hipStream_t stream);
 int launch_step_loss(const float *results3, float *loss1, hipStream_t stream);
 int64_t trace_workspace_bytes();
 int launch_trace_mat_mat(const float *a, int64_t a_stride, const float *b, int64_t b_stride, int64_t rows, int cols,

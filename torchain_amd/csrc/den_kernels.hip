@@ -485,6 +485,18 @@ int den_cus_used(const DenParams &p, int num_cus) {
   return p.S < num_cus ? p.S : num_cus;
 }
 
+// The kernels built on den_tied_frames.h's frames with gamma (fused, meet-in-the-middle) write xent_zero's rows next to
+// the derivative's; mirrors launch_den_mode's choice below.
+bool den_zeroes_xent(const DenParams &p, int num_cus) {
+  if (p.big.in.rows || !p.tied_fs || !p.deriv) return false;
+  if ((size_t)layout_lds_bytes(p.L, p.T) > (size_t)kLdsLimitBytes) return false;
+  if (pair_wanted(p, num_cus)) return false;
+  if (split_wanted(p) && 2 * p.S <= num_cus) return mitm_wanted(p);
+  DenParams pq = p;
+  pq.fwd_norm = nullptr;
+  return !rr_fits(pq);
+}
+
 // accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
 int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   if (p.big.in.rows) return launch_den_big(p, accumulate, stream);  // graph beyond the on-chip layout

@@ -139,6 +139,17 @@ struct TiedSeq {
 #endif
   }
 
+  // the cross-entropy output's derivative is zero outside the numerator's posteriors: its row of frame t, written where
+  // the derivative's row of that frame is (DenParams::xent_zero)
+  __device__ __forceinline__ void xent_zero_row(int t) {
+    if (p.xent_zero) {
+      const rsrc_t xrow = make_rsrc(p.xent_zero + ((int64_t)t * S + s) * p.xent_stride, row_bytes);
+#pragma unroll
+      for (int v = 0; v < PV; ++v)
+        if (4 * ((int)tid + kThreads * v) < Ps) row_st(xrow, own16 + v * kPlane, p.x_vec, mk4(0.f));
+    }
+  }
+
   // ================================================================================================== forward
   // ---- t = 0: alpha_0 = pi, alpha'_0 = pi + leaky*pi*sum(pi)   ([K] AlphaFirstFrame + AlphaDash(0)); then the
   // wave's stream: descriptor, row-end masks, resident chunks
@@ -338,6 +349,7 @@ struct TiedSeq {
           row_st(drow, own16 + v * kPlane, p.d_vec, o);
         }
       }
+      xent_zero_row(t - 1);
       chat = c * asum * __builtin_amdgcn_rcpf(n_t);  // c^_{t+1} = c_t asum_t / n_t
     }
     if (t < T) {
@@ -525,6 +537,7 @@ struct TiedSeq {
 #pragma unroll
           for (int v = 0; v < PV; ++v)
             if (4 * ((int)tid + kThreads * v) < Ps) row_st(drow, own16 + v * kPlane, p.d_vec, lds4(pb_next + own16 + v * kPlane));
+          xent_zero_row(t + 1);
         }
       }
     } TC_WALK_PASS);
@@ -628,7 +641,7 @@ struct TiedSeq {
           if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
 #ifndef TC_ABL_NODERIV
           if (kDeferDeriv && t > 0)
-            lds4_st(pb_cur + 4u * i0, o);
+            lds4_st(pb_cur + 4u * i0, o);  // (and the cross-entropy output's zero row with it, under the next walk)
           else
             row_st(drow, own16 + v * kPlane, p.d_vec, o);
 #else
@@ -636,6 +649,7 @@ struct TiedSeq {
 #endif
         }
       }
+      if (!(kDeferDeriv && t > 0)) xent_zero_row(t);
       if (t == 0) {
         // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
         const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);

@@ -36,6 +36,18 @@ __device__ __forceinline__ double log_add(double x, double y) {
 // weight: a few KB) are copied into LDS first.  The T steps are one chain of dependent loads per step -- offsets ->
 // arc ids -> arc fields -> alpha -- and from global memory every link was an L2 round trip: 0.73 us per step, 0.11 ms
 // for 150 frames whatever the batch; from LDS the chain is a fraction of that.
+// the 128 threads' shares of a sequence's cross-entropy objective, added in a fixed order
+__device__ __forceinline__ void seq_xent_sum(double v, double *out, int tid) {
+  __shared__ double xo_sh[128];
+  xo_sh[tid] = v;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 128; ++i) t += xo_sh[i];
+    *out = t;
+  }
+}
+
 template <bool STAGE>
 __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
   // scatter: [K] AddElements(weight, indexes, derivs)
   const int *uniq_begin = p.t.uniq_begin + ub + q;
   const int *uniq_arc = p.t.uniq_arc + ab;
+  double xo = 0.0;
   for (int u = tid; u < nu; u += 128) {
     float sum = 0.f;
     for (int i = uniq_begin[u]; i < uniq_begin[u + 1]; ++i) sum += occ[uniq_arc[i]];
@@ -166,7 +179,9 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
     // -xent_regularize * xent_deriv, formed here instead of in two more passes over the matrices)
     if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
     if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
+    if (p.seq_xent) xo += (double)(p.xent_scale * v) * (double)p.xent_out[row * p.xent_out_stride + pdf];
   }
+  if (p.seq_xent && !p.staged) seq_xent_sum(xo, p.seq_xent + q, tid);
 }
 
 // Second half of a staged numerator: deriv[row, pdf] += weight * posterior, xent_deriv[row, pdf] = it, one owner
@@ -174,13 +189,16 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
 __global__ __launch_bounds__(128) void num_scatter_kernel(const NumParams p) {
   const int q = blockIdx.x, S = p.S;
   const int ub = p.t.seq_uniq_off[q], nu = p.t.seq_uniq_off[q + 1] - ub;
+  double xo = 0.0;
   for (int u = threadIdx.x; u < nu; u += 128) {
     const float v = p.t.stage[ub + u];
     const int64_t row = (int64_t)p.t.uniq_t[ub + u] * S + q;
     const int pdf = p.t.uniq_pdf[ub + u];
     if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
     if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
+    if (p.seq_xent) xo += (double)(p.xent_scale * v) * (double)p.xent_out[row * p.xent_out_stride + pdf];
   }
+  if (p.seq_xent) seq_xent_sum(xo, p.seq_xent + q, threadIdx.x);
 }
 
 int launch_num_scatter(const NumParams &p, hipStream_t stream) {
@@ -361,6 +379,28 @@ __global__ void step_loss_kernel(const float *results3, float *loss1) { loss1[0]
 
 int launch_step_loss(const float *results3, float *loss1, hipStream_t stream) {
   hipLaunchKernelGGL(step_loss_kernel, dim3(1), dim3(1), 0, stream, results3, loss1);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
+
+// the sequences' cross-entropy objective sums (NumParams::seq_xent) -> their total; 0 after a numerical failure, as the
+// zeroed xent_deriv gives
+__global__ __launch_bounds__(256) void xent_total_kernel(const double *in, int n, const int32_t *fail_flag, double *out) {
+  __shared__ double sh[256];
+  const int tid = threadIdx.x;
+  double d = 0;
+  for (int i = tid; i < n; i += 256) d += in[i];
+  sh[tid] = d;
+  __syncthreads();
+  if (tid == 0) {
+    double D = 0;
+    for (int i = 0; i < 256; ++i) D += sh[i];
+    *out = *fail_flag ? 0.0 : D;
+  }
+}
+
+int launch_xent_total(const double *in, int n, const int32_t *fail_flag, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(xent_total_kernel, dim3(1), dim3(256), 0, stream, in, n, fail_flag, out);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
 }
