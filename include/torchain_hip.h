@@ -253,8 +253,11 @@ int tc_chain_objf_and_grad(tc_den_graph *graph, tc_supervision *supervision, con
  *   grad          = -(derivative of the objective w.r.t. input);  xent_grad = -xent_regularize * xent_deriv
  *                   (xent branch: xent_input != NULL and xent_regularize != 0, as in the reference)
  *   results_dev3  : device float[3] {objf, l2_term, weight};  loss_dev1 (nullable): device float[1] = -objf / weight
- *   xent_objf_dev : nullable device double[1] = scale * sum(xent_input * xent_deriv), scale = -xent_regularize for 2-D
- *                   tensors and 1 for (B, C, T) tensors (the matrices it is formed from; the caller divides)
+ *   xent_objf_dev : nullable device double[1] = -xent_regularize * sum(xent_input * xent_deriv) (the sum over xent_grad's
+ *                   entries as they are written; the caller divides).  xent_deriv has entries only where the numerator
+ *                   has posteriors: a (B, C, T) xent_grad is cleared and those entries written in place, xent_input read
+ *                   in place -- no frame-major copies of the two (kaldi_way == 0 still copies xent_input for its
+ *                   second call)
  * Workspace: tc_chain_step_workspace_bytes(graph, B, T, three_d, xent branch).  No host synchronisation. */
 int64_t tc_chain_step_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence,
                                       int three_d, int with_xent);

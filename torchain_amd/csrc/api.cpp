@@ -409,7 +409,8 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
                       int64_t y_stride, float *results_dev3, float *deriv, int64_t deriv_stride, float *xent,
                       int64_t xent_stride, float l2_regularize, float leaky, float deriv_scale, float xent_scale,
                       void *workspace, int64_t workspace_bytes, int device, void *stream_v,
-                      const float *xent_out = nullptr, int64_t xent_out_stride = 0, double *xent_objf_dev = nullptr) {
+                      const float *xent_out = nullptr, int64_t xent_out_stride = 0, double *xent_objf_dev = nullptr,
+                      int xent_bct = 0, int xent_out_bct = 0) {
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
@@ -434,13 +435,15 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   if (xent && xent_out && xent_objf_dev) {
     np.xent_out = xent_out;
     np.xent_out_stride = xent_out_stride;
+    np.xent_out_bct = xent_out_bct;
     np.seq_xent = w.xent_lp;
   }
+  np.xent_bct = xent_bct;  // (a (B, C, T) tensor the caller has cleared: only the posteriors' entries are written)
 
   SideStreams *ss = nullptr;
   rc = side_streams(stream, &ss);
   if (rc != TC_OK) return rc;
-  if (xent) {
+  if (xent && !xent_bct) {
     // xent_deriv is zero outside the numerator's posteriors.  The denominator kernels that write every row of deriv
     // anyway write these zero rows with them (under their arc walks, where stores cost next to nothing); the others get
     // a memset in front: 629 MB at C3, 0.13 ms.
@@ -495,7 +498,8 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
     rc = launch_xent_total(w.xent_lp, sup->S, w.fail, xent_objf_dev, stream);
     if (rc != TC_OK) return rc;
   }
-  return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_stride, y, y_stride,
+  // (a (B, C, T) xent tensor is rows * cols contiguous floats: cleared as such)
+  return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_bct ? (int64_t)cols : xent_stride, y, y_stride,
                              deriv_scale * (wgt * l2_regularize), rows, cols, stream);
 }
 
@@ -524,7 +528,7 @@ int tc_chain_objf_and_grad(tc_den_graph *g, tc_supervision *sup, const float *y,
 namespace {
 struct StepWorkspace {
   char *chain, *trace;
-  float *y2d, *g2d, *x2d, *xg2d;
+  float *y2d, *g2d, *x2d;
   size_t chain_bytes, total;
 };
 StepWorkspace carve_step(char *base, const tc_den_graph *g, int S, int T, int P, bool three_d, bool xent) {
@@ -542,7 +546,6 @@ StepWorkspace carve_step(char *base, const tc_den_graph *g, int S, int T, int P,
   w.y2d = three_d ? (float *)take(mat) : nullptr;
   w.g2d = three_d ? (float *)take(mat) : nullptr;
   w.x2d = three_d && xent ? (float *)take(mat) : nullptr;
-  w.xg2d = three_d && xent ? (float *)take(mat) : nullptr;
   w.total = off;
   return w;
 }
@@ -572,36 +575,44 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   float *gr = grad, *xg = use_xent ? xent_grad : nullptr;
   int64_t stride = row_stride, gstride = P;  // (2-D gradients are written as contiguous matrices)
   int rc = TC_OK;
+  // (B, C, T) with the regulariser: xent_deriv has entries only where the numerator has posteriors, so it is written
+  // straight into the caller's cleared (B, C, T) gradient, and the cross-entropy objective reads xent_input where it
+  // lies -- no frame-major copy of either (the reference's second call, !kaldi_way, still needs xent_input's)
+  const int bct = three_d && use_xent ? 1 : 0;
   if (three_d) {
     rc = tc_to2d(input, S, P, T, w.y2d, P, device, stream_v);
-    if (rc == TC_OK && use_xent) rc = tc_to2d(xent_input, S, P, T, w.x2d, P, device, stream_v);
+    if (rc == TC_OK && use_xent && !kaldi_way) rc = tc_to2d(xent_input, S, P, T, w.x2d, P, device, stream_v);
     if (rc != TC_OK) return rc;
     y = w.y2d;
-    xe = w.x2d;
+    xe = use_xent && !kaldi_way ? w.x2d : xent_input;
     gr = w.g2d;
-    xg = use_xent ? w.xg2d : nullptr;
+    xg = use_xent ? xent_grad : nullptr;
     stride = P;
+    if (use_xent) {
+      DeviceGuard guard(device);
+      if (!guard.ok) return TC_ERR_HIP;
+      TC_HIP_CHECK(hipMemsetAsync(xent_grad, 0, (size_t)rows * P * sizeof(float), stream));
+    }
   }
   // 2-D: the matrices leave as the reference's backward returns them (-deriv, -xent_regularize * xent_deriv); 3-D: the
   // sign and the scale ride on the way back through tc_from2d, so the 2-D scratch holds the plain derivatives
-  const float dscale = three_d ? 1.0f : -1.0f, xscale = three_d ? 1.0f : -xent_regularize;
+  const float dscale = three_d ? 1.0f : -1.0f, xscale = -xent_regularize;  // (the (B, C, T) xent gradient: final values too)
   // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the reference,
   // torchain/functions.py:88-89): xent_objf_dev receives it times `xscale`, summed by the numerator over the entries it
   // writes (tc_xent_objf is the dense statement of the same sum)
   rc = chain_objf(g, sup, y, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
-                  w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent ? xe : nullptr, stride,
-                  use_xent ? xent_objf_dev : nullptr);
+                  w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent ? xent_input : nullptr, row_stride,
+                  use_xent ? xent_objf_dev : nullptr, bct, bct);
   if (rc != TC_OK) return rc;
   if (use_xent) {
     if (!kaldi_way) {  // the reference's second call, on xent_input, overwriting results and the MMI gradient (functions.py:96-103)
       rc = chain_objf(g, sup, xe, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
-                      w.chain, (int64_t)w.chain_bytes, device, stream_v);
+                      w.chain, (int64_t)w.chain_bytes, device, stream_v, nullptr, 0, nullptr, bct, 0);
       if (rc != TC_OK) return rc;
     }
   }
   if (three_d) {
     rc = tc_from2d(gr, P, S, P, T, -1.0f, grad, device, stream_v);
-    if (rc == TC_OK && use_xent) rc = tc_from2d(xg, P, S, P, T, -xent_regularize, xent_grad, device, stream_v);
     if (rc != TC_OK) return rc;
   }
   if (loss_dev1) {

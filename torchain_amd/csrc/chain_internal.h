@@ -316,6 +316,9 @@ struct NumParams {
   const float *xent_out = nullptr;
   int64_t xent_out_stride = 0;
   double *seq_xent = nullptr;  // [S]
+  // non-zero: xent / xent_out are the caller's (B, C, T) tensors, element (sequence, pdf, frame) -- the numerator touches
+  // only its posteriors' entries, so the 3-D call needs no frame-major copy of either (tc_chain_step)
+  int xent_bct = 0, xent_out_bct = 0;
   int lds_states, lds_arcs, lds_uniq;
 };
 

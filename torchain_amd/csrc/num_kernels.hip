@@ -178,8 +178,9 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
     // (scales other than 1 only through tc_chain_objf_and_grad: the reference's backward, -deriv and
     // -xent_regularize * xent_deriv, formed here instead of in two more passes over the matrices)
     if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
-    if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
-    if (p.seq_xent) xo += (double)(p.xent_scale * v) * (double)p.xent_out[row * p.xent_out_stride + pdf];
+    const int64_t bct = ((int64_t)q * p.P + pdf) * p.T + p.t.uniq_t[ub + u];  // (sequence, pdf, frame) of a (B, C, T) tensor
+    if (p.xent) p.xent[p.xent_bct ? bct : row * p.xent_stride + pdf] = p.xent_scale * v;
+    if (p.seq_xent) xo += (double)(p.xent_scale * v) * (double)p.xent_out[p.xent_out_bct ? bct : row * p.xent_out_stride + pdf];
   }
   if (p.seq_xent && !p.staged) seq_xent_sum(xo, p.seq_xent + q, tid);
 }
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(128) void num_scatter_kernel(const NumParams p) {
     const int64_t row = (int64_t)p.t.uniq_t[ub + u] * S + q;
     const int pdf = p.t.uniq_pdf[ub + u];
     if (p.deriv) p.deriv[row * p.deriv_stride + pdf] += p.deriv_scale * v;
-    if (p.xent) p.xent[row * p.xent_stride + pdf] = p.xent_scale * v;
-    if (p.seq_xent) xo += (double)(p.xent_scale * v) * (double)p.xent_out[row * p.xent_out_stride + pdf];
+    const int64_t bct = ((int64_t)q * p.P + pdf) * p.T + p.t.uniq_t[ub + u];  // (sequence, pdf, frame) of a (B, C, T) tensor
+    if (p.xent) p.xent[p.xent_bct ? bct : row * p.xent_stride + pdf] = p.xent_scale * v;
+    if (p.seq_xent) xo += (double)(p.xent_scale * v) * (double)p.xent_out[p.xent_out_bct ? bct : row * p.xent_out_stride + pdf];
   }
   if (p.seq_xent) seq_xent_sum(xo, p.seq_xent + q, threadIdx.x);
 }

@@ -342,7 +342,7 @@ class _ChainStep(Function):
             if use_xent:
                 results._xent_dev = out[4:6].view(torch.float64)
                 results._xent_ready = results._ready
-                results._xent_scale = 1.0 if three_d else 1.0 / -float(xent_regularize)
+                results._xent_scale = 1.0 / -float(xent_regularize)  # (the library's sum is of the scaled gradient, both layouts)
                 results._xent_host = None
         ctx.grads = (grad, xgrad)
         if results._defer_host_copy:
