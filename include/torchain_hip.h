@@ -256,8 +256,9 @@ int tc_chain_objf_and_grad(tc_den_graph *graph, tc_supervision *supervision, con
  *   xent_objf_dev : nullable device double[1] = -xent_regularize * sum(xent_input * xent_deriv) (the sum over xent_grad's
  *                   entries as they are written; the caller divides).  xent_deriv has entries only where the numerator
  *                   has posteriors: a (B, C, T) xent_grad is cleared and those entries written in place, xent_input read
- *                   in place -- no frame-major copies of the two (kaldi_way == 0 still copies xent_input for its
- *                   second call)
+ *                   in place -- no frame-major copies of the two.  kaldi_way == 0: the reference's second call overwrites
+ *                   all the first wrote, so only it is made (on xent_input); the objective here is still that of the
+ *                   first call's xent_deriv (the numerator alone on `input`)
  * Workspace: tc_chain_step_workspace_bytes(graph, B, T, three_d, xent branch).  No host synchronisation. */
 int64_t tc_chain_step_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence,
                                       int three_d, int with_xent);

@@ -577,14 +577,17 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   int rc = TC_OK;
   // (B, C, T) with the regulariser: xent_deriv has entries only where the numerator has posteriors, so it is written
   // straight into the caller's cleared (B, C, T) gradient, and the cross-entropy objective reads xent_input where it
-  // lies -- no frame-major copy of either (the reference's second call, !kaldi_way, still needs xent_input's)
+  // lies -- no frame-major copy of either.
+  // The reference's way (kaldi_way == 0, functions.py:96-103) makes a second objective call on xent_input INTO THE SAME
+  // results, gradient and xent gradient: everything the first call wrote is overwritten.  Only that second call is made
+  // here; what remains of the first is this library's own extra, the cross-entropy objective, which is defined on the
+  // first call's xent_deriv: the numerator alone on `input` (no denominator, nothing written but the sequences' sums).
+  const bool second_only = use_xent && !kaldi_way;
   const int bct = three_d && use_xent ? 1 : 0;
   if (three_d) {
-    rc = tc_to2d(input, S, P, T, w.y2d, P, device, stream_v);
-    if (rc == TC_OK && use_xent && !kaldi_way) rc = tc_to2d(xent_input, S, P, T, w.x2d, P, device, stream_v);
+    rc = second_only ? tc_to2d(xent_input, S, P, T, w.x2d, P, device, stream_v) : tc_to2d(input, S, P, T, w.y2d, P, device, stream_v);
     if (rc != TC_OK) return rc;
-    y = w.y2d;
-    xe = use_xent && !kaldi_way ? w.x2d : xent_input;
+    y = second_only ? w.x2d : w.y2d;
     gr = w.g2d;
     xg = use_xent ? xent_grad : nullptr;
     stride = P;
@@ -593,23 +596,42 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
       if (!guard.ok) return TC_ERR_HIP;
       TC_HIP_CHECK(hipMemsetAsync(xent_grad, 0, (size_t)rows * P * sizeof(float), stream));
     }
+  } else if (second_only) {
+    y = xent_input;
   }
+  (void)xe;
   // 2-D: the matrices leave as the reference's backward returns them (-deriv, -xent_regularize * xent_deriv); 3-D: the
-  // sign and the scale ride on the way back through tc_from2d, so the 2-D scratch holds the plain derivatives
+  // MMI gradient's sign rides on the way back through tc_from2d, so the 2-D scratch holds the plain derivative
   const float dscale = three_d ? 1.0f : -1.0f, xscale = -xent_regularize;  // (the (B, C, T) xent gradient: final values too)
   // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the reference,
   // torchain/functions.py:88-89): xent_objf_dev receives it times `xscale`, summed by the numerator over the entries it
   // writes (tc_xent_objf is the dense statement of the same sum)
+  const Workspace wi = carve((char *)w.chain, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
+  if (second_only && xent_objf_dev) {
+    DeviceGuard guard(device);
+    if (!guard.ok) return TC_ERR_HIP;
+    NumParams np;
+    rc = fill_num_params(sup, device, stream, input, rows, P, three_d ? (int64_t)P : row_stride, nullptr, 0, nullptr, 0, wi.num_lp, &np);
+    if (rc != TC_OK) return rc;
+    np.y_bct = three_d ? 1 : 0;
+    np.xent_scale = xscale;
+    np.xent_out = xent_input;
+    np.xent_out_stride = row_stride;
+    np.xent_out_bct = three_d ? 1 : 0;
+    np.seq_xent = wi.xent_lp;
+    rc = launch_num(np, stream);
+    if (rc == TC_OK) rc = supervision_mark_use(sup, device, stream);
+    if (rc != TC_OK) return rc;
+  }
   rc = chain_objf(g, sup, y, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
-                  w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent ? xent_input : nullptr, row_stride,
-                  use_xent ? xent_objf_dev : nullptr, bct, bct);
+                  w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent && !second_only ? xent_input : nullptr, row_stride,
+                  use_xent && !second_only ? xent_objf_dev : nullptr, bct, bct);
   if (rc != TC_OK) return rc;
-  if (use_xent) {
-    if (!kaldi_way) {  // the reference's second call, on xent_input, overwriting results and the MMI gradient (functions.py:96-103)
-      rc = chain_objf(g, sup, xe, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
-                      w.chain, (int64_t)w.chain_bytes, device, stream_v, nullptr, 0, nullptr, bct, 0);
-      if (rc != TC_OK) return rc;
-    }
+  if (second_only && xent_objf_dev) {
+    DeviceGuard guard(device);
+    if (!guard.ok) return TC_ERR_HIP;
+    rc = launch_xent_total(wi.xent_lp, S, wi.fail, xent_objf_dev, stream);
+    if (rc != TC_OK) return rc;
   }
   if (three_d) {
     rc = tc_from2d(gr, P, S, P, T, -1.0f, grad, device, stream_v);

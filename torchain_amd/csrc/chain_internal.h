@@ -318,7 +318,7 @@ struct NumParams {
   double *seq_xent = nullptr;  // [S]
   // non-zero: xent / xent_out are the caller's (B, C, T) tensors, element (sequence, pdf, frame) -- the numerator touches
   // only its posteriors' entries, so the 3-D call needs no frame-major copy of either (tc_chain_step)
-  int xent_bct = 0, xent_out_bct = 0;
+  int xent_bct = 0, xent_out_bct = 0, y_bct = 0;  // (y is read at the supervision's (frame, pdf) pairs only)
   int lds_states, lds_arcs, lds_uniq;
 };
 

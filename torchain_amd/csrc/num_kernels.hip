@@ -101,11 +101,12 @@ __global__ __launch_bounds__(128) void num_fwd_bwd_kernel(const NumParams p) {
   auto arc_uniq = [&](int a) __attribute__((always_inline)) { return STAGE ? s_uq[a] : g_arc_uniq[a]; };
   auto arc_logw = [&](int a) __attribute__((always_inline)) { return STAGE ? s_lw[a] : g_arc_logw[a]; };
   const float *final_logw = p.t.final_logw + sb;
-  const bool want_beta = p.deriv != nullptr || p.xent != nullptr;
+  const bool want_beta = p.deriv != nullptr || p.xent != nullptr || p.seq_xent != nullptr;
 
   // gather: [K] nnet_output_.Lookup(nnet_output_indexes_, ...); row = t*S + q
   for (int u = tid; u < nu; u += 128)
-    ylp[u] = p.y[((int64_t)p.t.uniq_t[ub + u] * S + q) * p.y_stride + p.t.uniq_pdf[ub + u]];
+    ylp[u] = p.y_bct ? p.y[((int64_t)q * p.P + p.t.uniq_pdf[ub + u]) * T + p.t.uniq_t[ub + u]]
+                     : p.y[((int64_t)p.t.uniq_t[ub + u] * S + q) * p.y_stride + p.t.uniq_pdf[ub + u]];
   for (int i = tid; i < nst; i += 128) {
     log_alpha[i] = i == 0 ? 0.0 : -INFINITY;
     log_beta[i] = -INFINITY;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(128) void num_scatter_kernel(const NumParams p) {
 }
 
 int launch_num_scatter(const NumParams &p, hipStream_t stream) {
-  if (!p.deriv && !p.xent) return TC_OK;
+  if (!p.deriv && !p.xent && !p.seq_xent) return TC_OK;
   hipLaunchKernelGGL(num_scatter_kernel, dim3(p.S), dim3(128), 0, stream, p);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
