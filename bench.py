@@ -133,7 +133,23 @@ def extras(graph, fst, cfg, S, T, P, dev):
         finally:
             lib.tc_debug_set(b"no_phase_split", 0)
 
-    out = {"full_objective_ms": full, "objf_per_frame": float(res.data[0] / res.data[2]),
+    # the training-side step as the reference's recipe makes it: chain_loss + backward on a (B, C, T) output, with and
+    # without the cross-entropy regulariser (xent_regularize 0.1, a second output), kaldi_way and the reference's default
+    from torchain_amd.functions import chain_loss
+
+    def train_step(xent, kaldi_way):
+        a = x.detach().clone().requires_grad_(True)
+        b = torch.randn_like(a).requires_grad_(True) if xent else None
+
+        def step():
+            loss, _res = chain_loss(a, graph, hsup, cfg.get("l2", 0.0), cfg["leaky"], 0.1 if xent else 0.0, b, kaldi_way)
+            torch.autograd.grad(loss, [a, b] if xent else a)
+        return timeit(step, n=20, warm=8)
+
+    steps = {"train_step_bct_ms": train_step(False, True), "train_step_bct_xent_kaldi_way_ms": train_step(True, True),
+             "train_step_bct_xent_reference_way_ms": train_step(True, False)}
+
+    out = {"full_objective_ms": full, "objf_per_frame": float(res.data[0] / res.data[2]), **steps,
            "batch64_den_ms": den_ms(64, False), "batch64_den_fused_kernel_ms": den_ms(64, True),
            "to2d_hip_ms": timeit(lambda: to2d_hip(x)), "to2d_torch_ms": timeit(lambda: to2d(x)),
            "from2d_neg_hip_ms": timeit(lambda: from2d_hip(y, (S, P, T), -1.0)),
