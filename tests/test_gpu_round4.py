@@ -286,3 +286,38 @@ def test_two_ranks_fed_from_the_native_reader(tmp_path):
     full = [" ".join(whole.batch_keys(i)) for i in range(whole.n_batch)]
     got = [open(str(tmp_path / ("keys%d.txt" % k))).read().split("\n")[:-1] for k in range(2)]
     assert got[0] == full[0::2] and got[1] == full[1::2]
+
+
+@pytest.mark.parametrize("three_d", [True, False])
+@pytest.mark.parametrize("kaldi_way", [True, False])
+def test_one_call_step_numerical_failure_is_soft(three_d, kaldi_way):
+    """[K] NaN objf -> objf = -10 * weight, the MMI derivative is the l2 term alone, xent_deriv zero -- through
+    ``tc_chain_step``'s own ways of clearing the cross-entropy gradient (zero rows written by the denominator kernel, a
+    cleared (B, C, T) tensor with entries written in place, the single call of the reference's two-call form) and with
+    its cross-entropy objective, which must be that of a zero xent_deriv."""
+    from torchain_amd.functions import chain_loss
+    fst = synth.random_den_fst(300, 4, 96, seed=4)
+    S, T, P = 5, 11, 96
+    den = io.DenominatorGraph(fst, P)
+    sup = synth.random_supervision(fst, S, T, 3, seed=2, initial_probs=den.initial_probs())
+    hsup = io.Supervision.from_synth(sup)
+    y = synth.random_nnet_output(S, T, P, seed=6)
+    xe = synth.random_nnet_output(S, T, P, seed=7)
+    (xe if not kaldi_way else y)[17, 5] = np.nan  # (the reference's way evaluates the objective on xent_input)
+    a, b = torch.from_numpy(y).cuda(), torch.from_numpy(xe).cuda()
+    if three_d:
+        a = a.reshape(T, S, P).permute(1, 2, 0).contiguous()
+        b = b.reshape(T, S, P).permute(1, 2, 0).contiguous()
+    a.requires_grad_(True)
+    b.requires_grad_(True)
+    l2 = 1e-3
+    loss, res = chain_loss(a, den, hsup, l2, 0.05, 0.1, b, kaldi_way)
+    loss.backward()
+    assert float(res.data[0]) == -10.0 * S * T and float(res.data[2]) == S * T
+    src = b if not kaldi_way else a  # the tensor the objective was evaluated on
+    finite = torch.isfinite(src.detach())
+    # backward returns -deriv = +weight * l2 * output where the output is finite
+    want = (sup.weight * l2) * src.detach()
+    assert torch.allclose(a.grad[finite], want[finite], rtol=1e-6, atol=0)
+    assert torch.count_nonzero(b.grad) == 0
+    assert res.xent_objf == 0.0
