@@ -403,6 +403,10 @@ int tc_num_forward_backward(tc_supervision *sup, const float *y, int64_t rows, i
 }  // extern "C"
 
 // deriv_scale = 1: the reference's outputs.  deriv_scale = -1: what its backward returns (tc_chain_objf_and_grad).
+// bct_input (tc_chain_step, (B, C, T) tensors): `y` is scratch that this call fills from bct_input (tc_to2d) in front of the
+// denominator; the numerator, which reads y at the supervision's (frame, pdf) pairs only, reads bct_input where it lies
+// and runs BESIDE that copy and the denominator on the side stream (its posteriors wait in the supervision's staging
+// area for the scatter behind the denominator, as for small batches).
 // xent_out / xent_objf_dev (tc_chain_step): the cross-entropy output and where sum(xent_out * xent) goes -- formed from
 // the numerator's posteriors as they are written, not from the dense matrices
 static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int64_t rows, int32_t cols,
@@ -410,7 +414,7 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
                       int64_t xent_stride, float l2_regularize, float leaky, float deriv_scale, float xent_scale,
                       void *workspace, int64_t workspace_bytes, int device, void *stream_v,
                       const float *xent_out = nullptr, int64_t xent_out_stride = 0, double *xent_objf_dev = nullptr,
-                      int xent_bct = 0, int xent_out_bct = 0) {
+                      int xent_bct = 0, int xent_out_bct = 0, const float *bct_input = nullptr) {
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
@@ -439,6 +443,13 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
     np.seq_xent = w.xent_lp;
   }
   np.xent_bct = xent_bct;  // (a (B, C, T) tensor the caller has cleared: only the posteriors' entries are written)
+  if (bct_input) {
+    np.y = bct_input;
+    np.y_bct = 1;
+  }
+  auto fill_y = [&]() -> int {  // the frame-major copy the denominator reads
+    return bct_input ? launch_layout(true, bct_input, const_cast<float *>(y), sup->S, cols, sup->T, y_stride, 1.0f, stream) : TC_OK;
+  };
 
   SideStreams *ss = nullptr;
   rc = side_streams(stream, &ss);
@@ -461,12 +472,13 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   // adds its sparse posteriors.  [K] runs the numerator first; the sum is the same.
   // When the denominator leaves CUs idle (small batches) the numerator's recursion runs beside it on a side
   // stream, leaving its posteriors in the supervision's staging area; the scatter follows the denominator.
-  if ((deriv || xent) && den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
+  if ((deriv || xent) && (bct_input || den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus) && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
     std::lock_guard<std::recursive_mutex> lock(ss->enqueue);
     np.staged = 1;
     TC_HIP_CHECK(hipEventRecord(ss->num_fork, stream));
     TC_HIP_CHECK(hipStreamWaitEvent(ss->num_side, ss->num_fork, 0));
     rc = launch_num(np, ss->num_side);
+    if (rc == TC_OK) rc = fill_y();
     if (rc == TC_OK) rc = launch_den(dp, stream);
     // Join the side stream also when something failed after the fork: the caller sees an error and may free or reuse
     // the workspace and the supervision, which the numerator kernel could still be reading or writing -- and the
@@ -484,7 +496,8 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
       return rc;
     }
   } else {
-    rc = launch_den(dp, stream);
+    rc = fill_y();
+    if (rc == TC_OK) rc = launch_den(dp, stream);
     if (rc != TC_OK) return rc;
     rc = launch_num(np, stream);
     if (rc != TC_OK) return rc;
@@ -585,9 +598,7 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   const bool second_only = use_xent && !kaldi_way;
   const int bct = three_d && use_xent ? 1 : 0;
   if (three_d) {
-    rc = second_only ? tc_to2d(xent_input, S, P, T, w.x2d, P, device, stream_v) : tc_to2d(input, S, P, T, w.y2d, P, device, stream_v);
-    if (rc != TC_OK) return rc;
-    y = second_only ? w.x2d : w.y2d;
+    y = second_only ? w.x2d : w.y2d;  // (filled inside chain_objf, beside the numerator: bct_input)
     gr = w.g2d;
     xg = use_xent ? xent_grad : nullptr;
     stride = P;
@@ -625,7 +636,8 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   }
   rc = chain_objf(g, sup, y, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
                   w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent && !second_only ? xent_input : nullptr, row_stride,
-                  use_xent && !second_only ? xent_objf_dev : nullptr, bct, bct);
+                  use_xent && !second_only ? xent_objf_dev : nullptr, bct, bct,
+                  three_d ? (second_only ? xent_input : input) : nullptr);
   if (rc != TC_OK) return rc;
   if (second_only && xent_objf_dev) {
     DeviceGuard guard(device);
