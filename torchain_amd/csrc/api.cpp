@@ -414,7 +414,8 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
                       int64_t xent_stride, float l2_regularize, float leaky, float deriv_scale, float xent_scale,
                       void *workspace, int64_t workspace_bytes, int device, void *stream_v,
                       const float *xent_out = nullptr, int64_t xent_out_stride = 0, double *xent_objf_dev = nullptr,
-                      int xent_bct = 0, int xent_out_bct = 0, const float *bct_input = nullptr) {
+                      int xent_bct = 0, int xent_out_bct = 0, const float *bct_input = nullptr,
+                      bool xent_sums_ready = false, float *loss_dev1 = nullptr) {
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
@@ -505,12 +506,9 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   rc = supervision_mark_use(sup, device, stream);
   if (rc != TC_OK) return rc;
   rc = launch_finalize(w.den_lp, w.num_lp, w.y2, w.ab, w.gs, sup->S, sup->T, wgt, l2_regularize, deriv != nullptr,
-                       results_dev3, w.fail, stream);
+                       results_dev3, w.fail, stream, (np.seq_xent || xent_sums_ready) && xent_objf_dev ? w.xent_lp : nullptr,
+                       xent_objf_dev, loss_dev1);
   if (rc != TC_OK) return rc;
-  if (np.seq_xent) {
-    rc = launch_xent_total(w.xent_lp, sup->S, w.fail, xent_objf_dev, stream);
-    if (rc != TC_OK) return rc;
-  }
   // (a (B, C, T) xent tensor is rows * cols contiguous floats: cleared as such)
   return launch_zero_on_fail(w.fail, deriv, deriv_stride, xent, xent_bct ? (int64_t)cols : xent_stride, y, y_stride,
                              deriv_scale * (wgt * l2_regularize), rows, cols, stream);
@@ -636,25 +634,14 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   }
   rc = chain_objf(g, sup, y, rows, P, stride, results_dev3, gr, gstride, xg, gstride, l2_regularize, leaky, dscale, xscale,
                   w.chain, (int64_t)w.chain_bytes, device, stream_v, use_xent && !second_only ? xent_input : nullptr, row_stride,
-                  use_xent && !second_only ? xent_objf_dev : nullptr, bct, bct,
-                  three_d ? (second_only ? xent_input : input) : nullptr);
+                  use_xent ? xent_objf_dev : nullptr, bct, bct, three_d ? (second_only ? xent_input : input) : nullptr,
+                  second_only && xent_objf_dev != nullptr, loss_dev1);
   if (rc != TC_OK) return rc;
-  if (second_only && xent_objf_dev) {
-    DeviceGuard guard(device);
-    if (!guard.ok) return TC_ERR_HIP;
-    rc = launch_xent_total(wi.xent_lp, S, wi.fail, xent_objf_dev, stream);
-    if (rc != TC_OK) return rc;
-  }
   if (three_d) {
     rc = tc_from2d(gr, P, S, P, T, -1.0f, grad, device, stream_v);
     if (rc != TC_OK) return rc;
   }
-  if (loss_dev1) {
-    DeviceGuard guard(device);
-    if (!guard.ok) return TC_ERR_HIP;
-    rc = launch_step_loss(results_dev3, loss_dev1, stream);
-  }
-  return rc;
+  return rc;  // (the loss value -objf / weight was written with the results: finalize_kernel)
 }
 
 int tc_xent_objf(const float *xent_output, int64_t rows, int32_t cols, int64_t output_stride, const float *xent_deriv,

@@ -392,7 +392,8 @@ int den_cus_used(const DenParams &p, int num_cus);
 bool den_zeroes_xent(const DenParams &p, int num_cus);  // whether the kernel launch_den_mode will take honours xent_zero
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
                     int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,
-                    hipStream_t stream);
+                    hipStream_t stream, const double *xent_lp = nullptr, double *xent_total = nullptr,
+                    float *loss_out = nullptr);
 int launch_zero_on_fail(const int32_t *fail_flag, float *a, int64_t a_stride, float *b, int64_t b_stride,
                         const float *y, int64_t y_stride, float l2_scale, int64_t rows, int cols, hipStream_t stream);
 int launch_den_reduce(const double *den_lp, const float *ab, const float *gs, int S, double *logprob_out,

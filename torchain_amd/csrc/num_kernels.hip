@@ -232,10 +232,11 @@ int launch_num(const NumParams &p, hipStream_t stream) {
 __global__ __launch_bounds__(256) void finalize_kernel(const double *den_lp, const double *num_lp, const double *y2,
                                                        const float *ab, const float *gs, int S, int T,
                                                        float sup_weight, float l2, int have_deriv, float *results,
-                                                       int32_t *fail_flag) {
+                                                       int32_t *fail_flag, const double *xent_lp, double *xent_total,
+                                                       float *loss_out) {
   __shared__ double sh[4][256];
   const int tid = threadIdx.x;
-  double d = 0, n = 0, q = 0, a = 0, g = 0;
+  double d = 0, n = 0, q = 0, a = 0, g = 0, x = 0;
   // fixed-order partial sums: thread i takes sequences i, i+256, ... (deterministic)
   for (int s = tid; s < S; s += 256) {
     d += den_lp[s];
@@ -245,23 +246,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *den_lp, con
       a += (double)ab[s];
       g += (double)gs[s];
     }
+    if (xent_lp) x += xent_lp[s];
   }
   sh[0][tid] = d;
   sh[1][tid] = n;
   sh[2][tid] = q;
   sh[3][tid] = a;
   __syncthreads();
-  __shared__ double sh_g[256];
+  __shared__ double sh_g[256], sh_x[256];
   sh_g[tid] = g;
+  sh_x[tid] = x;
   __syncthreads();
   if (tid == 0) {
-    double D = 0, N = 0, Q = 0, A = 0, G = 0;
+    double D = 0, N = 0, Q = 0, A = 0, G = 0, X = 0;
     for (int i = 0; i < 256; ++i) {
       D += sh[0][i];
       N += sh[1][i];
       Q += sh[2][i];
       A += sh[3][i];
       G += sh_g[i];
+      X += sh_x[i];
     }
     const float num_logprob_weighted = (float)(N * (double)sup_weight);
     const float den_logprob = (float)D;
@@ -284,14 +288,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(const double *den_lp, con
     results[1] = l2_term;
     results[2] = weight;
     *fail_flag = fail;
+    // tc_chain_step's two scalars ride along: the sequences' cross-entropy objective sums (NumParams::seq_xent; 0 after
+    // a numerical failure, as the zeroed xent_deriv gives) and the loss -objf / weight (torchain/functions.py:104)
+    if (xent_total) *xent_total = fail ? 0.0 : X;
+    if (loss_out) loss_out[0] = -objf / weight;
   }
 }
 
 int launch_finalize(const double *den_lp, const double *num_lp, const double *y2, const float *ab, const float *gs,
                     int S, int T, float sup_weight, float l2, int have_deriv, float *results, int32_t *fail_flag,
-                    hipStream_t stream) {
+                    hipStream_t stream, const double *xent_lp, double *xent_total, float *loss_out) {
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, stream, den_lp, num_lp, y2, ab, gs, S, T, sup_weight, l2,
-                     have_deriv, results, fail_flag);
+                     have_deriv, results, fail_flag, xent_lp, xent_total, loss_out);
   TC_HIP_CHECK(hipGetLastError());
   return TC_OK;
 }
