@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -471,24 +472,82 @@ struct tc_example {
   Example eg;
 };
 
+namespace {
+// A minibatch is ~5 MB of vectors: allocated fresh for every batch they come from mmap and are paged in (and zeroed by
+// the kernel) while they are filled -- a third of the reader's time.  Freed examples wait here, emptied but with their
+// capacity, for the next read (a handful: the batches a training loop has in flight).
+constexpr size_t kExamplePoolMax = 12;
+struct ExamplePool {
+  std::mutex mu;
+  std::vector<tc_example *> v;
+  bool closed = false;  // (an example freed after this object: process teardown)
+  ~ExamplePool() {
+    std::lock_guard<std::mutex> lock(mu);
+    closed = true;
+    for (tc_example *ex : v) delete ex;
+    v.clear();
+  }
+} g_examples;
+
+void empty_example(Example *eg) {
+  for (Io &io : eg->in) {
+    io.name.clear();
+    io.idx.clear();
+    io.feat.clear();
+    io.rows = io.cols = 0;
+  }
+  for (Out &o : eg->out) {
+    o.name.clear();
+    o.idx.clear();
+    o.dw.clear();
+    o.sup.ab.clear();
+    o.sup.il.clear();
+    o.sup.nx.clear();
+    o.sup.w.clear();
+    o.sup.fin.clear();
+    o.sup.nstates = 0;
+  }
+}
+
+tc_example *pool_take() {
+  std::lock_guard<std::mutex> lock(g_examples.mu);
+  if (g_examples.closed || g_examples.v.empty()) return nullptr;
+  tc_example *ex = g_examples.v.back();
+  g_examples.v.pop_back();
+  return ex;
+}
+}  // namespace
+
 extern "C" {
 
 int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n, int merge_single, tc_example **out) {
   if (!paths || !out || n <= 0) return TC_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   g_example_error.clear();
-  std::vector<Example> egs((size_t)n);
+  // (per-thread scratch for the batch's examples, kept between calls: their vectors are refilled, not reallocated; the
+  // entries of a batch mostly name one archive: one FILE while consecutive entries do)
+  static thread_local std::vector<Example> egs;
+  egs.resize((size_t)n);
+  struct Closer {
+    std::FILE *f = nullptr;
+    ~Closer() {
+      if (f) std::fclose(f);
+    }
+  } open;
+  const char *open_path = nullptr;
   try {
     for (int32_t i = 0; i < n; ++i) {
-      std::FILE *f = paths[i] ? std::fopen(paths[i], "rb") : nullptr;
+      // (an entry without an offset reads from the start of a freshly opened file, which may not be seekable)
+      if (!(open.f && open_path && paths[i] && offsets && offsets[i] >= 0 && std::strcmp(open_path, paths[i]) == 0)) {
+        if (open.f) std::fclose(open.f);
+        open.f = paths[i] ? std::fopen(paths[i], "rb") : nullptr;
+        open_path = paths[i];
+      }
+      std::FILE *f = open.f;
       if (!f) {
         g_example_error = std::string("cannot open ") + (paths[i] ? paths[i] : "(null)");
         return TC_ERR_IO;
       }
-      struct Closer {
-        std::FILE *f;
-        ~Closer() { std::fclose(f); }
-      } closer{f};
       if (offsets && offsets[i] >= 0 && fseeko(f, (off_t)offsets[i], SEEK_SET) != 0) {
         g_example_error = "cannot seek";
         return TC_ERR_IO;
@@ -507,9 +566,10 @@ int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n,
     return TC_ERR_IO;
   }
   try {
-    tc_example *ex = new tc_example();
+    tc_example *ex = pool_take();
+    if (!ex) ex = new tc_example();
     if (n == 1 && !merge_single) {
-      ex->eg = std::move(egs[0]);
+      ex->eg = egs[0];  // (a copy: the scratch keeps its buffers)
     } else {
       const int rc = merge(egs, &ex->eg);
       if (rc != TC_OK) {
@@ -527,7 +587,18 @@ int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n,
   return TC_OK;
 }
 
-void tc_example_free(tc_example *ex) { delete ex; }
+void tc_example_free(tc_example *ex) {
+  if (!ex) return;
+  empty_example(&ex->eg);
+  {
+    std::lock_guard<std::mutex> lock(g_examples.mu);
+    if (!g_examples.closed && g_examples.v.size() < kExamplePoolMax) {
+      g_examples.v.push_back(ex);
+      return;
+    }
+  }
+  delete ex;
+}
 
 // ---- sequential archives ("ark:file", "ark:command |"): key SPACE \0B object, one after the other
 struct tc_archive {
