@@ -90,7 +90,8 @@ for _ in range(40):
     step(fixed)
 torch.cuda.synchronize()
 print("same supervision every step:        %.3f ms/step" % ((time.perf_counter() - t0) / 40 * 1e3))
-for label, prefetch in (("RandExample, 8 look-ahead threads: ", True), ("RandExample, 4 look-ahead threads: ", 4),
+for label, prefetch in (("RandExample, 8 look-ahead threads: ", 8), ("RandExample, 4 look-ahead threads: ", 4),
+                        ("RandExample, 3 (the default):      ", True), ("RandExample, 2 look-ahead threads: ", 2),
                         ("RandExample, 1 look-ahead thread:  ", 1), ("RandExample, synchronous:          ", False)):
     rd = io.RandExample(scp, seed=1, batchsize=batch, prefetch=prefetch)
     epochs(rd, 1)

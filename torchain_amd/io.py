@@ -344,7 +344,10 @@ class RandExample(Example):
         self._native = None
         if native:
             handle = C.c_void_p()
-            depth = (8 if prefetch is True else int(prefetch)) if prefetch else 0
+            # (True = 3 look-ahead threads: a batch of 64 x 150 frames costs one of them ~1.5 ms, a step 0.7 ms; with more
+            # the training thread's own enqueue slows down -- 0.11 ms beside two readers, 0.39 beside four, 0.47 beside
+            # eight on the test box -- and the step with it: profiles/r04_egs_steps.txt)
+            depth = (3 if prefetch is True else int(prefetch)) if prefetch else 0
             rc = lib.tc_rand_reader_new(os.fsencode(scp_path), int(seed), int(batchsize), os.fsencode(len_file or ""),
                                         int(rank), int(world), depth, C.byref(handle))
             if rc != 0:
