@@ -71,7 +71,7 @@ struct ScheduleHost {
   std::vector<int32_t> fix_begin;  // kThreads + 1: range of fix-up entries owned by each thread
   std::vector<int2> fix;           // {state, extra slot}
   int32_t extra_slots = 0;         // accumulator slots beyond Hs + 4
-  int64_t conflict_cost = 0, conflict_free_cost = 0;  // LDS cycles of the arc gathers: as placed / if conflict-free
+  int64_t conflict_cost = 0, conflict_free_cost = 0, conflict_bound = 0;  // LDS cycles of the arc gathers: as placed / if conflict-free
   int64_t real_arcs = 0, padded_arcs = 0;
   int32_t rows = 0;
   // owner-computes schedules of tied graphs (schedule_owner.cpp: build_owner)
@@ -342,6 +342,11 @@ bool make_work_graph(tc_den_graph *g);                                          
 bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row);      // schedule_owner.cpp
 int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
                  const int32_t *pdf, std::vector<std::vector<int>> *pos_out);          // den_layout.cpp
+// ... one gather per cell (tied schedules): step by step, a matching of lanes to banks that keeps the half-slot on its
+// lower bound max(steps, most loaded bank).  pad_bank[l][k]: the bank a padding cell should gather from.
+int arrange_half_matching(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
+                          std::vector<std::vector<int>> *pos_out, std::vector<std::vector<int>> *pad_bank,
+                          int *lower_bound);                                           // den_layout.cpp
 inline int round4(int x) { return (x + 3) & ~3; }
 bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L);
 int64_t layout_lds_bytes(const DenLayout &L, int T);
@@ -411,7 +416,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

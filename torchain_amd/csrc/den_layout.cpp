@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
 
@@ -185,6 +186,144 @@ int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, 
     }
   }
   *pos_out = pos;
+  return total;
+}
+
+// The same problem for schedules with ONE gather per cell (tied graphs), solved step by step as a matching problem.
+// A half-slot is a bipartite multigraph lanes x banks; it cannot take fewer than D = max(steps, most loaded bank)
+// LDS cycles, and it takes exactly D when every step of cost c (c lanes on its busiest bank) lowers that bound by c:
+// the step must serve every lane that has no slack left, and every bank b at least load(b) - (D - c) times.  Both are
+// degree constraints of a bipartite b-matching (lanes capacity 1, banks capacity c), found with augmenting paths --
+// first from the bank slots that must be filled, then from the lanes that must move (an augmenting path keeps every
+// matched vertex matched).  When no step of any cost keeps the bound, the step that loses least is taken.  (The greedy
+// placement above spreads a heavy bank's surplus over the steps one conflict at a time, wherever it meets another
+// lane; the bound needs the surpluses of different banks to fall into the SAME steps.)
+int arrange_half_matching(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
+                          std::vector<std::vector<int>> *pos_out, std::vector<std::vector<int>> *pad_bank, int *lower_bound) {
+  const int L = (int)lane_arcs.size();
+  constexpr int NB = 32, CAP = 64;
+  std::vector<std::array<std::vector<int>, NB>> by_bank(L);
+  std::vector<int> rem(L);
+  int d[NB] = {0};
+  for (int l = 0; l < L; ++l) {
+    rem[l] = (int)lane_arcs[l].size();
+    for (int i = 0; i < rem[l]; ++i) {
+      const int b = other[lane_arcs[l][i]] & (NB - 1);
+      by_bank[l][b].push_back(i);
+      d[b]++;
+    }
+  }
+  std::vector<std::vector<int>> pos(L, std::vector<int>(steps, -1)), padb(L, std::vector<int>(steps, 0));
+  if (lower_bound) *lower_bound = std::max(steps, *std::max_element(d, d + NB));
+  std::vector<int> match_lane(L), match_slot(NB * CAP);
+  std::vector<char> vis_lane(L), vis_slot(NB * CAP);
+  int c = 1;
+  // slot s = bank * CAP + i, i < c
+  std::function<bool(int)> try_slot = [&](int s) -> bool {  // a free slot looks for a lane
+    const int b = s / CAP;
+    for (int l = 0; l < L; ++l) {
+      if (vis_lane[l] || by_bank[l][b].empty()) continue;
+      if (match_lane[l] >= 0 && match_lane[l] / CAP == b) continue;
+      vis_lane[l] = 1;
+      if (match_lane[l] < 0 || try_slot(match_lane[l])) {
+        match_lane[l] = s;
+        match_slot[s] = l;
+        return true;
+      }
+    }
+    return false;
+  };
+  std::function<bool(int)> try_lane = [&](int l) -> bool {  // a free lane looks for a slot
+    for (int pass = 0; pass < 2; ++pass)  // free slots first
+      for (int b = 0; b < NB; ++b) {
+        if (by_bank[l][b].empty()) continue;
+        for (int i = 0; i < c; ++i) {
+          const int s = b * CAP + i;
+          if (pass == 0) {
+            if (match_slot[s] < 0) {
+              match_slot[s] = l;
+              match_lane[l] = s;
+              return true;
+            }
+            continue;
+          }
+          if (vis_slot[s] || match_slot[s] < 0) continue;
+          vis_slot[s] = 1;
+          if (try_lane(match_slot[s])) {
+            match_slot[s] = l;
+            match_lane[l] = s;
+            return true;
+          }
+        }
+      }
+    return false;
+  };
+  for (int k = 0; k < steps; ++k) {
+    const int r = steps - k;
+    const int D = std::max(r, *std::max_element(d, d + NB));
+    bool done = false;
+    for (int loss = 0; !done; ++loss)
+      for (c = 1; c <= std::min(D - r + 1 + loss, CAP) && !done; ++c) {
+        const int Dn = D - c + loss;
+        int need[NB];
+        bool ok = true;
+        for (int b = 0; b < NB; ++b) {
+          need[b] = std::max(0, d[b] - Dn);
+          if (need[b] > c) ok = false;
+        }
+        if (!ok) continue;
+        std::fill(match_lane.begin(), match_lane.end(), -1);
+        std::fill(match_slot.begin(), match_slot.end(), -1);
+        for (int b = 0; b < NB && ok; ++b)
+          for (int i = 0; i < need[b] && ok; ++i) {
+            std::fill(vis_lane.begin(), vis_lane.end(), 0);
+            ok = try_slot(b * CAP + i);
+          }
+        for (int l = 0; l < L && ok; ++l)
+          if (rem[l] == r && match_lane[l] < 0) {
+            std::fill(vis_slot.begin(), vis_slot.end(), 0);
+            ok = try_lane(l);
+          }
+        if (!ok) continue;
+        for (int l = 0; l < L; ++l)
+          if (rem[l] > 0 && match_lane[l] < 0) {
+            std::fill(vis_slot.begin(), vis_slot.end(), 0);
+            try_lane(l);
+          }
+        done = true;
+      }
+    int usage[NB] = {0};
+    for (int l = 0; l < L; ++l)
+      if (match_lane[l] >= 0) {
+        const int b = match_lane[l] / CAP;
+        pos[l][k] = by_bank[l][b].back();
+        by_bank[l][b].pop_back();
+        d[b]--;
+        rem[l]--;
+        usage[b]++;
+      }
+    for (int l = 0; l < L; ++l)
+      if (match_lane[l] < 0) {
+        const int b = (int)(std::min_element(usage, usage + NB) - usage);
+        padb[l][k] = b;
+        usage[b]++;
+      }
+  }
+  // LDS cycles as placed: per step, the most distinct addresses on one bank (equal addresses are one broadcast)
+  int total = 0;
+  for (int k = 0; k < steps; ++k) {
+    std::array<std::vector<int32_t>, NB> addr;
+    for (int l = 0; l < L; ++l) {
+      const int32_t a = pos[l][k] >= 0 ? other[lane_arcs[l][pos[l][k]]] : padb[l][k];
+      auto &v = addr[a & (NB - 1)];
+      if (std::find(v.begin(), v.end(), a) == v.end()) v.push_back(a);
+    }
+    size_t mx = 1;
+    for (auto &v : addr) mx = std::max(mx, v.size());
+    total += (int)mx;
+  }
+  *pos_out = pos;
+  if (pad_bank) *pad_bank = padb;
   return total;
 }
 

@@ -61,6 +61,18 @@ __device__ __forceinline__ void bst4(rsrc_t r, uint32_t voff, f4 v) {
                                          r, (int)voff, 0, TC_STORE_AUX);
 }
 
+// the same with the cache policy chosen by the caller (0: default, 2: nt)
+template <int AUX>
+__device__ __forceinline__ void bst4_aux(rsrc_t r, uint32_t voff, f4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
+                                         r, (int)voff, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ f4 bld4_aux(rsrc_t r, uint32_t voff) {
+  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, AUX);
+  return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+
 __device__ __forceinline__ f4 mk4(float x) { return f4{x, x, x, x}; }
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 // exp(clamp(y, -30, 30)) ([K] later Kaldi: ApplyExpLimited; equal to the 22fbdd ApplyExp() for |y| < 30) with the

@@ -241,8 +241,17 @@ struct TiedSeq {
     f4 yreg[PV];
     if (t < T) {  // y_t under the arc walk
       const rsrc_t yrow = make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes);
+#if defined(TC_LATE_CACHED) && !defined(TC_LATE_STORES_ONLY)
+      // (experiment: the rows the backward pass will not find in the Infinity Cache anyway are read past it)
+      if (t < T - TC_LATE_CACHED) {
 #pragma unroll
-      for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+        for (int v = 0; v < PV; ++v) yreg[v] = bld4_aux<2>(yrow, own16 + v * kPlane);
+      } else
+#endif
+      {
+#pragma unroll
+        for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+      }
     }
     float n_t = 1.f;
     if (GAMMA && t < T) n_t = vload_f32(bn + t);  // for c^_{t+1}
@@ -261,7 +270,14 @@ struct TiedSeq {
 #ifndef TC_ABL_NOHIST
 #pragma unroll
         for (int j = 0; j < JV; ++j)  // alpha'_{t-1} of the owned states: still in the gather buffer
-          if (j < planes) bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
+          if (j < planes) {
+#ifdef TC_LATE_CACHED
+            if (t - 1 >= T - TC_LATE_CACHED)
+              bst4_aux<0>(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
+            else
+#endif
+              bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
+          }
 #endif
       }
     } TC_WALK_PASS);
@@ -599,7 +615,9 @@ struct TiedSeq {
             const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
             const float bos = kGammaScale * bo;            // power-of-two scale: exact
             gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
+#ifndef TC_ABL_NOFADD  /* (ablation: what the forward-class half of the gamma adds costs) */
             gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
+#endif
           }
           return fmaf(ps_ws, bo, ax);                      // vf_s into beta'_t(g) * asum_t (PURE: into U_t(g))
         };

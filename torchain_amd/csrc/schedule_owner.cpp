@@ -36,7 +36,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
                               const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
                               ScheduleHost *out) {
   // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows
-  out->conflict_cost = out->conflict_free_cost = 0;
+  out->conflict_cost = out->conflict_free_cost = out->conflict_bound = 0;
   out->cells.clear();
   out->wave_range.assign(kWaves, make_int2(0, 0));
   std::vector<std::vector<uint32_t>> wave_masks(kWaves);
@@ -61,8 +61,14 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
           for (int i = 0; i < t.len; ++i) lane_arcs[l].push_back(order[t.begin + i]);
           if (t.len > 0) ++nrows;
         }
-        std::vector<std::vector<int>> pos;
-        out->conflict_cost += arrange_half(lane_arcs, steps, opos, nullptr, &pos);
+        std::vector<std::vector<int>> pos, padb;
+        if (debug_flag(kDbgOldArrange)) {
+          out->conflict_cost += arrange_half(lane_arcs, steps, opos, nullptr, &pos);
+        } else {
+          int lb = 0;
+          out->conflict_cost += arrange_half_matching(lane_arcs, steps, opos, &pos, &padb, &lb);
+          out->conflict_bound += lb;
+        }
         out->conflict_free_cost += steps;
         for (int l = 0; l < 32; ++l) {
           const int lane = half * 32 + l;
@@ -72,7 +78,8 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
               const int64_t a = lane_arcs[l][pos[l][i]];
               cell = ArcRec{prob[a], (uint32_t)opos[a] << 18};
             } else {
-              cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? l : 0) << 18};  // padding: w = 0, conflict-free offset
+              // padding: w = 0, gathered from a bank that is idle in this step
+              cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? (padb.empty() ? l : padb[l][i]) : 0) << 18};
             }
           }
         }
@@ -124,6 +131,9 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       }
     }
   }
+  if (debug_flag(kDbgSchedTrace))
+    fprintf(stderr, "[sched] gathers: %lld LDS cycles as placed, bound %lld, conflict-free %lld\n", (long long)out->conflict_cost,
+            (long long)out->conflict_bound, (long long)out->conflict_free_cost);
   out->real_arcs = (int64_t)order.size();
   out->padded_arcs = arc_cells;
   out->rows = nrows;
@@ -355,20 +365,30 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
       H_(0, half_of(g->pos[dst[a]]), bank_of(g->pos[src[a]]))++;
       H_(1, half_of(g->pos[src[a]]), bank_of(g->pos[dst[a]]))++;
     }
+    static const int kPhiMode = getenv("TC_PHI") ? atoi(getenv("TC_PHI")) : 0;
+    static const int kPhiT = getenv("TC_PHIT") ? atoi(getenv("TC_PHIT")) : 8;
+    static const int kPropMul = getenv("TC_PROP") ? atoi(getenv("TC_PROP")) : 200;
+    auto phi = [&](int h) -> int64_t {
+      if (kPhiMode == 0) return (int64_t)h * h;
+      const int e = std::max(0, h - kPhiT);
+      if (kPhiMode == 1) return (int64_t)h * h + 64ll * e * e;
+      if (kPhiMode == 2) return (int64_t)h * h * h;
+      return (int64_t)1 << std::min(h, 40);
+    };
     // moving state u from bank b1 to bank b2 changes sum h^2 by the sum over the rows gathering u
     auto move_delta = [&](int u, int b1, int b2) {
       int64_t d = 0;
       for (int64_t i = out_first[u]; i < out_first[u + 1]; ++i) {  // arcs u -> x: row of x gathers u (forward)
         const int hf = half_of(g->pos[dst[out_order[i]]]);
         int32_t &x1 = H_(0, hf, b1), &x2 = H_(0, hf, b2);
-        d += (int64_t)(2 * x2 + 1) - (2 * x1 - 1);
+        d += (phi(x2 + 1) - phi(x2)) - (phi(x1) - phi(x1 - 1));
         --x1;
         ++x2;
       }
       for (int64_t i = in_first[u]; i < in_first[u + 1]; ++i) {  // arcs x -> u: row of x gathers u (backward)
         const int hf = half_of(g->pos[src[in_order[i]]]);
         int32_t &x1 = H_(1, hf, b1), &x2 = H_(1, hf, b2);
-        d += (int64_t)(2 * x2 + 1) - (2 * x1 - 1);
+        d += (phi(x2 + 1) - phi(x2)) - (phi(x1) - phi(x1 - 1));
         --x1;
         ++x2;
       }
@@ -381,7 +401,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
       rng ^= rng << 17;
       return rng;
     };
-    const int64_t proposals = (int64_t)Npos * 200;
+    const int64_t proposals = (int64_t)Npos * kPropMul;
     int64_t accepted = 0;
     for (int64_t it = 0; it < proposals; ++it) {
       const uint64_t r = next();
