@@ -322,13 +322,20 @@ int tc_den_graph_tuning(tc_den_graph *graph, int device, int32_t *two_sequence_k
  * tc_den_graph_prepare on the device times again).  Called BEFORE the graph first reaches `device` no timing launch is
  * made at all; called later the choice applies from the next launch on.  This is what makes the choice reproducible:
  * each kernel is bitwise reproducible by itself, the two differ in the last bits, and a timing race decides by clock
- * noise for a graph near the 3 % threshold -- from run to run and from rank to rank.  The Python wrapper keeps a cache
- * of the measured choices keyed by tc_den_graph_hash and the device name (io.DenominatorGraph.prepare) and applies
- * rank 0's choice on every rank of a data-parallel job (parallel.sync_den_graph_variant).
+ * noise for a graph near the 3 % threshold -- from run to run and from rank to rank.  Since round 5 the LIBRARY keeps the
+ * cache of measured choices (csrc/tuning_cache.cpp): tc_den_graph_prepare looks the graph up -- key: tc_den_graph_hash +
+ * the device's name -- in the JSON file $TORCHAIN_TUNING_CACHE (else ~/.cache/torchain_amd/tuning.json) before it times
+ * anything and stores what it timed, so a caller of this ABI gets the same kernel run after run without calling this
+ * function; the Python wrapper applies rank 0's choice on every rank of a data-parallel job
+ * (parallel.sync_den_graph_variant).
  * (The reference's call is deterministic for fixed inputs: src/my_lib_chain.cpp:129-131.) */
 int tc_den_graph_set_variant(tc_den_graph *graph, int device, int32_t two_sequence_kernel);
 /* 64-bit FNV-1a hash of the graph (sizes, arcs, pdfs, probabilities): the key of such a cache.  0 for a null handle. */
 uint64_t tc_den_graph_hash(const tc_den_graph *graph);
+/* That cache, directly (host only; e.g. to ship the choices measured on one machine to a fleet): 1 / 0 = found / not. */
+int tc_tuning_cache_get(uint64_t graph_hash, const char *device_name, int32_t *two_sequence_kernel);
+int tc_tuning_cache_put(uint64_t graph_hash, const char *device_name, int32_t two_sequence_kernel, float fused_ms,
+                        float two_sequence_ms);
 
 /* ---- layout conversion either side of the path -------------------------- */
 

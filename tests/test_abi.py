@@ -289,3 +289,35 @@ def test_graph_hash_and_fixed_kernel_choice_need_no_gpu():
         assert lib.tc_den_graph_set_variant(a.ptr, 0, v) == 0
     assert lib.tc_den_graph_set_variant(a.ptr, 0, 2) < 0 and lib.tc_den_graph_set_variant(a.ptr, 0, -2) < 0
     assert lib.tc_den_graph_set_variant(None, 0, 0) < 0
+
+
+def test_tuning_cache_is_the_librarys_and_reads_the_python_format(tmp_path, monkeypatch):
+    """Round 5: the cache of measured kernel choices lives below the Python layer (csrc/tuning_cache.cpp,
+    consulted by tc_den_graph_prepare).  Host-only part: entries written through the C ABI are valid JSON in the format
+    round 4's io.py wrote, entries written by that Python code are found by the library, a damaged file means "not cached"."""
+    import ctypes as C
+    import json
+    path = tmp_path / "sub" / "tuning.json"
+    monkeypatch.setenv("TORCHAIN_TUNING_CACHE", str(path))
+    got = C.c_int32(-7)
+    assert lib.tc_tuning_cache_get(0x1234, b"AMD Instinct MI355X", C.byref(got)) == 0 and got.value == -7
+    assert lib.tc_tuning_cache_put(0x1234, b"AMD Instinct MI355X", 1, 0.5, 0.25) == 0
+    assert lib.tc_tuning_cache_put(0xABCDEF0123456789, b"AMD Instinct MI355X", 0, 0.75, 0.875) == 0
+    table = json.load(open(path))
+    assert table["0000000000001234:AMD Instinct MI355X"] == {"fused_ms": 0.5, "two_sequence_kernel": 1, "two_sequence_ms": 0.25}
+    assert table["abcdef0123456789:AMD Instinct MI355X"]["two_sequence_kernel"] == 0
+    assert lib.tc_tuning_cache_get(0x1234, b"AMD Instinct MI355X", C.byref(got)) == 1 and got.value == 1
+    assert lib.tc_tuning_cache_get(0xABCDEF0123456789, b"AMD Instinct MI355X", C.byref(got)) == 1 and got.value == 0
+    assert lib.tc_tuning_cache_get(0x1234, b"another device", C.byref(got)) == 0
+    # the round-4 Python writer's format (json.dump(indent=1, sort_keys=True))
+    table["00000000000000ff:dev"] = {"fused_ms": 1.0, "two_sequence_kernel": 1, "two_sequence_ms": 0.5}
+    with open(path, "w") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    assert lib.tc_tuning_cache_get(0xFF, b"dev", C.byref(got)) == 1 and got.value == 1
+    assert lib.tc_tuning_cache_get(0x1234, b"AMD Instinct MI355X", C.byref(got)) == 1 and got.value == 1
+    with open(path, "w") as f:
+        f.write("{ not json")
+    assert lib.tc_tuning_cache_get(0x1234, b"AMD Instinct MI355X", C.byref(got)) == 0
+    assert lib.tc_tuning_cache_put(0x1, b"d", 1, 0.1, 0.05) == 0 and json.load(open(path)) == {
+        "0000000000000001:d": {"fused_ms": pytest.approx(0.1), "two_sequence_kernel": 1, "two_sequence_ms": pytest.approx(0.05)}}
+    assert lib.tc_tuning_cache_put(0x1, None, 1, 0.1, 0.05) < 0 and lib.tc_tuning_cache_put(0x1, b"d", 2, 0.1, 0.05) < 0

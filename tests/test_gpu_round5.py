@@ -42,6 +42,60 @@ def _compare(oracle, cfg, S, T, seed, expect_tied):
     assert np.abs(rows - 1.0).max() <= 1e-4, np.abs(rows - 1.0).max()
 
 
+# ---- the plane-wise on-chip kernel (den_tied_planes.hip): tied graphs of 16385..28672 positions --------------------------
+def test_plane_wise_kernel_small_batches(oracle):
+    """5, 6 and 7 planes, few sequences and frames, against the full objective's oracle (numerator included)."""
+    from helpers import hip_chain
+    for H, deg, P, S, T in ((17000, 3, 900, 2, 7), (24000, 4, 2000, 3, 5), (28000, 5, 2928, 2, 6)):
+        fst = synth.random_den_fst(H, deg, P, seed=H)
+        g = oracle.DenGraph(fst)
+        sup = synth.random_supervision(fst, S, T, 2, seed=H + 1, initial_probs=g.initial_probs())
+        y = synth.random_nnet_output(S, T, P, seed=H + 2)
+        ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+        out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, xent=True)
+        st = out["graph"].stats()
+        assert st["tied"] == 1 and st["lds_bytes"] > 100 * 1024, st
+        res = out["results"]
+        assert abs(res[0] - ref["objf"]) <= REL * max(abs(ref["objf"]), 0.05 * S * T), (H, res, ref["results"])
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL, H
+        assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL, H
+
+
+@pytest.mark.parametrize("S,T", [(64, 150), (256, 30)])
+def test_plane_wise_kernel_at_size(oracle, S, T):
+    """R4 on its default path: on chip (tied == 1), log-prob, derivative matrix-wise and element-wise, row sums."""
+    _compare(oracle, "R4", S, T, seed=511, expect_tied=1)
+
+
+def test_plane_wise_kernel_accumulate_and_no_deriv(oracle):
+    """[K] Backward(deriv_weight, &deriv) adds into deriv; the forward-only call gives the same log-prob."""
+    fst = synth.random_den_fst(20000, 3, 700, seed=31)
+    S, T = 3, 9
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=41)
+    ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=0.05, deriv_weight=1.0)
+    out = hip_den(fst, y, S, leaky=0.05, deriv_weight=1.0, accumulate=True, init=0.5)
+    assert out["graph"].stats()["tied"] == 1 and out["status"] == 0
+    assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+    assert rel_err(out["deriv"] - 0.5, ref["deriv"]) <= REL
+    out2 = hip_den(fst, y, S, leaky=0.05, want_deriv=False)
+    assert abs(out2["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
+
+
+def test_plane_wise_kernel_is_bitwise_reproducible_and_slices():
+    """Sequences never interact: a 5-sequence call's rows equal the rows of the same sequences in an 8-sequence call."""
+    fst = synth.config_den_fst("R4")
+    P = synth.CONFIGS["R4"]["P"]
+    S, T = 8, 12
+    y = synth.random_nnet_output(S, T, P, seed=43)
+    g = io.DenominatorGraph(fst, P)
+    a = hip_den(fst, y, S, leaky=0.1, graph=g)
+    b = hip_den(fst, y, S, leaky=0.1, graph=g)
+    assert a["logprob"] == b["logprob"] and np.array_equal(a["deriv"], b["deriv"])
+    sub = np.ascontiguousarray(y.reshape(T, S, P)[:, :5].reshape(T * 5, P))
+    c = hip_den(fst, sub, 5, leaky=0.1, graph=g)
+    assert np.array_equal(c["deriv"].reshape(T, 5, P), a["deriv"].reshape(T, S, P)[:, :5])
+
+
 @pytest.mark.parametrize("width", ["slab_narrow", "slab_wide"])
 @pytest.mark.parametrize("cfg", ["R4", "X2"])
 def test_streamed_path_at_size_64x150(oracle, kernel_family, cfg, width):

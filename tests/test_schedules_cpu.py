@@ -43,6 +43,20 @@ def test_tied_schedules_with_hub_states_replay():
     check_graph(synth.skewed_tied_den_fst(3000, 30000, 500, seed=9, hub_fraction=0.005), 1)
 
 
+@pytest.mark.parametrize("H,deg,P", [(17000, 3, 900), (20000, 3, 700), (24576, 4, 2000), (28000, 6, 2928)])
+def test_plane_wise_schedules_replay(H, deg, P):
+    """16385..28672 positions: a wave's stream cut into sub-streams (secondary rows, then one per plane of 4096 positions),
+    16-bit positions in the cells, fix-up lists per thread and plane (den_tied_planes.hip)."""
+    fst = synth.random_den_fst(H, deg, P, seed=H + deg)
+    assert io.DenominatorGraph(fst, P).stats()["lds_bytes"] <= 160 * 1024
+    check_graph(fst, 1)
+
+
+def test_plane_wise_schedules_of_phone_lm_graphs_replay():
+    """R4 (24000 states, 312000 arcs, in-degrees to 200: secondary rows folded per plane) stays on chip."""
+    check_graph(synth.config_den_fst("R4"), 1)
+
+
 def test_left_to_right_graph_replay():
     check_graph(synth.left_to_right_den_fst(200, seed=42), io.DenominatorGraph(synth.left_to_right_den_fst(200, seed=42), 200).stats()["tied"])
 
@@ -61,6 +75,7 @@ def test_streamed_tables_replay(kernel_family, width):
     """The streamed path's lists (rows bundled four or two at a time for slabs of 16 / 32 sequences, entries in
     chunks per bundle) replayed on the host against the definition."""
     kernel_family(width)
+    kernel_family("no_planes")  # (a tied graph of this size would otherwise take the plane-wise on-chip kernel)
     check_graph(synth.random_den_fst(20000, 3, 700, seed=31), 2)      # tied streamed tables
     kernel_family("force_streamed")
     check_graph(synth.skewed_den_fst(300, 6000, 120, seed=4), 2)       # general streamed tables

@@ -86,6 +86,10 @@ def _load():
     L.tc_den_graph_set_variant.argtypes = [vp, C.c_int, C.c_int32]
     L.tc_den_graph_hash.restype = C.c_uint64
     L.tc_den_graph_hash.argtypes = [vp]
+    L.tc_tuning_cache_get.restype = C.c_int
+    L.tc_tuning_cache_get.argtypes = [C.c_uint64, C.c_char_p, C.POINTER(C.c_int32)]
+    L.tc_tuning_cache_put.restype = C.c_int
+    L.tc_tuning_cache_put.argtypes = [C.c_uint64, C.c_char_p, C.c_int32, C.c_float, C.c_float]
     L.tc_debug_set.restype = C.c_int
     L.tc_debug_set.argtypes = [C.c_char_p, C.c_int]
     L.tc_debug_counter.restype = C.c_int64

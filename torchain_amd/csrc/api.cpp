@@ -4,6 +4,7 @@
 // the kernels on the caller's stream.  No host synchronisation; no allocation once the per-device supervision
 // pool (supervision.cpp) is warm.
 #include <algorithm>
+#include <string>
 #include <cstring>
 
 #include "chain_internal.h"
@@ -46,7 +47,7 @@ int big_g(const tc_den_graph *g) { return g->big ? g->big_G : 16; }
 int big_hb(const tc_den_graph *g) { return g->big ? g->big_hb : 0; }
 // Batches the tied on-chip kernel may run as two CUs per sequence get room for the second history.  (Whether
 // they do is decided at launch: device size, layout for this T, diagnostic switch.)
-bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq; }
+bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq && !(g->layout_ok && g->layout.planewise); }
 // Tied on-chip graphs of at most 8192 positions may run two sequences per workgroup (den_tied_pair.hip): two more
 // history rows, the two roles' normalisers and the pairing words.
 bool pair_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.JV == kJvSmall; }
@@ -74,8 +75,11 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   // streamed path: exp(y) of every frame, transposed once and used by both passes, when that is at most 1 GB
   // (else one frame at a time, recomputed by the backward pass: 2-7 % slower, measured; the cap keeps the workspace
   // of exactly the largest graphs from growing by gigabytes -- include/torchain_hip.h states the sizes)
-  w.big_exp_frames = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)1 << 30) && !debug_flag(kDbgExpPerFrame) ? T : 1;
-  w.big_expy = big_P ? (float *)take((size_t)w.big_exp_frames * Sp * big_P * sizeof(float)) : nullptr;
+  // (the diagnostic switch exp_per_frame selects the one-frame form at LAUNCH; the workspace is sized for the larger
+  // layout whatever the switch says, so a size a caller cached stays valid when the switch changes)
+  const int exp_frames_room = big_P && (size_t)T * Sp * big_P * sizeof(float) <= ((size_t)1 << 30) ? T : 1;
+  w.big_exp_frames = debug_flag(kDbgExpPerFrame) ? 1 : exp_frames_room;
+  w.big_expy = big_P ? (float *)take((size_t)exp_frames_room * Sp * big_P * sizeof(float)) : nullptr;
   w.big_beta = big_P ? (float *)take((size_t)2 * Sp * big_H * sizeof(float)) : nullptr;
   w.big_small = big_P ? (float *)take((size_t)big_small_floats(big_hb, big_P, T, Sp) * sizeof(float)) : nullptr;
   w.big_y = big_P ? (float *)take((size_t)Sp * big_H * sizeof(float)) : nullptr;
@@ -249,6 +253,17 @@ int tune_den_variant(tc_den_graph *g, int device) {
     choice = preset;
     return finish();
   }
+  // the choice an earlier run measured for this graph on this kind of device: no timing launches, no scratch allocation
+  std::string cache_key;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) cache_key = tuning_cache_key(tc_den_graph_hash(g), prop.name);
+    int cached = 0;
+    if (!cache_key.empty() && tuning_cache_get(cache_key, &cached)) {
+      choice = cached;
+      return finish();
+    }
+  }
   DeviceGuard guard(device);
   if (!guard.ok) return finish();
   int num_cus = 0;
@@ -299,6 +314,7 @@ int tune_den_variant(tc_den_graph *g, int device) {
   }
   if (mem) (void)hipFree(mem);
   (void)hipGetLastError();  // (a failed scratch allocation is not the caller's error)
+  if (ms[0] > 0.f && ms[1] > 0.f && !cache_key.empty()) tuning_cache_put(cache_key, choice, ms[0], ms[1]);  // (really timed)
   return finish();
 }
 

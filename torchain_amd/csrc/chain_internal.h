@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "torchain_hip.h"
@@ -63,6 +64,12 @@ constexpr int kStreamUnrollTied = 8;  // tied streams: a wave's range is padded 
 // (den_tied_kernel.hip), which must exist whatever the graph
 constexpr int kTiedMinChunks = 6;
 constexpr int kMaxIndex = 1 << 14;
+// Tied graphs of 16385..28672 positions ("plane-wise" form of the owner-computes kernel, den_tied_planes.hip): the gather
+// source alone takes 4 bytes per position of the CU's 160 KB, so a thread's 20-28 states are taken one float4 ("plane")
+// at a time -- walk the four rows of the plane, then its per-state pass -- and the row sums of all planes share four
+// rows per wave.  Cells carry positions (16 bits), not byte offsets.
+constexpr int kJvPlanes = 7;
+constexpr int kMaxPlanePositions = 4096 * kJvPlanes;
 
 struct ScheduleHost {
   std::vector<ArcRec> cells;       // all waves' streams, [cell][lane] (final layout [pair][lane][2])
@@ -83,6 +90,10 @@ struct ScheduleHost {
   // finds its row register in GPR-index mode, 0xC000 | row index (den_tied_rr.hip); two cells per word
   std::vector<uint32_t> images;
   int32_t img_stride = 0, max_chunks = 0;  // max_chunks: the longest wave stream, in chunks
+  // plane-wise form (kMaxIndex < positions <= kMaxPlanePositions): a wave's stream is `subs` sub-streams -- its secondary
+  // rows, then one per plane -- each padded to whole chunks, with mask words of its own: wave_range[wave * subs + sub],
+  // masks[(wave * subs + sub) * mask_stride ...]; fix_begin is [thread][plane] (+ 1)
+  int32_t subs = 0;
 };
 
 struct ScheduleDev {
@@ -96,6 +107,7 @@ struct ScheduleDev {
   const void *cells_pair = nullptr;     // tied graphs of at most 8192 positions: the stream with offsets = position * 8
   const uint32_t *images = nullptr;     // owner-computes schedules: row-register images per chunk (ScheduleHost::images)
   int32_t img_stride = 0, max_chunks = 0;
+  int32_t subs = 0;                     // plane-wise form: sub-streams per wave (ScheduleHost::subs), else 0
 };
 
 // ---- graphs too large for the on-chip layout ("streamed" path, den_slab_kernel.hip) ------------------
@@ -165,6 +177,7 @@ struct DenLayout {
   int off_p2;           // tied graphs, backward: second exp(y) buffer (frame t-1 while frame t is in use)
   int JV, PV;           // template instantiation: float4s of states / pdfs owned per thread
   int acc_floats;       // size of the accumulator region: Hs + 4 + extra slots, rounded to 4
+  bool planewise = false;  // den_tied_planes.hip: [P | A | 4 rows per wave + 4 + extra slots | GAMMA | red | asum]
 };
 
 struct DenParams {
@@ -349,6 +362,7 @@ int arrange_half_matching(const std::vector<std::vector<int64_t>> &lane_arcs, in
                           int *lower_bound);                                           // den_layout.cpp
 inline int round4(int x) { return (x + 3) & ~3; }
 bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L);
+bool compute_layout_planes(int Npos, int P, int T_hint, int extra_slots, DenLayout *L);
 int64_t layout_lds_bytes(const DenLayout &L, int T);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size class) instead of before every
@@ -357,6 +371,7 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes);             
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip
+int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_planes.hip
 // den_tied_rr.hip: the fused kernel with the row sums in registers and one more chunk of the stream in LDS (graphs without
 // hub states, 8 states and 4 pdfs per thread)
 bool rr_fits(const DenParams &p);
@@ -371,6 +386,10 @@ constexpr int kSplitMaxSeq = 128;  // two CUs per sequence: batches of at most h
 int launch_den_tied_pair(const DenParams &p, int extra_slots, int accumulate, hipStream_t stream);
 bool pair_fits(const DenLayout &L, int extra_slots, int T);
 int tune_den_variant(tc_den_graph *g, int device);  // api.cpp
+// tuning_cache.cpp: the measured choices of earlier runs, keyed by graph hash and device name
+std::string tuning_cache_key(uint64_t graph_hash, const char *device_name);
+bool tuning_cache_get(const std::string &key, int *two_sequence_kernel);
+void tuning_cache_put(const std::string &key, int two_sequence_kernel, float fused_ms, float two_sequence_ms);
 // den_tied_mitm.hip: two CUs per sequence meeting in the middle (batches of at most half the CUs)
 int launch_den_tied_mitm(const DenParams &p, uint32_t *sync, int accumulate, hipStream_t stream);
 bool mitm_fits(const DenLayout &L, int T);
@@ -416,7 +435,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

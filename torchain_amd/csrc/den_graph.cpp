@@ -35,8 +35,9 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes) {
 
 // One set of side streams and fork / join events per (device, CALLER stream): callers on different streams neither
 // share events (a wait binds to the latest record) nor serialise on one mutex.  Created on first use, all or nothing.
-static std::mutex g_side_mu;
-static std::map<std::pair<int, hipStream_t>, SideStreams> g_side_ctx;
+// (process lifetime, never destroyed: see the pools of supervision.cpp / egs_reader.cpp)
+static std::mutex &g_side_mu = *new std::mutex();
+static std::map<std::pair<int, hipStream_t>, SideStreams> &g_side_ctx = *new std::map<std::pair<int, hipStream_t>, SideStreams>();
 
 // A caller stream that is about to be destroyed (api.cpp: the tuning launches' temporary stream) takes its entry along:
 // the stream's value may be handed out again by the runtime, and the entry holds two streams and four events.
@@ -252,7 +253,7 @@ static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
 }
 
 int build_schedules(tc_den_graph *g) {
-  bool want_big = debug_flag(kDbgForceStreamed) || g->H > kMaxIndex || g->P > kMaxIndex;
+  bool want_big = debug_flag(kDbgForceStreamed) || g->H > kMaxPlanePositions || g->P > kMaxIndex;
   bool split_made = false;  // tied only thanks to make_work_graph
   // ---- the tied path: on the FST as it is, or on its tied-ified work graph
   std::vector<char> special;
@@ -364,7 +365,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "reg_rows", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "reg_rows", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -686,9 +687,12 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   if (!g->layout_ok) return TC_ERR_UNSUPPORTED;
   const ScheduleHost &sc = direction == 0 ? g->fwd : g->bwd;
   const int Hs = g->layout.Hs;
-  std::vector<float> acc((size_t)g->layout.acc_floats + 64, 0.f);
+  // (plane-wise form: the replay keeps one accumulator per position, where the kernel reuses four rows per wave)
+  std::vector<float> acc((size_t)std::max(g->layout.acc_floats, Hs + 4 + sc.extra_slots) + 64, 0.f);
   if (g->tied) {
     const int K = Hs / kThreads;
+    const bool pw = g->layout.planewise;
+    const int subs = pw ? sc.subs : 1;
     std::vector<float> src_pos((size_t)Hs + 4, 0.f);
     // a split state's alpha is the sum of its copies' (forward: the first copy carries the value), its
     // beta is shared by all copies (backward: every copy presents it)
@@ -698,11 +702,12 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
         src_pos[g->pos[c]] = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f)
                                             : gather[h] * pdf_factor[(fs & 0xffffu) >> 2];
       }
-    for (int w = 0; w < kWaves; ++w) {
-      const int first = sc.wave_range[w].x, n = sc.wave_range[w].y;
+    for (int w = 0; w < kWaves; ++w)
+     for (int sub = 0; sub < subs; ++sub) {
+      const int first = sc.wave_range[(size_t)w * subs + sub].x, n = sc.wave_range[(size_t)w * subs + sub].y;
       for (int l = 0; l < 64; ++l) {
         const int tid = 64 * w + l;
-        int k = 0;
+        int k = !pw ? 0 : sub == 0 ? K : 4 * (sub - 1);  // (sub-stream 0: the wave's secondary rows)
         float ax = 0.f, ay = 0.f;
         auto slot = [&]() {
           return k < K ? 4 * (tid + kThreads * (k >> 2)) + (k & 3) : Hs + 4 + 64 * (sc.extra_first[w] + (k - K)) + l;
@@ -713,14 +718,14 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
           uint32_t x = base[((q / 4) * 64 + l) * 4 + (q % 4)];
           memcpy(wgt, &x, 4);
           const uint32_t o = base[(2 * 64 + l) * 4 + q / 2];
-          *position = (int)(((q & 1) ? o >> 16 : o & 0xffffu) >> 2);
+          *position = (int)(((q & 1) ? o >> 16 : o & 0xffffu) >> (pw ? 0 : 2));
         };
         for (int i = 0; i < n; i += 2) {
           float w0, w1;
           int p0, p1;
           cell(i, &w0, &p0);
           cell(i + 1, &w1, &p1);
-          const uint32_t m = sc.masks[(size_t)w * sc.mask_stride + (i / 2) / 8];
+          const uint32_t m = sc.masks[((size_t)w * subs + sub) * sc.mask_stride + (i / 2) / 8];
           const int bit = (i / 2) % 8;
           if ((m >> (8 + bit)) & 1u) {  // the row ends with the pair's first cell
             acc[slot()] = (ax + w0 * src_pos[p0]) + ay;
@@ -739,8 +744,12 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
         }
       }
     }
-    for (int t = 0; t < kThreads; ++t)
-      for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) acc[sc.fix[e].x] += acc[sc.fix[e].y];
+    for (size_t t = 0; t + 1 < sc.fix_begin.size(); ++t)
+      for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) {
+        if (pw && ((sc.fix[e].x >> 2) % kThreads != (int)(t / (K / 4)) || sc.fix[e].x / (4 * kThreads) != (int)(t % (K / 4))))
+          return TC_ERR_UNSUPPORTED;  // (an entry must sit in the list of the thread and plane that own its state)
+        acc[sc.fix[e].x] += acc[sc.fix[e].y];
+      }
     for (int h = 0; h < H; ++h) {
       float sum = 0.f;
       for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
@@ -932,6 +941,8 @@ static int upload_den_graph(tc_den_graph *g, int device) {
                       (const int32_t *)(blob + parts[7].off), (const int2 *)(blob + parts[8].off),
                       (const uint32_t *)(blob + parts[12].off), (const int32_t *)(blob + parts[14].off),
                       g->bwd.mask_stride, g->bwd.nfix};
+  d.fwd.subs = g->fwd.subs;
+  d.bwd.subs = g->bwd.subs;
   d.pi = (const float *)(blob + parts[4].off);
   if (g->tied) {
     d.tied_fs = (const uint32_t *)(blob + parts[9].off);

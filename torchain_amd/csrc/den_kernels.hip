@@ -507,6 +507,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
     SideStreams *c = nullptr;
     const int src = side_streams(stream, &c);
     if (src != TC_OK) return src;
+    if (p.L.planewise) return launch_den_tied_planes(p, accumulate, stream);  // den_tied_planes.hip
     if (pair_wanted(p, c->num_cus)) return launch_den_tied_pair(p, p.pair_extra_slots, accumulate, stream);
     if (split_wanted(p)) {
       if (2 * p.S <= c->num_cus) {

@@ -70,9 +70,39 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
     off += round4(T_hint + 1);
     L->total_floats = off;
     L->alpha_in_lds = with_alpha != 0;
+    L->planewise = false;
     if ((int64_t)off * 4 <= kLdsLimitBytes) return true;
   }
   return false;
+}
+
+// The plane-wise form (chain_internal.h: kJvPlanes): exp(y) in its compile-time region, the gather source for every
+// position, four accumulator rows per wave that all planes share (+ the dummy row and the private slots of secondary
+// rows), gamma, the reduction scratch and the frame sums.  One exp(y) buffer, alpha'_{t+1} from the history (the tight
+// layout's rules).
+bool compute_layout_planes(int Npos, int P, int T_hint, int extra_slots, DenLayout *L) {
+  L->Hs = Npos;
+  L->Ps = round4(P);
+  if (Npos % (4 * kThreads) != 0 || Npos > kMaxPlanePositions || L->Ps > 4 * kThreads * kPvSmall) return false;
+  L->JV = Npos / (4 * kThreads);  // the kernel is instantiated per plane count (den_tied_planes.hip)
+  if (L->JV < 5) return false;
+  L->PV = kPvSmall;
+  L->planewise = true;
+  int off = L->PV * 4 * kThreads;
+  L->off_a = off;
+  off += Npos;
+  L->off_acc = off;
+  L->acc_floats = round4(4 * kThreads + 4 + extra_slots);
+  off += L->acc_floats;
+  L->off_g = off;
+  off += L->Ps;
+  L->off_al = L->off_p2 = L->off_red = off;
+  off += 4 * kWaves;
+  L->off_asum = off;
+  off += round4(T_hint + 1);
+  L->total_floats = off;
+  L->alpha_in_lds = false;
+  return (int64_t)off * 4 <= kLdsLimitBytes;
 }
 
 int64_t layout_lds_bytes(const DenLayout &L, int T) {

@@ -150,6 +150,22 @@ __device__ __forceinline__ uint32_t hi16(uint32_t x) {
   return r;
 }
 
+// Plane-wise form (den_tied_planes.hip, graphs beyond 16384 positions): the cell's 16-bit field is the POSITION of its
+// source, and the byte offset is field << 2 -- word select and shift in one SDWA instruction, so the unpacking still
+// costs one VALU instruction per cell.
+__device__ __forceinline__ uint32_t lo16w(uint32_t x) {
+  uint32_t r;
+  const uint32_t two = 2u;
+  asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(two), "v"(x));
+  return r;
+}
+__device__ __forceinline__ uint32_t hi16w(uint32_t x) {
+  uint32_t r;
+  const uint32_t two = 2u;
+  asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(two), "v"(x));
+  return r;
+}
+
 // Where a finished row sum goes.  All 64 lanes of a wave are at the same row index k, so the row sums are
 // kept [row][lane]: own rows of wave w at rows w * K + k, secondary rows (k >= K, hub states only) behind
 // them.  A commit is then ds_write_addtid_b32 -- address = M0 + 4 * lane, no address VGPR (a VGPR that is only
@@ -174,17 +190,28 @@ struct RowCommit {
 // faster per cell but need 14-21 % more cells; issuing the next chunk's gathers ahead of this chunk's sums
 // gains nothing; without any row ends the same loop would run 1.6x faster -- the commits, two taken branches
 // each, are what the rows cost.)
-template <uint32_t SRC, int HALF>
+template <uint32_t SRC, int HALF, bool WIDE = false>
 __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc, RowCommit &rc) {
   uint32_t o[8];
-  o[0] = lo16(q.oc.x);
-  o[1] = hi16(q.oc.x);
-  o[2] = lo16(q.oc.y);
-  o[3] = hi16(q.oc.y);
-  o[4] = lo16(q.oc.z);
-  o[5] = hi16(q.oc.z);
-  o[6] = lo16(q.oc.w);
-  o[7] = hi16(q.oc.w);
+  if constexpr (WIDE) {
+    o[0] = lo16w(q.oc.x);
+    o[1] = hi16w(q.oc.x);
+    o[2] = lo16w(q.oc.y);
+    o[3] = hi16w(q.oc.y);
+    o[4] = lo16w(q.oc.z);
+    o[5] = hi16w(q.oc.z);
+    o[6] = lo16w(q.oc.w);
+    o[7] = hi16w(q.oc.w);
+  } else {
+    o[0] = lo16(q.oc.x);
+    o[1] = hi16(q.oc.x);
+    o[2] = lo16(q.oc.y);
+    o[3] = hi16(q.oc.y);
+    o[4] = lo16(q.oc.z);
+    o[5] = hi16(q.oc.z);
+    o[6] = lo16(q.oc.w);
+    o[7] = hi16(q.oc.w);
+  }
   float a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -276,6 +303,33 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
   __builtin_amdgcn_s_waitcnt(0xC07F);
   wst[1] += clock64() - wst[2];  // streamed part
 #endif
+}
+
+// Plane-wise form: a wave's stream is a run of sub-streams (its secondary rows, then one per plane), each a whole number
+// of chunks with mask words of its own (schedule_owner.cpp), and the per-state pass of a plane runs between two of them.
+// The stream is one: the look-ahead load at the end of a sub-stream brings the first chunk of the next, so `qa` arrives
+// loaded with chunk c0 and leaves loaded with chunk c0 + n (an odd sub-stream pays twelve moves for that).  Mask word i of
+// the sub-stream is lane m0 + i of `vmask`.
+template <uint32_t SRC>
+__device__ __forceinline__ void walk_sub(Chunk6 &qa, rsrc_t sbase, uint32_t lane16, int &c0, int n, uint32_t vmask, int m0,
+                                         RowCommit rc) {
+  auto mk = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)vmask, m0 + i); };
+  float acc = 0.f;
+  Chunk6 qb;
+  int c = 0;
+  for (; c + 2 <= n; c += 2) {
+    const uint32_t m = mk(c >> 1);
+    load_chunk(qb, sbase, lane16, c0 + c + 1);
+    do_chunk<SRC, 0, true>(qa, m, acc, rc);
+    load_chunk(qa, sbase, lane16, c0 + c + 2);
+    do_chunk<SRC, 1, true>(qb, m, acc, rc);
+  }
+  if (c < n) {
+    load_chunk(qb, sbase, lane16, c0 + c + 1);
+    do_chunk<SRC, 0, true>(qa, mk(c >> 1), acc, rc);
+    qa = qb;
+  }
+  c0 += n;
 }
 
 // ---- row sums in REGISTERS (round 4; den_tied_rr.hip) ---------------------------------------------------------
@@ -404,6 +458,13 @@ __device__ __forceinline__ void fold_row(int2 f, uint32_t vrow, uint32_t aACC, i
   const int k = 4 * (f.x / (4 * kThreads)) + (f.x & 3);
   const uint32_t dst = vrow + 256u * (uint32_t)k;
   const uint32_t src = aACC + 256u * (uint32_t)(K * kWaves) + 4u * (uint32_t)(f.y - Hs - 4);
+  ldsf_st(dst, ldsf(dst) + ldsf(src));
+}
+
+// ... plane-wise form: the four rows of the plane in progress are the wave's rows 0..3
+__device__ __forceinline__ void fold_row_pw(int2 f, uint32_t vrow, uint32_t aACC, int Hs) {
+  const uint32_t dst = vrow + 256u * (uint32_t)(f.x & 3);
+  const uint32_t src = aACC + 256u * (uint32_t)(4 * kWaves) + 4u * (uint32_t)(f.y - Hs - 4);
   ldsf_st(dst, ldsf(dst) + ldsf(src));
 }
 

@@ -50,7 +50,9 @@ __device__ __forceinline__ float vload_f32(const float *ptr) {
 // MITM = false: the fused kernel (per-state tables parked in LDS during the forward phase, phase stamps of the
 // diagnostic builds, normalisers to the workspace after the phase); true: the two roles of den_tied_mitm.hip
 // (gamma region live from frame 0, normalisers to the workspace frame by frame, the B history).
-template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, int RESF, int RESB, bool MITM>
+// PW = true: the plane-wise form of graphs beyond 16384 positions (den_tied_planes.hip: forward_frame_pw /
+// backward_frame_pw below drive the same per-state formulas plane by plane; tight layout, nothing resident).
+template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, int RESF, int RESB, bool MITM, bool PW = false>
 struct TiedSeq {
   const DenParams &p;
   const uint32_t tid, lane;
@@ -86,6 +88,7 @@ struct TiedSeq {
   // walk's scalar loop control then becomes vector code.
   // ---- uniform
   int fnch, store_slot, bnch, bstore_slot;
+  int mstride_f, mstride_b;  // plane-wise form: mask words per sub-stream
   uint32_t fsec, bsec;  // byte address of the wave's first secondary row (forward / backward schedule)
   uint32_t aFS, aWS;
   bool tabs_lds;
@@ -99,6 +102,7 @@ struct TiedSeq {
   float part, y2, part_tot;
   int ffx0, ffx1, bfx0, bfx1;
   uint32_t fmask, bmask;
+  uint32_t fsubn, bsubn;  // plane-wise form: chunks of the wave's sub-stream i in lane i
   Chunk6 fres[RESF > 0 ? RESF : 1];
   Chunk6 bres[RESB > 0 ? RESB : 1];
   f4 v4[JV];         // alpha_t (un-dashed) of the owned states
@@ -112,9 +116,9 @@ struct TiedSeq {
 
   __device__ __forceinline__ TiedSeq(const DenParams &pp, int seq, int meet)
       : p(pp), tid(threadIdx.x), lane(threadIdx.x & 63u), wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)), s(seq),
-        H(pp.H), P(pp.P), S(pp.S), T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), K(pp.L.Hs / kThreads),
+        H(pp.H), P(pp.P), S(pp.S), T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), K(PW ? 4 : pp.L.Hs / kThreads),
         own16(16u * threadIdx.x), lane16(16u * (threadIdx.x & 63u)), aACC(4u * (uint32_t)pp.L.off_acc),
-        vrow(4u * (uint32_t)pp.L.off_acc + 256u * (uint32_t)((pp.L.Hs / kThreads) * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) +
+        vrow(4u * (uint32_t)pp.L.off_acc + 256u * (uint32_t)((PW ? 4 : pp.L.Hs / kThreads) * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) +
              4u * (threadIdx.x & 63u)),
         aGM(4u * (uint32_t)pp.L.off_g), aAL(4u * (uint32_t)pp.L.off_al), aRed(4u * (uint32_t)pp.L.off_red),
         aAsum(4u * (uint32_t)pp.L.off_asum), tab_bytes(4u * (uint32_t)(pp.L.Hs + 4)), row_bytes(4u * (uint32_t)pp.P),
@@ -123,6 +127,10 @@ struct TiedSeq {
         hist(pp.alpha_hist + (int64_t)seq * pp.L.Hs), fn(MITM ? pp.fwd_norm + (int64_t)seq * (pp.T + 2) : nullptr),
         bn(MITM ? pp.bwd_norm + (int64_t)seq * (pp.T + 1) : nullptr), bhist(MITM ? pp.beta_hist + (int64_t)seq * pp.L.Hs : nullptr),
         M(meet) {}
+
+  // which of its JV float4s of states a thread really has (plane-wise form: instantiated per plane count, all of them --
+  // a run-time test here makes the compiler carry the per-state arrays as one wide value through the frame loop)
+  __device__ __forceinline__ bool plane_on(int j) const { return PW ? true : j < planes; }
 
   // diagnostic builds (-DTC_PHASE_STAMPS): per-phase cycle totals of a phase's frames, by wave, to p.stamps + base
   __device__ __forceinline__ void stamps_reset() {
@@ -150,6 +158,44 @@ struct TiedSeq {
     }
   }
 
+  // ---- the per-state formulas, stated once for the frame drivers below
+  // forward: alpha_t(g) * asum_{t-1} = p(f(g)) * sum_{h != g} w alpha'_{t-1}(h) + p(s(g)) * w_s * alpha'_{t-1}(g); with
+  // B_t(g) the two parts are the occupations in frame t-1 of the forward-class arcs into g and of its self-loop
+  template <bool GAMMA>
+  __device__ __forceinline__ float fwd_state(uint32_t fsx, float wsx, float Fx, float alx, float bx, float gs, float &dpart) {
+    const float pf = ldsf(kPB + (fsx & 0xffffu)), ps = ldsf(kPB + (fsx >> 16));
+    const float sp = ps * (wsx * alx);
+    const float a = fmaf(pf, Fx, sp) * inv_prev;
+    if constexpr (GAMMA) {
+      const float g = gs * bx, spn = sp * inv_prev;
+      gamma_add_a(aGM + (fsx >> 16), g * spn);
+      gamma_add_a(aGM + (fsx & 0xffffu), g * fmaxf(a - spn, 0.f));
+      dpart = fmaf(a, bx, dpart);
+    }
+    return a;
+  }
+  // backward: everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
+  //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
+  //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
+  //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
+  // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history (measured against float64 on peaky
+  // outputs, profiles/r02_peaky.txt: keeping the un-dashed alpha in the history instead changes nothing).
+  // The self-loop arc also adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t (PURE: to U_t(g)).
+  template <bool PURE>
+  __device__ __forceinline__ float bwd_state(uint32_t pb, uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float ax,
+                                             float inv_as, float asum_up) {
+    const float ps_ws = ldsf(pb + (fsx >> 16)) * wsx;
+    if constexpr (!PURE) {
+      const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
+      const float bos = kGammaScale * bo;            // power-of-two scale: exact
+      gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
+#ifndef TC_ABL_NOFADD  /* (ablation: what the forward-class half of the gamma adds costs) */
+      gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
+#endif
+    }
+    return fmaf(ps_ws, bo, ax);
+  }
+
   // ================================================================================================== forward
   // ---- t = 0: alpha_0 = pi, alpha'_0 = pi + leaky*pi*sum(pi)   ([K] AlphaFirstFrame + AlphaDash(0)); then the
   // wave's stream: descriptor, row-end masks, resident chunks
@@ -158,13 +204,13 @@ struct TiedSeq {
     part = 0.f;
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
-      pi4[j] = j < planes ? bld4(r_pi, own16, j * kPlane) : mk4(0.f);
+      pi4[j] = plane_on(j) ? bld4(r_pi, own16, j * kPlane) : mk4(0.f);
       part += hsum(pi4[j]);
     }
     asum = block_sum_a(part, aRed, wave, lane);
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) {
+      if (plane_on(j)) {
         const f4 a = pi4[j] + (leaky * pi4[j]) * asum;
         lds4_st(kA0 + own16 + j * kPlane, a);
         bst4(make_rsrc(hist, 4u * Hs), own16 + j * kPlane, a);
@@ -188,6 +234,11 @@ struct TiedSeq {
     }
     inv_prev = __builtin_amdgcn_rcpf(asum);
 
+    if constexpr (PW) {
+      stream_begin_pw(p.fwd, fbase, fmask, fsubn, mstride_f, fsec);
+      fnch = 0;
+      ffx0 = ffx1 = 0;
+    } else {
     const int2 frange = p.fwd.wave_range[wave];
 #ifdef TC_ABL_NOSTREAM
     fnch = RESF;
@@ -204,6 +255,7 @@ struct TiedSeq {
     fsec = aACC + 256u * (uint32_t)(K * kWaves + p.fwd.extra_first[wave]);
 #pragma unroll
     for (int i = 0; i < RESF; ++i) load_chunk(fres[i], fbase, lane16, i);
+    }
     // A forward phase without gamma does not use the gamma / alpha'_{t+1} / second exp(y) regions: when they hold
     // the two per-state tables (C3: exactly), each thread parks its own entries there and the per-state pass reads
     // them at LDS latency instead of waiting for L2 every frame.  (GAMMA frames: forward_unpark first.)
@@ -213,7 +265,7 @@ struct TiedSeq {
     if (tabs_lds) {
 #pragma unroll
       for (int j = 0; j < JV; ++j)
-        if (j < planes) {
+        if (plane_on(j)) {
           *reinterpret_cast<lds_u4 *>(aFS + own16 + j * kPlane) = bld4u(r_fs, own16, j * kPlane);
           lds4_st(aWS + own16 + j * kPlane, bld4(r_ws, own16, j * kPlane));
         }
@@ -270,7 +322,7 @@ struct TiedSeq {
 #ifndef TC_ABL_NOHIST
 #pragma unroll
         for (int j = 0; j < JV; ++j)  // alpha'_{t-1} of the owned states: still in the gather buffer
-          if (j < planes) {
+          if (plane_on(j)) {
 #ifdef TC_LATE_CACHED
             if (t - 1 >= T - TC_LATE_CACHED)
               bst4_aux<0>(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
@@ -293,7 +345,7 @@ struct TiedSeq {
     f4 ws[JV], cpi[JV];
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) {
+      if (plane_on(j)) {
         fs[j] = tabs_lds ? lds4u(aFS + own16 + j * kPlane) : bld4u(r_fs, own16, j * kPlane);
         ws[j] = tabs_lds ? lds4(aWS + own16 + j * kPlane) : bld4(r_ws, own16, j * kPlane);
         cpi[j] = bld4(r_pi, own16, j * kPlane);  // pi: first touched behind the reduction, which hides its L2 trip
@@ -302,25 +354,11 @@ struct TiedSeq {
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       v4[j] = mk4(0.f);
-      if (j < planes) {
+      if (plane_on(j)) {
         const f4 F = own_rows(vrow, j);
         const f4 al = lds4(kA0 + own16 + j * kPlane);  // alpha'_{t-1} of the owned states
-        // alpha_t(g) * asum_{t-1} = p(f(g)) * sum_{h != g} w alpha'_{t-1}(h) + p(s(g)) * w_s * alpha'_{t-1}(g); with
-        // B_t(g) the two parts are the occupations in frame t-1 of the forward-class arcs into g and of its self-loop
-        auto one = [&](uint32_t fsx, float wsx, float Fx, float alx, float bx) __attribute__((always_inline)) {
-          const float pf = ldsf(kPB + (fsx & 0xffffu)), ps = ldsf(kPB + (fsx >> 16));
-          const float sp = ps * (wsx * alx);
-          const float a = fmaf(pf, Fx, sp) * inv_prev;
-          if constexpr (GAMMA) {
-            const float g = gs * bx, spn = sp * inv_prev;
-            gamma_add_a(aGM + (fsx >> 16), g * spn);
-            gamma_add_a(aGM + (fsx & 0xffffu), g * fmaxf(a - spn, 0.f));
-            dpart = fmaf(a, bx, dpart);
-          }
-          return a;
-        };
-        v4[j] = f4{one(fs[j].x, ws[j].x, F.x, al.x, bt[j].x), one(fs[j].y, ws[j].y, F.y, al.y, bt[j].y),
-                   one(fs[j].z, ws[j].z, F.z, al.z, bt[j].z), one(fs[j].w, ws[j].w, F.w, al.w, bt[j].w)};
+        v4[j] = f4{fwd_state<GAMMA>(fs[j].x, ws[j].x, F.x, al.x, bt[j].x, gs, dpart), fwd_state<GAMMA>(fs[j].y, ws[j].y, F.y, al.y, bt[j].y, gs, dpart),
+                   fwd_state<GAMMA>(fs[j].z, ws[j].z, F.z, al.z, bt[j].z, gs, dpart), fwd_state<GAMMA>(fs[j].w, ws[j].w, F.w, al.w, bt[j].w, gs, dpart)};
         part += hsum(v4[j]);
       }
     }
@@ -344,7 +382,7 @@ struct TiedSeq {
     part_tot = 0.f;
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) {
+      if (plane_on(j)) {
         const f4 a = v4[j] + (leaky * cpi[j]) * asum;
         lds4_st(kA0 + own16 + j * kPlane, a);
         part_tot += hsum(a);
@@ -401,7 +439,7 @@ struct TiedSeq {
     const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs);
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) bst4(hist_t, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
+      if (plane_on(j)) bst4(hist_t, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
   }
 
   // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h); `bad` = NaN poisons the sequence
@@ -423,7 +461,7 @@ struct TiedSeq {
     const rsrc_t brow = make_rsrc(bhist + (int64_t)t * hist_step, 4u * Hs);
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) bst4(brow, own16 + j * kPlane, bown[j]);
+      if (plane_on(j)) bst4(brow, own16 + j * kPlane, bown[j]);
   }
 
   // ================================================================================================== backward
@@ -435,10 +473,15 @@ struct TiedSeq {
     part = 0.f;
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) part += hsum(leaky * bld4(r_pi, own16, j * kPlane)) * b_T;
+      if (plane_on(j)) part += hsum(leaky * bld4(r_pi, own16, j * kPlane)) * b_T;
     bsum = block_sum_a(part, aRed + 12u * kWaves, wave, lane);  // also orders the reuse of the gather buffer
     pb_cur = kPB;
     pb_next = ALPHA_LDS ? 4u * (uint32_t)p.L.off_p2 : kPB;
+    if constexpr (PW) {
+      stream_begin_pw(p.bwd, bbase, bmask, bsubn, mstride_b, bsec);
+      bnch = 0;
+      bfx0 = bfx1 = 0;
+    } else {
     const int2 brange = p.bwd.wave_range[wave];
 #ifdef TC_ABL_NOSTREAM
     bnch = RESB;
@@ -454,6 +497,7 @@ struct TiedSeq {
     bsec = aACC + 256u * (uint32_t)(K * kWaves + p.bwd.extra_first[wave]);
 #pragma unroll
     for (int i = 0; i < RESB; ++i) load_chunk(bres[i], bbase, lane16, i);
+    }
     {
       const rsrc_t hist_up = make_rsrc(hist + (int64_t)T * hist_step, 4u * Hs);
       const rsrc_t bT = make_rsrc(bhist + (int64_t)T * hist_step, PURE ? 4u * Hs : 0u);
@@ -461,7 +505,7 @@ struct TiedSeq {
 #pragma unroll
       for (int j = 0; j < JV; ++j) {
         bown[j] = areg[j] = mk4(0.f);
-        if (j < planes) {
+        if (plane_on(j)) {
           const int h0 = 4 * ((int)tid + kThreads * j);
           const float b = b_T + bsum;
           bown[j] = f4{h0 < H ? b : 0.f, h0 + 1 < H ? b : 0.f, h0 + 2 < H ? b : 0.f, h0 + 3 < H ? b : 0.f};
@@ -481,7 +525,7 @@ struct TiedSeq {
       __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = beta_T(g) * p_{T-1}(f(g))
 #pragma unroll
       for (int j = 0; j < JV; ++j)
-        if (j < planes) {
+        if (plane_on(j)) {
           const u4 fs = bld4u(r_fs, own16, j * kPlane);
           lds4_st(kA0 + own16 + j * kPlane,
                   f4{bown[j].x * ldsf(pb_cur + (fs.x & 0xffffu)), bown[j].y * ldsf(pb_cur + (fs.y & 0xffffu)),
@@ -526,7 +570,7 @@ struct TiedSeq {
       if (!PURE) {
         const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs);
 #pragma unroll
-        for (int j = 0; j < JV; ++j) areg[j] = j < planes ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
+        for (int j = 0; j < JV; ++j) areg[j] = plane_on(j) ? bld4(hist_t, own16, j * kPlane) : mk4(0.f);
       }
     }
     // beta'_t(h) * asum_t = sum over out-arcs of w * Y(dst): the same walk as forward, no atomics
@@ -547,7 +591,7 @@ struct TiedSeq {
           const rsrc_t brow_up = make_rsrc(bhist + (int64_t)(t + 1) * hist_step, 4u * Hs);
 #pragma unroll
           for (int j = 0; j < JV; ++j)
-            if (j < planes) bst4(brow_up, own16 + j * kPlane, bown[j]);
+            if (plane_on(j)) bst4(brow_up, own16 + j * kPlane, bown[j]);
         } else {
           const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)(t + 1) * S + s) * p.deriv_stride, row_bytes);
 #pragma unroll
@@ -592,7 +636,7 @@ struct TiedSeq {
 #pragma unroll
     for (int j = 0; j < JV; ++j) {
       b4[j] = mk4(0.f);
-      if (j < planes) {
+      if (plane_on(j)) {
         if (!kAhead) request(j);
         const u4 fs = fs_n;
         const f4 ws = ws_n;
@@ -602,29 +646,10 @@ struct TiedSeq {
         f4 a = own_rows(vrow, j);
         const f4 al = areg[j];  // alpha'_t of the owned states
         const f4 aup = (!PURE && ALPHA_LDS) ? lds4(aAL + own16 + j * kPlane) : aup_g;
-        // Everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
-        //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
-        //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
-        //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
-        // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history (measured against float64 on peaky
-        // outputs, profiles/r02_peaky.txt: keeping the un-dashed alpha in the history instead changes nothing).
-        // The self-loop arc also adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t.
-        auto one = [&](uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float ax) __attribute__((always_inline)) {
-          const float ps_ws = ldsf(pb_cur + (fsx >> 16)) * wsx;
-          if constexpr (!PURE) {
-            const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
-            const float bos = kGammaScale * bo;            // power-of-two scale: exact
-            gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
-#ifndef TC_ABL_NOFADD  /* (ablation: what the forward-class half of the gamma adds costs) */
-            gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
-#endif
-          }
-          return fmaf(ps_ws, bo, ax);                      // vf_s into beta'_t(g) * asum_t (PURE: into U_t(g))
-        };
-        a.x = one(fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x);
-        a.y = one(fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y);
-        a.z = one(fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z);
-        a.w = one(fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w);
+        a.x = bwd_state<PURE>(pb_cur, fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x, inv_as, asum_up);
+        a.y = bwd_state<PURE>(pb_cur, fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y, inv_as, asum_up);
+        a.z = bwd_state<PURE>(pb_cur, fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z, inv_as, asum_up);
+        a.w = bwd_state<PURE>(pb_cur, fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w, inv_as, asum_up);
         b4[j] = PURE ? a : a * inv_as;  // [K] * inv_arbitrary_scale
         fpk[j][0] = (fs.x & 0xffffu) | (fs.y << 16);
         fpk[j][1] = (fs.z & 0xffffu) | (fs.w << 16);
@@ -692,7 +717,7 @@ struct TiedSeq {
     // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
 #pragma unroll
     for (int j = 0; j < JV; ++j)
-      if (j < planes) {
+      if (plane_on(j)) {
         const f4 b = PURE ? b4[j] * inv_n + bsum : b4[j] + bsum;
         bown[j] = b;
         const f4 yv = f4{b.x * ldsf(pb_next + (fpk[j][0] & 0xffffu)), b.y * ldsf(pb_next + (fpk[j][0] >> 16)),
@@ -708,6 +733,199 @@ struct TiedSeq {
     const uint32_t tmp = pb_cur;
     pb_cur = pb_next;
     pb_next = tmp;
+    return false;
+  }
+
+  // ============================================================================================== plane-wise form
+  // Graphs of 16385..28672 positions (chain_internal.h: kJvPlanes).  The gather source takes 4 bytes per position of the
+  // 160 KB, so nothing else may be per-position in LDS and little per-state may wait in registers: a thread's states are
+  // taken one float4 ("plane") at a time -- request the plane's tables, walk its four rows (the wave's sub-stream of
+  // that plane: schedule_owner.cpp), run its per-state pass -- and the row sums of every plane share the wave's four
+  // accumulator rows.  What a frame keeps per owned state is ONE value: alpha_t until the block sum is known
+  // (forward), beta_{t+1} overwritten by beta'_t as each plane is passed (backward).  A wave's secondary rows (hub
+  // states) are its first sub-stream: their private slots are complete before any plane folds them in.
+  __device__ __forceinline__ void stream_begin_pw(const ScheduleDev &sc, rsrc_t &base, uint32_t &vmask, uint32_t &subn, int &mstride, uint32_t &sec) {
+    const int subs = planes + 1;
+    const int2 r0 = sc.wave_range[wave * subs], r1 = sc.wave_range[wave * subs + subs - 1];
+    const int first = __builtin_amdgcn_readfirstlane(r0.x) / kChunk;
+    const int total = (__builtin_amdgcn_readfirstlane(r1.x) + __builtin_amdgcn_readfirstlane(r1.y)) / kChunk - first;
+    base = make_rsrc(reinterpret_cast<const char *>(sc.cells) + (int64_t)first * (3 * 64 * 16), (uint32_t)(total + 2) * (3 * 64 * 16));
+    mstride = sc.mask_stride;
+    vmask = sc.masks[(size_t)(wave * subs) * sc.mask_stride + lane];  // (the array ends with a register's worth of padding)
+    subn = (int)lane < subs ? (uint32_t)(sc.wave_range[wave * subs + (int)lane].y / kChunk) : 0u;
+    sec = aACC + 256u * (uint32_t)(4 * kWaves + sc.extra_first[wave]);
+  }
+  __device__ __forceinline__ int sub_chunks(uint32_t subn, int sub) { return __builtin_amdgcn_readlane((int)subn, sub); }
+
+  // frame t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
+  __device__ __forceinline__ void forward_frame_pw(int t) {
+    static_assert(PW && !MITM && !ALPHA_LDS && RESF == 0 && RESB == 0, "plane-wise form: tight layout, nothing resident");
+    Chunk6 q0;
+    load_chunk(q0, fbase, lane16, 0);
+    __syncthreads();  // alpha'_{t-1}, exp(y_{t-1}) ready
+    f4 yreg[PV];
+    if (t < T) {  // y_t under the arc walks
+      const rsrc_t yrow = make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+    }
+    age_prio_on(wave);
+    int c0 = 0;
+    walk_sub<kA0>(q0, fbase, lane16, c0, sub_chunks(fsubn, 0), fmask, 0, RowCommit{fsec, fsec, 1 << 30});
+    const rsrc_t hist_prev = make_rsrc(hist + (int64_t)(t - 1) * hist_step, t > 1 ? 4u * Hs : 0u);  // (row 0 went out in forward_begin)
+    const RowCommit frc{aACC + 256u * (uint32_t)(4 * wave), fsec, 4};
+    part = 0.f;
+    float dpart = 0.f;
+#pragma unroll
+    for (int j = 0; j < JV; ++j) {
+      v4[j] = mk4(0.f);
+      if (plane_on(j)) {
+        // the history row of frame t-1 leaves plane by plane, each store ahead of its plane's walk
+        bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
+        const u4 fs = bld4u(r_fs, own16, j * kPlane);
+        const f4 ws = bld4(r_ws, own16, j * kPlane);
+        int fx0 = 0, fx1 = 0;
+        if (p.fwd.nfix) {
+          fx0 = p.fwd.fix_begin[(int)tid * planes + j];
+          fx1 = p.fwd.fix_begin[(int)tid * planes + j + 1];
+        }
+        walk_sub<kA0>(q0, fbase, lane16, c0, sub_chunks(fsubn, 1 + j), fmask, (1 + j) * mstride_f, frc);
+        for (int e = fx0; e < fx1; ++e) fold_row_pw(p.fwd.fix[e], vrow, aACC, Hs);
+        const f4 F = own_rows(vrow, 0);
+        const f4 al = lds4(kA0 + own16 + j * kPlane);  // alpha'_{t-1} of the owned states
+        v4[j] = f4{fwd_state<false>(fs.x, ws.x, F.x, al.x, 0.f, 0.f, dpart), fwd_state<false>(fs.y, ws.y, F.y, al.y, 0.f, 0.f, dpart),
+                   fwd_state<false>(fs.z, ws.z, F.z, al.z, 0.f, 0.f, dpart), fwd_state<false>(fs.w, ws.w, F.w, al.w, 0.f, 0.f, dpart)};
+        part += hsum(v4[j]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    f4 cpi[JV];
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (plane_on(j)) cpi[j] = bld4(r_pi, own16, j * kPlane);  // (first touched behind the reduction, which hides the L2 trip)
+    asum = block_sum_a(part, aRed, wave, lane);  // every wave has finished its walks: the gather buffer may change
+    __builtin_amdgcn_sched_barrier(0);
+    part_tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (plane_on(j)) {
+        const f4 a = v4[j] + (leaky * cpi[j]) * asum;
+        lds4_st(kA0 + own16 + j * kPlane, a);
+        part_tot += hsum(a);
+      }
+    if (t < T) {
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * ((int)tid + kThreads * v);
+        if (i0 < Ps) {
+          y2 += hsum(yreg[v] * yreg[v]);
+          lds4_st(kPB + 4u * i0, exp4(yreg[v]));
+        }
+      }
+    }
+    if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
+    inv_prev = __builtin_amdgcn_rcpf(asum);
+  }
+
+  // frame t = T-1..0   ([K] BetaDashGeneralFrame(t) + Beta(t)); returns true after frame 0
+  __device__ __forceinline__ bool backward_frame_pw(int t) {
+    Chunk6 q0;
+    load_chunk(q0, bbase, lane16, 0);
+    __syncthreads();  // Y, exp(y_t) ready; gamma zero
+    const float asum_t = ldsf(aAsum + 4u * t), asum_up = ldsf(aAsum + 4u * (t + 1));
+    const float inv_as = __builtin_amdgcn_rcpf(asum_t);
+    {
+      const int tn = t > 0 ? t - 1 : 0;  // (at t == 0 y re-reads frame 0)
+      const rsrc_t yrow = make_rsrc(p.y + ((int64_t)tn * S + s) * p.y_stride, row_bytes);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) ynext[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
+    }
+    age_prio_on(wave);
+    int c0 = 0;
+    walk_sub<kA0>(q0, bbase, lane16, c0, sub_chunks(bsubn, 0), bmask, 0, RowCommit{bsec, bsec, 1 << 30});
+    const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs), hist_up = make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs);
+    const RowCommit brc{aACC + 256u * (uint32_t)(4 * wave), bsec, 4};
+    part = 0.f;
+    float part_ab = 0.f, part_g = 0.f;
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (plane_on(j)) {
+        // the plane's tables and history values are requested ahead of its walk
+        const u4 fs = bld4u(r_fs, own16, j * kPlane);
+        const f4 ws = bld4(r_ws, own16, j * kPlane);
+        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
+        const f4 al = bld4(hist_t, own16, j * kPlane);    // alpha'_t of the owned states
+        const f4 aup = bld4(hist_up, own16, j * kPlane);  // alpha'_{t+1}
+        int fx0 = 0, fx1 = 0;
+        if (p.bwd.nfix) {
+          fx0 = p.bwd.fix_begin[(int)tid * planes + j];
+          fx1 = p.bwd.fix_begin[(int)tid * planes + j + 1];
+        }
+        walk_sub<kA0>(q0, bbase, lane16, c0, sub_chunks(bsubn, 1 + j), bmask, (1 + j) * mstride_b, brc);
+        for (int e = fx0; e < fx1; ++e) fold_row_pw(p.bwd.fix[e], vrow, aACC, Hs);
+        f4 a = own_rows(vrow, 0);
+        a.x = bwd_state<false>(kPB, fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x, inv_as, asum_up);
+        a.y = bwd_state<false>(kPB, fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y, inv_as, asum_up);
+        a.z = bwd_state<false>(kPB, fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z, inv_as, asum_up);
+        a.w = bwd_state<false>(kPB, fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w, inv_as, asum_up);
+        const f4 b = a * inv_as;  // [K] * inv_arbitrary_scale: beta'_t, which takes beta_{t+1}'s registers
+        part += hsum(cp * b);
+        if (t == 0) part_ab += hsum(al * b);
+        bown[j] = b;
+      }
+    __builtin_amdgcn_s_setprio(0);
+    u4 fsT[JV];  // the forward pdfs again, for the Y update behind the two barriers
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (plane_on(j)) fsT[j] = bld4u(r_fs, own16, j * kPlane);
+    bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
+    {
+      const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
+#pragma unroll
+      for (int v = 0; v < PV; ++v) {
+        const int i0 = 4 * ((int)tid + kThreads * v);
+        if (i0 < Ps) {
+          const u4 gu = lds4u(aGM + 4u * i0);
+          lds4_st(aGM + 4u * i0, mk4(0.f));
+          const f4 g = f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} * kGammaInvScale;
+          if (t == 0) part_g += hsum(g);
+          f4 o = p.deriv_weight * g - p.l2_scale * ycur[v];
+          if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
+          row_st(drow, own16 + v * kPlane, p.d_vec, o);
+        }
+      }
+      xent_zero_row(t);
+      if (t == 0) {
+        // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
+        const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
+        const float gsum = block_sum_a(part_g, aRed + 8u * kWaves, wave, lane);
+        if (tid == 0) {
+          p.seq_ab[s] = ab;
+          p.seq_gsum[s] = gsum;
+        }
+        return true;
+      }
+    }
+    // exp(y_{t-1}) overwrites exp(y_t) in place -- its readers are behind the reduction's barrier -- and one more barrier
+    // publishes it to the Y update
+#pragma unroll
+    for (int v = 0; v < PV; ++v) {
+      const int i0 = 4 * ((int)tid + kThreads * v);
+      if (i0 < Ps) lds4_st(kPB + 4u * i0, exp4(ynext[v]));
+    }
+    __syncthreads();
+    // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
+#pragma unroll
+    for (int j = 0; j < JV; ++j)
+      if (plane_on(j)) {
+        const f4 b = bown[j] + bsum;
+        bown[j] = b;
+        lds4_st(kA0 + own16 + j * kPlane,
+                f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)), b.z * ldsf(kPB + (fsT[j].z & 0xffffu)),
+                   b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
+      }
+#pragma unroll
+    for (int v = 0; v < PV; ++v) ycur[v] = ynext[v];
     return false;
   }
 };

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -477,17 +478,17 @@ namespace {
 // the kernel) while they are filled -- a third of the reader's time.  Freed examples wait here, emptied but with their
 // capacity, for the next read (a handful: the batches a training loop has in flight).
 constexpr size_t kExamplePoolMax = 12;
+// The pool has PROCESS lifetime (allocated once, never destroyed): look-ahead threads of a reader that is still alive when
+// the process exits (csrc/rand_reader.cpp) may be inside pool_take / tc_example_free while static destructors run, and a
+// pool destroyed under them would leave them with a dead mutex.  A few MB of capacity the OS reclaims with the process.
 struct ExamplePool {
   std::mutex mu;
   std::vector<tc_example *> v;
-  bool closed = false;  // (an example freed after this object: process teardown)
-  ~ExamplePool() {
-    std::lock_guard<std::mutex> lock(mu);
-    closed = true;
-    for (tc_example *ex : v) delete ex;
-    v.clear();
-  }
-} g_examples;
+};
+ExamplePool &examples() {
+  static ExamplePool *const pool = new ExamplePool();
+  return *pool;
+}
 
 void empty_example(Example *eg) {
   for (Io &io : eg->in) {
@@ -510,10 +511,11 @@ void empty_example(Example *eg) {
 }
 
 tc_example *pool_take() {
-  std::lock_guard<std::mutex> lock(g_examples.mu);
-  if (g_examples.closed || g_examples.v.empty()) return nullptr;
-  tc_example *ex = g_examples.v.back();
-  g_examples.v.pop_back();
+  ExamplePool &pool = examples();
+  std::lock_guard<std::mutex> lock(pool.mu);
+  if (pool.v.empty()) return nullptr;
+  tc_example *ex = pool.v.back();
+  pool.v.pop_back();
   return ex;
 }
 }  // namespace
@@ -566,20 +568,19 @@ int tc_example_read(const char *const *paths, const int64_t *offsets, int32_t n,
     return TC_ERR_IO;
   }
   try {
-    tc_example *ex = pool_take();
-    if (!ex) ex = new tc_example();
+    std::unique_ptr<tc_example> ex(pool_take());  // (owned here until it is handed out: a throwing merge leaks nothing)
+    if (!ex) ex.reset(new tc_example());
     if (n == 1 && !merge_single) {
       ex->eg = egs[0];  // (a copy: the scratch keeps its buffers)
     } else {
       const int rc = merge(egs, &ex->eg);
       if (rc != TC_OK) {
-        delete ex;
         g_example_error = "examples of a minibatch do not merge (inputs, weight, frames or label-dim differ, or a "
                           "supervision is not a connected acceptor of the stated length)";
         return rc;
       }
     }
-    *out = ex;
+    *out = ex.release();
   } catch (...) {
     g_example_error = "out of memory";
     return TC_ERR_IO;
@@ -591,9 +592,10 @@ void tc_example_free(tc_example *ex) {
   if (!ex) return;
   empty_example(&ex->eg);
   {
-    std::lock_guard<std::mutex> lock(g_examples.mu);
-    if (!g_examples.closed && g_examples.v.size() < kExamplePoolMax) {
-      g_examples.v.push_back(ex);
+    ExamplePool &pool = examples();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    if (pool.v.size() < kExamplePoolMax) {
+      pool.v.push_back(ex);
       return;
     }
   }

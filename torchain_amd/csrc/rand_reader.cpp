@@ -8,13 +8,16 @@
 //     recipe, example/chime5/parallel_train.py:26-75, splits one gathered batch on the host instead);
 //   * the next `lookahead` batches are read, parsed, merged and their supervision handles built on worker threads while
 //     the caller trains on the current one (round 3 did this in Python: 0.27 + 0.16 ms of interpreter time per step).
-// Host code only: no GPU is touched here (tc_supervision_create builds host tables; they reach the device with the
-// first loss call, through the per-device pool of supervision.cpp).
+// Host code, with one exception the caller asks for: after tc_rand_reader_set_device the look-ahead threads also fill the
+// pinned staging of each supervision's upload (tc_supervision_stage: hipSetDevice and the per-device pool's pinned /
+// device allocations of supervision.cpp, made on those threads).  Without that call no GPU is touched here --
+// tc_supervision_create builds host tables, which reach the device with the first loss call.
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -95,7 +98,24 @@ struct tc_rand_reader {
     for (size_t i = 0; i < per_rank; ++i) batches.push_back(std::move(all[i * (size_t)world + (size_t)rank]));
   }
 
-  Ready load(const std::vector<int32_t> &batch) const {
+  // (`dev`: the staging device as the caller read it under `mu`)
+  Ready load(const std::vector<int32_t> &batch, int dev) const {
+    Ready r;
+    try {
+      r = load_unguarded(batch, dev);
+    } catch (const std::exception &e) {  // (bad_alloc and whatever else: a failed batch, not std::terminate on a worker)
+      release(r);
+      r.rc = TC_ERR_IO;
+      r.error = std::string("reading a minibatch failed: ") + e.what();
+    } catch (...) {
+      release(r);
+      r.rc = TC_ERR_IO;
+      r.error = "reading a minibatch failed";
+    }
+    return r;
+  }
+
+  Ready load_unguarded(const std::vector<int32_t> &batch, int dev) const {
     Ready r;
     std::vector<const char *> paths;
     std::vector<int64_t> offs;
@@ -116,7 +136,7 @@ struct tc_rand_reader {
     r.rc = tc_example_output(r.example, 0, &name, &nidx, &idx, &dw, &weight, dims, &ab, &il, &aw, &nx, &fin);
     if (r.rc == TC_OK) r.rc = tc_supervision_create(&r.sup, weight, dims[0], dims[1], dims[2], dims[3], ab, il, aw, nx, fin);
     if (r.rc != TC_OK) r.error = "the minibatch's supervision does not build (tc_supervision_create)";
-    if (r.rc == TC_OK && device >= 0) (void)tc_supervision_stage(r.sup, device);  // (a failure shows at the first use)
+    if (r.rc == TC_OK && dev >= 0) (void)tc_supervision_stage(r.sup, dev);  // (a failure shows at the first use)
     return r;
   }
 
@@ -126,9 +146,17 @@ struct tc_rand_reader {
       cv_work.wait(lock, [&] { return stop || next_claim < want_until; });
       if (stop) return;
       const int64_t mine = next_claim++, my_epoch = epoch;
-      const std::vector<int32_t> batch = batches[(size_t)mine];
+      Ready r;
+      std::vector<int32_t> batch;
+      const int dev = device;  // (tc_rand_reader_set_device writes it under this lock)
+      try {
+        batch = batches[(size_t)mine];
+      } catch (...) {
+        r.rc = TC_ERR_IO;
+        r.error = "out of memory";
+      }
       lock.unlock();
-      Ready r = load(batch);
+      if (r.rc == TC_OK) r = load(batch, dev);
       lock.lock();
       if (my_epoch == epoch && !stop)
         done[mine] = r;
@@ -194,7 +222,12 @@ int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char
       const size_t colon = loc.rfind(':');
       if (colon != std::string::npos && colon + 1 < loc.size() &&
           loc.find_first_not_of("0123456789", colon + 1) == std::string::npos) {
-        e.offset = std::stoll(loc.substr(colon + 1));
+        try {
+          e.offset = std::stoll(loc.substr(colon + 1));
+        } catch (const std::exception &) {  // (out_of_range: more digits than an offset has)
+          g_error = "malformed scp line of key " + e.key + ": offset " + loc.substr(colon + 1);
+          return TC_ERR_BAD_FST;
+        }
         loc.resize(colon);
       }
       e.path = loc;
@@ -278,8 +311,9 @@ int tc_rand_reader_next(tc_rand_reader *r) {
     r->done.erase(want);
   } else {
     const std::vector<int32_t> batch = r->batches[(size_t)want];
+    const int dev = r->device;
     lock.unlock();
-    Ready got = r->load(batch);
+    Ready got = r->load(batch, dev);
     lock.lock();
     r->cur = got;
   }

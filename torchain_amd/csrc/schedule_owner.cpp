@@ -34,87 +34,97 @@ struct OwnerTask {
 
 static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std::vector<OwnerTask>>> &slots,
                               const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
-                              ScheduleHost *out) {
+                              ScheduleHost *out, bool planewise) {
   // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows
   out->conflict_cost = out->conflict_free_cost = out->conflict_bound = 0;
   out->cells.clear();
-  out->wave_range.assign(kWaves, make_int2(0, 0));
-  std::vector<std::vector<uint32_t>> wave_masks(kWaves);
+  // plane-wise form: per wave, sub-stream 0 = its secondary rows, sub-stream 1 + j = the four rows of plane j
+  const int subs = planewise ? K / 4 + 1 : 1;
+  const int off_shift = planewise ? 16 : 18;  // the cell's 16-bit offset field: position, or position * 4
+  out->subs = planewise ? subs : 0;
+  out->wave_range.assign((size_t)kWaves * subs, make_int2(0, 0));
+  std::vector<std::vector<uint32_t>> wave_masks((size_t)kWaves * subs);
   std::vector<std::vector<char>> wave_row_end;  // per wave and pair of cells: flags A | B
   int64_t arc_cells = 0;
   int nrows = 0;
-  for (int w = 0; w < kWaves; ++w) {
-    const size_t first = out->cells.size() / 64;
-    size_t cells_before = 0;
-    std::vector<char> row_end;  // per pair of this wave: flags A | B
-    for (size_t k = 0; k < slots[w].size(); ++k) {
-      const auto &tasks = slots[w][k];
-      int steps = 1;  // rows need not be whole pairs: a pair may straddle two rows (flag A below)
-      for (const OwnerTask &t : tasks) steps = std::max(steps, t.len);
-      const size_t off = out->cells.size();
-      out->cells.resize(off + (size_t)steps * 64, ArcRec{0.f, 0u});
-      arc_cells += (int64_t)steps * 64;
-      for (int half = 0; half < 2; ++half) {
-        std::vector<std::vector<int64_t>> lane_arcs(32);
-        for (int l = 0; l < 32; ++l) {
-          const OwnerTask &t = tasks[half * 32 + l];
-          for (int i = 0; i < t.len; ++i) lane_arcs[l].push_back(order[t.begin + i]);
-          if (t.len > 0) ++nrows;
-        }
-        std::vector<std::vector<int>> pos, padb;
-        if (debug_flag(kDbgOldArrange)) {
-          out->conflict_cost += arrange_half(lane_arcs, steps, opos, nullptr, &pos);
-        } else {
-          int lb = 0;
-          out->conflict_cost += arrange_half_matching(lane_arcs, steps, opos, &pos, &padb, &lb);
-          out->conflict_bound += lb;
-        }
-        out->conflict_free_cost += steps;
-        for (int l = 0; l < 32; ++l) {
-          const int lane = half * 32 + l;
-          for (int i = 0; i < steps; ++i) {
-            ArcRec &cell = out->cells[off + (size_t)i * 64 + lane];
-            if (pos[l][i] >= 0) {
-              const int64_t a = lane_arcs[l][pos[l][i]];
-              cell = ArcRec{prob[a], (uint32_t)opos[a] << 18};
-            } else {
-              // padding: w = 0, gathered from a bank that is idle in this step
-              cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? (padb.empty() ? l : padb[l][i]) : 0) << 18};
+  for (int w = 0; w < kWaves; ++w)
+    for (int sub = 0; sub < subs; ++sub) {
+      const size_t first = out->cells.size() / 64;
+      size_t cells_before = 0;
+      std::vector<char> row_end;  // per pair of this stream: flags A | B
+      const size_t k0 = !planewise ? 0 : sub == 0 ? (size_t)K : (size_t)4 * (sub - 1);
+      const size_t k1 = !planewise ? slots[w].size() : sub == 0 ? slots[w].size() : (size_t)4 * sub;
+      for (size_t k = k0; k < k1; ++k) {
+        const auto &tasks = slots[w][k];
+        int steps = 1;  // rows need not be whole pairs: a pair may straddle two rows (flag A below)
+        for (const OwnerTask &t : tasks) steps = std::max(steps, t.len);
+        const size_t off = out->cells.size();
+        out->cells.resize(off + (size_t)steps * 64, ArcRec{0.f, 0u});
+        arc_cells += (int64_t)steps * 64;
+        for (int half = 0; half < 2; ++half) {
+          std::vector<std::vector<int64_t>> lane_arcs(32);
+          for (int l = 0; l < 32; ++l) {
+            const OwnerTask &t = tasks[half * 32 + l];
+            for (int i = 0; i < t.len; ++i) lane_arcs[l].push_back(order[t.begin + i]);
+            if (t.len > 0) ++nrows;
+          }
+          std::vector<std::vector<int>> pos, padb;
+          if (debug_flag(kDbgOldArrange)) {
+            out->conflict_cost += arrange_half(lane_arcs, steps, opos, nullptr, &pos);
+          } else {
+            int lb = 0;
+            out->conflict_cost += arrange_half_matching(lane_arcs, steps, opos, &pos, &padb, &lb);
+            out->conflict_bound += lb;
+          }
+          out->conflict_free_cost += steps;
+          for (int l = 0; l < 32; ++l) {
+            const int lane = half * 32 + l;
+            for (int i = 0; i < steps; ++i) {
+              ArcRec &cell = out->cells[off + (size_t)i * 64 + lane];
+              if (pos[l][i] >= 0) {
+                const int64_t a = lane_arcs[l][pos[l][i]];
+                cell = ArcRec{prob[a], (uint32_t)opos[a] << off_shift};
+              } else {
+                // padding: w = 0, gathered from a bank that is idle in this step
+                cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? (padb.empty() ? l : padb[l][i]) : 0) << off_shift};
+              }
             }
           }
         }
+        cells_before += steps;
+        row_end.resize((cells_before + 1) / 2, 0);
+        // bit 0 (B): the row ends with the pair's second cell; bit 1 (A): with its first cell
+        row_end[(cells_before - 1) / 2] |= ((cells_before - 1) & 1) ? 1 : 2;
       }
-      cells_before += steps;
-      row_end.resize((cells_before + 1) / 2, 0);
-      // bit 0 (B): the row ends with the pair's second cell; bit 1 (A): with its first cell
-      row_end[(cells_before - 1) / 2] |= ((cells_before - 1) & 1) ? 1 : 2;
+      // whole chunks, and (one stream per wave) at least kTiedMinChunks of them: the walks keep a prefix in registers
+      while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 ||
+             (!planewise && out->cells.size() / 64 - first < (size_t)kTiedMinChunks * kStreamUnrollTied))
+        for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
+      row_end.resize((out->cells.size() / 64 - first + 1) / 2, 0);  // the padding cells end no row
+      out->wave_range[(size_t)w * subs + sub] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
+      if (debug_flag(kDbgSchedTrace))
+        fprintf(stderr, "[sched] wave %d sub %d: %d cells, %zu rows\n", w, sub, out->wave_range[(size_t)w * subs + sub].y, k1 - k0);
+      auto &mw = wave_masks[(size_t)w * subs + sub];
+      mw.assign((row_end.size() + 7) / 8, 0u);
+      for (size_t i = 0; i < row_end.size(); ++i) {
+        if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
+        if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
+      }
+      wave_row_end.push_back(row_end);
     }
-    // whole chunks, and at least kTiedMinChunks of them (the walks keep a prefix of the stream in registers)
-    while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 ||
-           out->cells.size() / 64 - first < (size_t)kTiedMinChunks * kStreamUnrollTied)
-      for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
-    row_end.resize((out->cells.size() / 64 - first) / 2, 0);  // the padding cells end no row
-    out->wave_range[w] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
-    if (debug_flag(kDbgSchedTrace)) fprintf(stderr, "[sched] wave %d: %d cells, %zu rows\n", w, out->wave_range[w].y, slots[w].size());
-    auto &mw = wave_masks[w];
-    mw.assign((row_end.size() + 7) / 8, 0u);
-    for (size_t i = 0; i < row_end.size(); ++i) {
-      if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
-      if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
-    }
-    wave_row_end.push_back(row_end);
-  }
   // readable padding: the kernels request up to four chunks past a wave's range
   for (int i = 0; i < 64 * 32; ++i) out->cells.push_back(ArcRec{0.f, 0u});
   size_t stride = 1;
   for (auto &mw : wave_masks) stride = std::max(stride, mw.size());
-  stride += 2;  // the walk prefetches one word ahead
+  if (!planewise) stride += 2;  // (the walk once prefetched a word ahead)
   out->mask_stride = (int32_t)stride;
-  out->masks.assign(stride * kWaves, 0u);
-  for (int w = 0; w < kWaves; ++w) std::copy(wave_masks[w].begin(), wave_masks[w].end(), out->masks.begin() + w * stride);
+  out->masks.assign(stride * wave_masks.size() + 64, 0u);  // (+ a register's worth: the kernels read 64 words per wave)
+  for (size_t i = 0; i < wave_masks.size(); ++i) std::copy(wave_masks[i].begin(), wave_masks[i].end(), out->masks.begin() + i * stride);
   // row-register images (den_tied_rr.hip): cell i of a wave's stream belongs to row (number of row ends before it); rows
   // beyond 15 -- secondary rows of hub states, which that kernel does not take -- are capped
-  {
+  out->images.clear();
+  out->img_stride = out->max_chunks = 0;
+  if (!planewise) {
     size_t max_chunks = 1;
     for (auto &re : wave_row_end) max_chunks = std::max(max_chunks, (re.size() + 3) / 4);
     out->img_stride = (int32_t)std::max<size_t>(max_chunks + 4, 16);  // (+ the chunks a walk may request ahead; a register's worth)
@@ -149,7 +159,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       uint32_t *base = &out->cells6[chunk * 3 * 64 * 4];
       base[((i / 4) * 64 + l) * 4 + (i % 4)] = x;
       uint32_t &o = base[(2 * 64 + l) * 4 + i / 2];
-      const uint32_t off16 = cell.idx >> 16;  // position * 4
+      const uint32_t off16 = cell.idx >> 16;  // position * 4 (plane-wise form: position)
       o |= (i & 1) ? off16 << 16 : off16;
     }
   out->cells.clear();
@@ -161,7 +171,9 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
 bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row) {
   const int H = g->work_H;  // states of the work graph (tc_den_graph::work_*)
   const int Npos = 4096 * ((H + 4095) / 4096);
-  if (Npos > kMaxIndex) return false;
+  // beyond 16384 positions: the plane-wise form (chain_internal.h: kJvPlanes), whose rows need not be short either
+  const bool planewise = Npos > kMaxIndex;
+  if (Npos > kMaxPlanePositions || (planewise && debug_flag(kDbgNoPlanes))) return false;
   const int K = Npos / kThreads;
   std::vector<int32_t> src, dst;
   std::vector<float> prob;
@@ -277,7 +289,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
   // A wave's stream is padded to whole chunks of 8 steps, and a chunk of padding costs a walk as much as a chunk of arcs:
   // dealt by load alone, 10 of C3's 16 forward streams were 57 steps -- 8 chunks -- long.  Groups trade places between
   // waves while that lowers the number of chunks (first the longest stream's, then the sum over waves and directions).
-  {
+  if (!planewise) {
     auto chunks = [](int64_t steps) { return (std::max<int64_t>(steps, (int64_t)kTiedMinChunks * kStreamUnrollTied) + kStreamUnrollTied - 1) / kStreamUnrollTied; };
     auto cost = [&]() {
       int64_t mx_in = 0, mx_out = 0, sum = 0;
@@ -508,17 +520,33 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     out->extra_slots = 64 * extra_first[kWaves];
     extra_total[dir] = out->extra_slots;
     out->fix.clear();
-    out->fix_begin.assign(kThreads + 1, 0);
-    for (int t = 0; t < kThreads; ++t) {
-      out->fix_begin[t] = (int)out->fix.size();
-      for (auto &f : fix_of_thread[t]) out->fix.push_back(f);
+    if (planewise) {
+      // per thread AND plane: the pass of a plane folds that plane's secondary rows
+      const int planes = K / 4;
+      out->fix_begin.assign((size_t)kThreads * planes + 1, 0);
+      for (int t = 0; t < kThreads; ++t)
+        for (int j = 0; j < planes; ++j) {
+          out->fix_begin[(size_t)t * planes + j] = (int)out->fix.size();
+          for (auto &f : fix_of_thread[t])
+            if (f.x / (4 * kThreads) == j) out->fix.push_back(f);
+        }
+      out->fix_begin[(size_t)kThreads * planes] = (int)out->fix.size();
+    } else {
+      out->fix_begin.assign(kThreads + 1, 0);
+      for (int t = 0; t < kThreads; ++t) {
+        out->fix_begin[t] = (int)out->fix.size();
+        for (auto &f : fix_of_thread[t]) out->fix.push_back(f);
+      }
+      out->fix_begin[kThreads] = (int)out->fix.size();
     }
-    out->fix_begin[kThreads] = (int)out->fix.size();
     out->nfix = (int32_t)out->fix.size();
     if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
-    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out);
+    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise);
+    if (planewise && (int64_t)out->subs * out->mask_stride > 64) return false;  // (a wave's mask words live in one register)
   }
-  if (!compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), true, &g->layout)) return false;
+  if (planewise ? !compute_layout_planes(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), &g->layout)
+                : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), true, &g->layout))
+    return false;
   // per-state tables in position order
   std::vector<uint32_t> fs(Npos + 4, 0u);
   std::vector<float> ws(Npos + 4, 0.f);
@@ -615,7 +643,7 @@ bool make_work_graph(tc_den_graph *g) {
   // nearly tied graphs of 3000 / 6000 states with 60-90 % of the states entered through 2-3 pdfs (one MI355X,
   // 256 x 150, tied vs general): 1.77 vs 2.04 ms at 1.9x the states, 1.54 vs 2.04 at 2.3x; across the 8192-state
   // step 2.63 vs 3.26 at 1.9x but 3.56 vs 3.24 at 2.3x.
-  if (WH > kMaxIndex) return false;
+  if (WH > kMaxPlanePositions) return false;
   if (WH <= 8192 ? WH > (int64_t)H * 5 / 2 + 64 : WH > 2 * (int64_t)H + 64) return false;
   std::vector<int32_t> ws, wd, wp;
   std::vector<float> ww;

@@ -53,13 +53,18 @@ struct DevPool {
   std::mutex mu;
   std::vector<PoolSlot *> idle;
 };
-std::mutex g_pools_mu;
-std::map<int, DevPool> g_pools;
+// (process lifetime, never destroyed: a reader's look-ahead threads may stage supervisions while static destructors run at
+// exit -- csrc/rand_reader.cpp, and the same reasoning as the example pool of csrc/egs_reader.cpp)
+struct Pools {
+  std::mutex mu;
+  std::map<int, DevPool> by_device;
+};
 std::atomic<int64_t> g_pool_device_allocs{0}, g_pool_reuses{0};
 
 DevPool &pool_of(int device) {
-  std::lock_guard<std::mutex> lock(g_pools_mu);
-  return g_pools[device];
+  static Pools *const pools = new Pools();
+  std::lock_guard<std::mutex> lock(pools->mu);
+  return pools->by_device[device];
 }
 }  // namespace
 

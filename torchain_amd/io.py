@@ -22,35 +22,6 @@ def _tuning_cache_path():
     return os.environ.get("TORCHAIN_TUNING_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "torchain_amd", "tuning.json")
 
 
-def _tuning_cache_get(key):
-    """The measured kernel choice of a graph on a kind of device from an earlier run, or None (any failure: None)."""
-    import json
-    try:
-        with open(_tuning_cache_path()) as f:
-            return json.load(f).get(key)
-    except (OSError, ValueError):
-        return None
-
-
-def _tuning_cache_put(key, entry):
-    import json
-    path = _tuning_cache_path()
-    try:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        try:
-            with open(path) as f:
-                table = json.load(f)
-        except (OSError, ValueError):
-            table = {}
-        table[key] = entry
-        tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "w") as f:
-            json.dump(table, f, indent=1, sort_keys=True)
-        os.replace(tmp, path)
-    except OSError:
-        pass  # (a read-only home: the choice is timed again next run)
-
-
 def set_kaldi_device(device_id=0):
     """Reference ``io.py:15-17`` re-points Kaldi's process-wide CuDevice singleton at a torch
     device.  The HIP path is stateless (device and stream are explicit arguments of every call), so
@@ -118,25 +89,17 @@ class DenominatorGraph:
         an earlier run measured for this graph on this kind of device (a JSON cache: ``$TORCHAIN_TUNING_CACHE`` or
         ``~/.cache/torchain_amd/tuning.json``, keyed by ``tc_den_graph_hash`` and the device name), else the library
         times the two kernels once and the result goes into that cache.  So the choice -- and with it the last bits of
-        the results -- is the same from run to run and from rank to rank."""
+        the results -- is the same from run to run and from rank to rank.  Since round 5 the cache is the LIBRARY's
+        (``csrc/tuning_cache.cpp``, inside ``tc_den_graph_prepare``): a caller of the C ABI gets the same without this
+        class."""
         dev = torch.cuda.current_device() if device is None else torch.device(device).index
         dev = int(dev or 0)
         done = self.__dict__.setdefault("_prepared", {})
         if dev in done and variant is None:
             return self
-        key = "%016x:%s" % (int(lib.tc_den_graph_hash(self.ptr)), torch.cuda.get_device_name(dev))
-        choice = variant
-        if choice is None and dev not in done:
-            entry = _tuning_cache_get(key)
-            if entry is not None:
-                choice = int(entry.get("two_sequence_kernel", 0))
-        if choice is not None:
-            check(lib.tc_den_graph_set_variant(self.ptr, dev, int(choice)), "tc_den_graph_set_variant")
-        check(lib.tc_den_graph_prepare(self.ptr, dev), "tc_den_graph_prepare")
-        if choice is None:
-            t = self.tuning(dev)
-            if t["fused_ms"] > 0.0 and t["two_sequence_ms"] > 0.0:  # (really timed: not switched off, not unfit)
-                _tuning_cache_put(key, t)
+        if variant is not None:
+            check(lib.tc_den_graph_set_variant(self.ptr, dev, int(variant)), "tc_den_graph_set_variant")
+        check(lib.tc_den_graph_prepare(self.ptr, dev), "tc_den_graph_prepare")  # (looks the graph up in the cache, or times)
         done[dev] = True
         return self
 
@@ -326,15 +289,20 @@ class RandExample(Example):
     ``frames_per_sequence`` into minibatches, shuffles inside and across groups and merges each minibatch
     ([K] MergeChainExamples) -- reference ``io.py:138-175`` over ``src/my_lib_example_rand.cpp:35-177``.  The
     length file (``scp_path + ".len"`` unless given) holds ``key length`` pairs; without it the lengths are read
-    from the egs.  The shuffle uses NumPy's MT19937 seeded with ``seed``: the same generator as the reference's
-    ``std::mt19937`` but not the same draw order as ``std::shuffle``, whose algorithm is not specified."""
+    from the egs.  The shuffle of the default (native) reader is a Fisher-Yates pass over ``std::mt19937`` draws
+    (``csrc/rand_reader.cpp``): the reference's generator, but not the draw order of its ``std::shuffle``, whose algorithm
+    is not specified -- and not the order round 3's Python reader (``native=False``: NumPy's MT19937 shuffle) gives for
+    the same ``seed``: the batch order for a given seed changed when the native reader became the default in round 4."""
 
     def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True, rank=0, world=1, native=True, device=None):
         """``rank`` / ``world``: this process's share of a data-parallel job (every rank forms the same shuffled list of
         minibatches from ``seed`` and takes every ``world``-th; all ranks get the same number).  ``native`` (default): the
         whole reader -- bucketing, shuffle, look-ahead threads, merge, supervision handles -- is the library's
         ``tc_rand_reader_*`` handle, as the reference's is ``my_lib_example_rand_reader_*`` (``src/my_lib.h:8-17``);
-        ``device`` is the GPU the batches are for (default: the current one, when there is one).
+        ``device`` is the GPU the batches are for: given explicitly, the look-ahead threads also fill the pinned staging of
+        each supervision's upload (they then touch that GPU: ``hipSetDevice`` / pinned allocations on worker threads); left
+        ``None``, building the reader touches no GPU -- a script may still fork or re-launch itself -- and the staging starts
+        with the first ``next()`` made after the process has initialised CUDA, for the then current device.
         ``native=False`` keeps the Python statement of it below (NumPy's MT19937 shuffle, a thread pool), which needs
         ``rank == 0, world == 1``."""
         assert os.path.exists(scp_path)
@@ -355,12 +323,12 @@ class RandExample(Example):
             self._native = handle
             self._cur = None
             self._have = False
-            # the GPU the minibatches are for (default: the current one): the look-ahead threads then also fill the pinned
-            # staging of each supervision's upload, which otherwise falls to the training thread's first use of it
-            if device is None and torch.cuda.is_available():
-                device = torch.cuda.current_device()
+            # the GPU the minibatches are for: the look-ahead threads then also fill the pinned staging of each supervision's
+            # upload, which otherwise falls to the training thread's first use of it.  Only an EXPLICIT device is set here:
+            # asking torch for the current one would initialise the GPU context in a constructor (see the docstring).
+            self._staging_device = None
             if device is not None:
-                check(lib.tc_rand_reader_set_device(handle, int(torch.device("cuda", device).index if not isinstance(device, int) else device)), "tc_rand_reader_set_device")
+                self._set_staging_device(int(torch.device("cuda", device).index if not isinstance(device, int) else device))
             return
         if rank != 0 or world != 1:
             raise ValueError("the Python reader does not shard: use native=True")
@@ -388,6 +356,10 @@ class RandExample(Example):
         self._shuffle_keys()
         self._pos = -1
         self._cur = None
+
+    def _set_staging_device(self, index):
+        check(lib.tc_rand_reader_set_device(self._native, int(index)), "tc_rand_reader_set_device")
+        self._staging_device = int(index)
 
     def _shuffle_keys(self):
         self._key_batch = []
@@ -472,6 +444,8 @@ class RandExample(Example):
 
     def next(self):
         if self._native is not None:
+            if self._staging_device is None and torch.cuda.is_available() and torch.cuda.is_initialized():
+                self._set_staging_device(torch.cuda.current_device())  # (the process uses the GPU by now: no new context)
             rc = lib.tc_rand_reader_next(self._native)
             self._cur = None
             self._have = rc == 1
