@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../torchain_amd/csrc"
 name=$1; shift
 mkdir -p ../../scratch_abl
-all="den_kernels den_tied_kernel den_tied_rr den_tied_split den_tied_pair den_tied_mitm den_slab_kernel"
+all="den_kernels den_tied_kernel den_tied_planes den_tied_rr den_tied_split den_tied_pair den_tied_mitm den_slab_kernel"
 only=${ONLY:-$all}
 objs=""
 for f in $all; do
@@ -18,4 +18,4 @@ for f in $all; do
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_abl/lib_$name.so den_graph.o den_layout.o schedule_general.o schedule_owner.o supervision.o supervision_merge.o egs_reader.o rand_reader.o self_test.o api.o $objs num_kernels.o layout_kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../scratch_abl/lib_$name.so den_graph.o den_layout.o schedule_general.o schedule_owner.o supervision.o supervision_merge.o egs_reader.o rand_reader.o self_test.o tuning_cache.o api.o $objs num_kernels.o layout_kernels.o

@@ -50,10 +50,13 @@ int big_hb(const tc_den_graph *g) { return g->big ? g->big_hb : 0; }
 bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq && !(g->layout_ok && g->layout.planewise); }
 // Tied on-chip graphs of at most 8192 positions may run two sequences per workgroup (den_tied_pair.hip): two more
 // history rows, the two roles' normalisers and the pairing words.
+// ... and the plane-wise kernel of 16385..28672 positions keeps one more history row (den_tied_planes.hip)
+bool planes_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.planewise; }
 bool pair_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.JV == kJvSmall; }
 
 // big_P != 0 selects the streamed path's layout: sequences padded to slabs of 16, [slab][state][16] matrices
-Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, int big_G = 16, int big_hb = 0, bool split = false, bool pair = false) {
+Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, int big_G = 16, int big_hb = 0, bool split = false, bool pair = false,
+                bool planes = false) {
   Workspace w;
   const int Sp = (S + big_G - 1) / big_G * big_G;
   size_t off = 0;
@@ -62,8 +65,8 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
     off += align256(bytes);
     return p;
   };
-  // (pair form: row T + 1 holds the backward role's B_M)
-  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair ? 2 : 1)) * S * Hs * sizeof(float));
+  // (pair form: row T + 1 holds the backward role's B_M; plane-wise form: beta'_t of the running backward frame)
+  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair || planes ? 2 : 1)) * S * Hs * sizeof(float));
   w.den_lp = (double *)take((size_t)S * 8);
   w.num_lp = (double *)take((size_t)S * 8);
   w.xent_lp = (double *)take((size_t)S * 8);
@@ -135,7 +138,8 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
     p->L.Hs = (nstates + 3) & ~3;
     p->L.Ps = (g->P + 3) & ~3;
     tied = false;  // the on-chip tied kernel's tables are not used; p->big.tied selects the streamed variant
-  } else if (!compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
+  } else if (g->layout.planewise ? !compute_layout_planes(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &p->L)
+                                 : !compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
     return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit LDS
   }
   p->big = d.big;
@@ -270,7 +274,7 @@ int tune_den_variant(tc_den_graph *g, int device) {
   if (hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || num_cus < 2)
     return finish();
   const int S = num_cus & ~1, T = kTuneFrames, P = g->P;
-  const Workspace w0 = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
+  const Workspace w0 = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g));
   const size_t ybytes = (size_t)S * T * P * sizeof(float);
   char *mem = nullptr;
   hipStream_t stream = nullptr;
@@ -283,7 +287,7 @@ int tune_den_variant(tc_den_graph *g, int device) {
     float *y = (float *)mem, *deriv = (float *)(mem + ybytes);
     char *wsp = mem + 2 * ybytes;
     wsp += (256 - ((uintptr_t)wsp & 255)) & 255;
-    const Workspace w = carve(wsp, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
+    const Workspace w = carve(wsp, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g));
     DenParams p[2];
     for (int variant = 0; variant < 2 && ok; ++variant) {
       d.pair_choice = variant;
@@ -371,7 +375,7 @@ uint64_t tc_den_graph_hash(const tc_den_graph *g) {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g)).total;
+  return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g)).total;
 }
 
 int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t rows, int32_t cols,
@@ -380,7 +384,7 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
   const int T = (int)(rows / S);
-  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
+  Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -435,7 +439,7 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
-  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, sup->S), pair_room(g));
+  Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, sup->S), pair_room(g), planes_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
   DeviceGuard guard(device);
   if (!guard.ok) return TC_ERR_HIP;
@@ -566,7 +570,7 @@ StepWorkspace carve_step(char *base, const tc_den_graph *g, int S, int T, int P,
     off += align256(bytes);
     return p;
   };
-  w.chain_bytes = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g)).total;
+  w.chain_bytes = carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g)).total;
   w.chain = take(w.chain_bytes);
   w.trace = take((size_t)trace_workspace_bytes());
   const size_t mat = (size_t)S * T * P * sizeof(float);
@@ -631,7 +635,7 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   // Kaldi's cross-entropy objective sum(xent_output * xent_deriv) ([K] nnet-chain-training.cc; a TODO in the reference,
   // torchain/functions.py:88-89): xent_objf_dev receives it times `xscale`, summed by the numerator over the entries it
   // writes (tc_xent_objf is the dense statement of the same sum)
-  const Workspace wi = carve((char *)w.chain, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g));
+  const Workspace wi = carve((char *)w.chain, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g));
   if (second_only && xent_objf_dev) {
     DeviceGuard guard(device);
     if (!guard.ok) return TC_ERR_HIP;

@@ -704,7 +704,10 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
       }
     for (int w = 0; w < kWaves; ++w)
      for (int sub = 0; sub < subs; ++sub) {
-      const int first = sc.wave_range[(size_t)w * subs + sub].x, n = sc.wave_range[(size_t)w * subs + sub].y;
+      // (plane-wise form: .y is the sub-stream's END counted from the wave's first cell, and the mask bytes are the wave's)
+      const int first = sc.wave_range[(size_t)w * subs + sub].x;
+      const int rel = pw ? first - sc.wave_range[(size_t)w * subs].x : 0;
+      const int n = sc.wave_range[(size_t)w * subs + sub].y - rel;
       for (int l = 0; l < 64; ++l) {
         const int tid = 64 * w + l;
         int k = !pw ? 0 : sub == 0 ? K : 4 * (sub - 1);  // (sub-stream 0: the wave's secondary rows)
@@ -725,8 +728,14 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
           int p0, p1;
           cell(i, &w0, &p0);
           cell(i + 1, &w1, &p1);
-          const uint32_t m = sc.masks[((size_t)w * subs + sub) * sc.mask_stride + (i / 2) / 8];
-          const int bit = (i / 2) % 8;
+          uint32_t m = sc.masks[((size_t)w * subs + sub) * sc.mask_stride + (i / 2) / 8];
+          int bit = (i / 2) % 8;
+          if (pw) {  // one byte per chunk of the wave's stream; re-stated in the pair form the loop below tests
+            const int cell = rel + i, chunk = cell / 8;
+            const uint32_t byte = (sc.masks[(size_t)w * sc.mask_stride + chunk / 4] >> (8 * (chunk % 4))) & 0xffu;
+            m = (((byte >> (cell % 8)) & 1u) << 8) | ((byte >> (cell % 8 + 1)) & 1u);
+            bit = 0;
+          }
           if ((m >> (8 + bit)) & 1u) {  // the row ends with the pair's first cell
             acc[slot()] = (ax + w0 * src_pos[p0]) + ay;
             ++k;

@@ -190,28 +190,17 @@ struct RowCommit {
 // faster per cell but need 14-21 % more cells; issuing the next chunk's gathers ahead of this chunk's sums
 // gains nothing; without any row ends the same loop would run 1.6x faster -- the commits, two taken branches
 // each, are what the rows cost.)
-template <uint32_t SRC, int HALF, bool WIDE = false>
+template <uint32_t SRC, int HALF>
 __device__ __forceinline__ void do_chunk(const Chunk6 &q, uint32_t m, float &acc, RowCommit &rc) {
   uint32_t o[8];
-  if constexpr (WIDE) {
-    o[0] = lo16w(q.oc.x);
-    o[1] = hi16w(q.oc.x);
-    o[2] = lo16w(q.oc.y);
-    o[3] = hi16w(q.oc.y);
-    o[4] = lo16w(q.oc.z);
-    o[5] = hi16w(q.oc.z);
-    o[6] = lo16w(q.oc.w);
-    o[7] = hi16w(q.oc.w);
-  } else {
-    o[0] = lo16(q.oc.x);
-    o[1] = hi16(q.oc.x);
-    o[2] = lo16(q.oc.y);
-    o[3] = hi16(q.oc.y);
-    o[4] = lo16(q.oc.z);
-    o[5] = hi16(q.oc.z);
-    o[6] = lo16(q.oc.w);
-    o[7] = hi16(q.oc.w);
-  }
+  o[0] = lo16(q.oc.x);
+  o[1] = hi16(q.oc.x);
+  o[2] = lo16(q.oc.y);
+  o[3] = hi16(q.oc.y);
+  o[4] = lo16(q.oc.z);
+  o[5] = hi16(q.oc.z);
+  o[6] = lo16(q.oc.w);
+  o[7] = hi16(q.oc.w);
   float a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -305,31 +294,31 @@ __device__ __forceinline__ void walk(const Chunk6 (&res)[RES > 0 ? RES : 1], Chu
 #endif
 }
 
-// Plane-wise form: a wave's stream is a run of sub-streams (its secondary rows, then one per plane), each a whole number
-// of chunks with mask words of its own (schedule_owner.cpp), and the per-state pass of a plane runs between two of them.
-// The stream is one: the look-ahead load at the end of a sub-stream brings the first chunk of the next, so `qa` arrives
-// loaded with chunk c0 and leaves loaded with chunk c0 + n (an odd sub-stream pays twelve moves for that).  Mask word i of
-// the sub-stream is lane m0 + i of `vmask`.
+// Plane-wise form (den_tied_planes.hip): acc(row) += w * SRC[4 * position] over one chunk; m8 = the chunk's row-end byte
+// (bit i: a row ends with cell i -- schedule_owner.cpp keeps one byte per chunk for this form).
 template <uint32_t SRC>
-__device__ __forceinline__ void walk_sub(Chunk6 &qa, rsrc_t sbase, uint32_t lane16, int &c0, int n, uint32_t vmask, int m0,
-                                         RowCommit rc) {
-  auto mk = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)vmask, m0 + i); };
-  float acc = 0.f;
-  Chunk6 qb;
-  int c = 0;
-  for (; c + 2 <= n; c += 2) {
-    const uint32_t m = mk(c >> 1);
-    load_chunk(qb, sbase, lane16, c0 + c + 1);
-    do_chunk<SRC, 0, true>(qa, m, acc, rc);
-    load_chunk(qa, sbase, lane16, c0 + c + 2);
-    do_chunk<SRC, 1, true>(qb, m, acc, rc);
+__device__ __forceinline__ void chunk_pw(const Chunk6 &q, uint32_t m8, float &acc, RowCommit &rc) {
+  uint32_t o[8];
+  o[0] = lo16w(q.oc.x);
+  o[1] = hi16w(q.oc.x);
+  o[2] = lo16w(q.oc.y);
+  o[3] = hi16w(q.oc.y);
+  o[4] = lo16w(q.oc.z);
+  o[5] = hi16w(q.oc.z);
+  o[6] = lo16w(q.oc.w);
+  o[7] = hi16w(q.oc.w);
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = ldsf(SRC + o[i]);
+  const uint32_t w[8] = {q.wa.x, q.wa.y, q.wa.z, q.wa.w, q.wb.x, q.wb.y, q.wb.z, q.wb.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc = fmaf(a[i], __uint_as_float(w[i]), acc);
+    if (__builtin_expect((m8 >> i) & 1u, 0)) {
+      rc.commit(acc);
+      acc = 0.f;
+    }
   }
-  if (c < n) {
-    load_chunk(qb, sbase, lane16, c0 + c + 1);
-    do_chunk<SRC, 0, true>(qa, mk(c >> 1), acc, rc);
-    qa = qb;
-  }
-  c0 += n;
 }
 
 // ---- row sums in REGISTERS (round 4; den_tied_rr.hip) ---------------------------------------------------------

@@ -47,12 +47,51 @@ __device__ __forceinline__ float vload_f32(const float *ptr) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(ptr, 4u), 0, 0, 0));
 }
 
+// ---- the per-state formulas of a tied frame, stated ONCE for every frame driver (TiedSeq below; the plane-wise kernel
+// den_tied_planes.hip).  pb: byte address of exp(y_t); aGM: of gamma_t (u32 fixed point).
+// forward: alpha_t(g) * asum_{t-1} = p(f(g)) * sum_{h != g} w alpha'_{t-1}(h) + p(s(g)) * w_s * alpha'_{t-1}(g); with
+// B_t(g) the two parts are the occupations in frame t-1 of the forward-class arcs into g and of its self-loop
+template <bool GAMMA>
+__device__ __forceinline__ float tied_fwd_state(uint32_t pb, uint32_t aGM, float inv_prev, uint32_t fsx, float wsx, float Fx, float alx,
+                                                float bx, float gs, float &dpart) {
+  const float pf = ldsf(pb + (fsx & 0xffffu)), ps = ldsf(pb + (fsx >> 16));
+  const float sp = ps * (wsx * alx);
+  const float a = fmaf(pf, Fx, sp) * inv_prev;
+  if constexpr (GAMMA) {
+    const float g = gs * bx, spn = sp * inv_prev;
+    gamma_add_a(aGM + (fsx >> 16), g * spn);
+    gamma_add_a(aGM + (fsx & 0xffffu), g * fmaxf(a - spn, 0.f));
+    dpart = fmaf(a, bx, dpart);
+  }
+  return a;
+}
+// backward: everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
+//   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
+//   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
+//                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
+// with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history (measured against float64 on peaky
+// outputs, profiles/r02_peaky.txt: keeping the un-dashed alpha in the history instead changes nothing; the plane-wise
+// kernel does keep it un-dashed and passes asum_up = 0).
+// The self-loop arc also adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t (PURE: to U_t(g)).
+template <bool PURE>
+__device__ __forceinline__ float tied_bwd_state(uint32_t pb, uint32_t aGM, uint32_t fsx, float wsx, float bo, float alx, float aupx,
+                                                float cpx, float ax, float inv_as, float asum_up) {
+  const float ps_ws = ldsf(pb + (fsx >> 16)) * wsx;
+  if constexpr (!PURE) {
+    const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
+    const float bos = kGammaScale * bo;            // power-of-two scale: exact
+    gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
+#ifndef TC_ABL_NOFADD  /* (ablation: what the forward-class half of the gamma adds costs) */
+    gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
+#endif
+  }
+  return fmaf(ps_ws, bo, ax);
+}
+
 // MITM = false: the fused kernel (per-state tables parked in LDS during the forward phase, phase stamps of the
 // diagnostic builds, normalisers to the workspace after the phase); true: the two roles of den_tied_mitm.hip
 // (gamma region live from frame 0, normalisers to the workspace frame by frame, the B history).
-// PW = true: the plane-wise form of graphs beyond 16384 positions (den_tied_planes.hip: forward_frame_pw /
-// backward_frame_pw below drive the same per-state formulas plane by plane; tight layout, nothing resident).
-template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, int RESF, int RESB, bool MITM, bool PW = false>
+template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, int RESF, int RESB, bool MITM>
 struct TiedSeq {
   const DenParams &p;
   const uint32_t tid, lane;
@@ -88,7 +127,6 @@ struct TiedSeq {
   // walk's scalar loop control then becomes vector code.
   // ---- uniform
   int fnch, store_slot, bnch, bstore_slot;
-  int mstride_f, mstride_b;  // plane-wise form: mask words per sub-stream
   uint32_t fsec, bsec;  // byte address of the wave's first secondary row (forward / backward schedule)
   uint32_t aFS, aWS;
   bool tabs_lds;
@@ -102,7 +140,6 @@ struct TiedSeq {
   float part, y2, part_tot;
   int ffx0, ffx1, bfx0, bfx1;
   uint32_t fmask, bmask;
-  uint32_t fsubn, bsubn;  // plane-wise form: chunks of the wave's sub-stream i in lane i
   Chunk6 fres[RESF > 0 ? RESF : 1];
   Chunk6 bres[RESB > 0 ? RESB : 1];
   f4 v4[JV];         // alpha_t (un-dashed) of the owned states
@@ -116,9 +153,9 @@ struct TiedSeq {
 
   __device__ __forceinline__ TiedSeq(const DenParams &pp, int seq, int meet)
       : p(pp), tid(threadIdx.x), lane(threadIdx.x & 63u), wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)), s(seq),
-        H(pp.H), P(pp.P), S(pp.S), T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), K(PW ? 4 : pp.L.Hs / kThreads),
+        H(pp.H), P(pp.P), S(pp.S), T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), K(pp.L.Hs / kThreads),
         own16(16u * threadIdx.x), lane16(16u * (threadIdx.x & 63u)), aACC(4u * (uint32_t)pp.L.off_acc),
-        vrow(4u * (uint32_t)pp.L.off_acc + 256u * (uint32_t)((PW ? 4 : pp.L.Hs / kThreads) * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) +
+        vrow(4u * (uint32_t)pp.L.off_acc + 256u * (uint32_t)((pp.L.Hs / kThreads) * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) +
              4u * (threadIdx.x & 63u)),
         aGM(4u * (uint32_t)pp.L.off_g), aAL(4u * (uint32_t)pp.L.off_al), aRed(4u * (uint32_t)pp.L.off_red),
         aAsum(4u * (uint32_t)pp.L.off_asum), tab_bytes(4u * (uint32_t)(pp.L.Hs + 4)), row_bytes(4u * (uint32_t)pp.P),
@@ -128,9 +165,8 @@ struct TiedSeq {
         bn(MITM ? pp.bwd_norm + (int64_t)seq * (pp.T + 1) : nullptr), bhist(MITM ? pp.beta_hist + (int64_t)seq * pp.L.Hs : nullptr),
         M(meet) {}
 
-  // which of its JV float4s of states a thread really has (plane-wise form: instantiated per plane count, all of them --
-  // a run-time test here makes the compiler carry the per-state arrays as one wide value through the frame loop)
-  __device__ __forceinline__ bool plane_on(int j) const { return PW ? true : j < planes; }
+  // which of its JV float4s of states a thread really has
+  __device__ __forceinline__ bool plane_on(int j) const { return j < planes; }
 
   // diagnostic builds (-DTC_PHASE_STAMPS): per-phase cycle totals of a phase's frames, by wave, to p.stamps + base
   __device__ __forceinline__ void stamps_reset() {
@@ -158,42 +194,15 @@ struct TiedSeq {
     }
   }
 
-  // ---- the per-state formulas, stated once for the frame drivers below
-  // forward: alpha_t(g) * asum_{t-1} = p(f(g)) * sum_{h != g} w alpha'_{t-1}(h) + p(s(g)) * w_s * alpha'_{t-1}(g); with
-  // B_t(g) the two parts are the occupations in frame t-1 of the forward-class arcs into g and of its self-loop
+  // ---- the per-state formulas (tied_fwd_state / tied_bwd_state above), with this object's scale and regions
   template <bool GAMMA>
   __device__ __forceinline__ float fwd_state(uint32_t fsx, float wsx, float Fx, float alx, float bx, float gs, float &dpart) {
-    const float pf = ldsf(kPB + (fsx & 0xffffu)), ps = ldsf(kPB + (fsx >> 16));
-    const float sp = ps * (wsx * alx);
-    const float a = fmaf(pf, Fx, sp) * inv_prev;
-    if constexpr (GAMMA) {
-      const float g = gs * bx, spn = sp * inv_prev;
-      gamma_add_a(aGM + (fsx >> 16), g * spn);
-      gamma_add_a(aGM + (fsx & 0xffffu), g * fmaxf(a - spn, 0.f));
-      dpart = fmaf(a, bx, dpart);
-    }
-    return a;
+    return tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fsx, wsx, Fx, alx, bx, gs, dpart);
   }
-  // backward: everything the arcs INTO an owned state g contribute to gamma_t, from per-state quantities:
-  //   self-loop arc : occ_s = w_s * beta_{t+1}(g) * p_t(s(g)) * alpha'_t(g) / asum_t   -> gamma_t(s(g))
-  //   forward class : sum_h w alpha'_t(h) p_t(f(g)) / asum_t = alpha_{t+1}(g) - selfpart, so
-  //                   occ_f = beta_{t+1}(g) * (alpha_{t+1}(g) - selfpart)               -> gamma_t(f(g))
-  // with alpha_{t+1} = alpha'_{t+1} - leaky*pi*asum_{t+1} from the history (measured against float64 on peaky
-  // outputs, profiles/r02_peaky.txt: keeping the un-dashed alpha in the history instead changes nothing).
-  // The self-loop arc also adds vf_s = w_s * beta_{t+1}(g) * p_t(s(g)) to beta'_t(g) * asum_t (PURE: to U_t(g)).
   template <bool PURE>
   __device__ __forceinline__ float bwd_state(uint32_t pb, uint32_t fsx, float wsx, float bo, float alx, float aupx, float cpx, float ax,
                                              float inv_as, float asum_up) {
-    const float ps_ws = ldsf(pb + (fsx >> 16)) * wsx;
-    if constexpr (!PURE) {
-      const float selfpart = ps_ws * alx * inv_as;  // self-loop part of alpha_{t+1}(g)
-      const float bos = kGammaScale * bo;            // power-of-two scale: exact
-      gamma_add_a(aGM + (fsx >> 16), bos * selfpart);
-#ifndef TC_ABL_NOFADD  /* (ablation: what the forward-class half of the gamma adds costs) */
-      gamma_add_a(aGM + (fsx & 0xffffu), bos * fmaxf((aupx - cpx * asum_up) - selfpart, 0.f));
-#endif
-    }
-    return fmaf(ps_ws, bo, ax);
+    return tied_bwd_state<PURE>(pb, aGM, fsx, wsx, bo, alx, aupx, cpx, ax, inv_as, asum_up);
   }
 
   // ================================================================================================== forward
@@ -234,11 +243,7 @@ struct TiedSeq {
     }
     inv_prev = __builtin_amdgcn_rcpf(asum);
 
-    if constexpr (PW) {
-      stream_begin_pw(p.fwd, fbase, fmask, fsubn, mstride_f, fsec);
-      fnch = 0;
-      ffx0 = ffx1 = 0;
-    } else {
+    {
     const int2 frange = p.fwd.wave_range[wave];
 #ifdef TC_ABL_NOSTREAM
     fnch = RESF;
@@ -477,11 +482,7 @@ struct TiedSeq {
     bsum = block_sum_a(part, aRed + 12u * kWaves, wave, lane);  // also orders the reuse of the gather buffer
     pb_cur = kPB;
     pb_next = ALPHA_LDS ? 4u * (uint32_t)p.L.off_p2 : kPB;
-    if constexpr (PW) {
-      stream_begin_pw(p.bwd, bbase, bmask, bsubn, mstride_b, bsec);
-      bnch = 0;
-      bfx0 = bfx1 = 0;
-    } else {
+    {
     const int2 brange = p.bwd.wave_range[wave];
 #ifdef TC_ABL_NOSTREAM
     bnch = RESB;
@@ -733,199 +734,6 @@ struct TiedSeq {
     const uint32_t tmp = pb_cur;
     pb_cur = pb_next;
     pb_next = tmp;
-    return false;
-  }
-
-  // ============================================================================================== plane-wise form
-  // Graphs of 16385..28672 positions (chain_internal.h: kJvPlanes).  The gather source takes 4 bytes per position of the
-  // 160 KB, so nothing else may be per-position in LDS and little per-state may wait in registers: a thread's states are
-  // taken one float4 ("plane") at a time -- request the plane's tables, walk its four rows (the wave's sub-stream of
-  // that plane: schedule_owner.cpp), run its per-state pass -- and the row sums of every plane share the wave's four
-  // accumulator rows.  What a frame keeps per owned state is ONE value: alpha_t until the block sum is known
-  // (forward), beta_{t+1} overwritten by beta'_t as each plane is passed (backward).  A wave's secondary rows (hub
-  // states) are its first sub-stream: their private slots are complete before any plane folds them in.
-  __device__ __forceinline__ void stream_begin_pw(const ScheduleDev &sc, rsrc_t &base, uint32_t &vmask, uint32_t &subn, int &mstride, uint32_t &sec) {
-    const int subs = planes + 1;
-    const int2 r0 = sc.wave_range[wave * subs], r1 = sc.wave_range[wave * subs + subs - 1];
-    const int first = __builtin_amdgcn_readfirstlane(r0.x) / kChunk;
-    const int total = (__builtin_amdgcn_readfirstlane(r1.x) + __builtin_amdgcn_readfirstlane(r1.y)) / kChunk - first;
-    base = make_rsrc(reinterpret_cast<const char *>(sc.cells) + (int64_t)first * (3 * 64 * 16), (uint32_t)(total + 2) * (3 * 64 * 16));
-    mstride = sc.mask_stride;
-    vmask = sc.masks[(size_t)(wave * subs) * sc.mask_stride + lane];  // (the array ends with a register's worth of padding)
-    subn = (int)lane < subs ? (uint32_t)(sc.wave_range[wave * subs + (int)lane].y / kChunk) : 0u;
-    sec = aACC + 256u * (uint32_t)(4 * kWaves + sc.extra_first[wave]);
-  }
-  __device__ __forceinline__ int sub_chunks(uint32_t subn, int sub) { return __builtin_amdgcn_readlane((int)subn, sub); }
-
-  // frame t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
-  __device__ __forceinline__ void forward_frame_pw(int t) {
-    static_assert(PW && !MITM && !ALPHA_LDS && RESF == 0 && RESB == 0, "plane-wise form: tight layout, nothing resident");
-    Chunk6 q0;
-    load_chunk(q0, fbase, lane16, 0);
-    __syncthreads();  // alpha'_{t-1}, exp(y_{t-1}) ready
-    f4 yreg[PV];
-    if (t < T) {  // y_t under the arc walks
-      const rsrc_t yrow = make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
-    }
-    age_prio_on(wave);
-    int c0 = 0;
-    walk_sub<kA0>(q0, fbase, lane16, c0, sub_chunks(fsubn, 0), fmask, 0, RowCommit{fsec, fsec, 1 << 30});
-    const rsrc_t hist_prev = make_rsrc(hist + (int64_t)(t - 1) * hist_step, t > 1 ? 4u * Hs : 0u);  // (row 0 went out in forward_begin)
-    const RowCommit frc{aACC + 256u * (uint32_t)(4 * wave), fsec, 4};
-    part = 0.f;
-    float dpart = 0.f;
-#pragma unroll
-    for (int j = 0; j < JV; ++j) {
-      v4[j] = mk4(0.f);
-      if (plane_on(j)) {
-        // the history row of frame t-1 leaves plane by plane, each store ahead of its plane's walk
-        bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f4 ws = bld4(r_ws, own16, j * kPlane);
-        int fx0 = 0, fx1 = 0;
-        if (p.fwd.nfix) {
-          fx0 = p.fwd.fix_begin[(int)tid * planes + j];
-          fx1 = p.fwd.fix_begin[(int)tid * planes + j + 1];
-        }
-        walk_sub<kA0>(q0, fbase, lane16, c0, sub_chunks(fsubn, 1 + j), fmask, (1 + j) * mstride_f, frc);
-        for (int e = fx0; e < fx1; ++e) fold_row_pw(p.fwd.fix[e], vrow, aACC, Hs);
-        const f4 F = own_rows(vrow, 0);
-        const f4 al = lds4(kA0 + own16 + j * kPlane);  // alpha'_{t-1} of the owned states
-        v4[j] = f4{fwd_state<false>(fs.x, ws.x, F.x, al.x, 0.f, 0.f, dpart), fwd_state<false>(fs.y, ws.y, F.y, al.y, 0.f, 0.f, dpart),
-                   fwd_state<false>(fs.z, ws.z, F.z, al.z, 0.f, 0.f, dpart), fwd_state<false>(fs.w, ws.w, F.w, al.w, 0.f, 0.f, dpart)};
-        part += hsum(v4[j]);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    f4 cpi[JV];
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (plane_on(j)) cpi[j] = bld4(r_pi, own16, j * kPlane);  // (first touched behind the reduction, which hides the L2 trip)
-    asum = block_sum_a(part, aRed, wave, lane);  // every wave has finished its walks: the gather buffer may change
-    __builtin_amdgcn_sched_barrier(0);
-    part_tot = 0.f;
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (plane_on(j)) {
-        const f4 a = v4[j] + (leaky * cpi[j]) * asum;
-        lds4_st(kA0 + own16 + j * kPlane, a);
-        part_tot += hsum(a);
-      }
-    if (t < T) {
-#pragma unroll
-      for (int v = 0; v < PV; ++v) {
-        const int i0 = 4 * ((int)tid + kThreads * v);
-        if (i0 < Ps) {
-          y2 += hsum(yreg[v] * yreg[v]);
-          lds4_st(kPB + 4u * i0, exp4(yreg[v]));
-        }
-      }
-    }
-    if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
-    inv_prev = __builtin_amdgcn_rcpf(asum);
-  }
-
-  // frame t = T-1..0   ([K] BetaDashGeneralFrame(t) + Beta(t)); returns true after frame 0
-  __device__ __forceinline__ bool backward_frame_pw(int t) {
-    Chunk6 q0;
-    load_chunk(q0, bbase, lane16, 0);
-    __syncthreads();  // Y, exp(y_t) ready; gamma zero
-    const float asum_t = ldsf(aAsum + 4u * t), asum_up = ldsf(aAsum + 4u * (t + 1));
-    const float inv_as = __builtin_amdgcn_rcpf(asum_t);
-    {
-      const int tn = t > 0 ? t - 1 : 0;  // (at t == 0 y re-reads frame 0)
-      const rsrc_t yrow = make_rsrc(p.y + ((int64_t)tn * S + s) * p.y_stride, row_bytes);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) ynext[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
-    }
-    age_prio_on(wave);
-    int c0 = 0;
-    walk_sub<kA0>(q0, bbase, lane16, c0, sub_chunks(bsubn, 0), bmask, 0, RowCommit{bsec, bsec, 1 << 30});
-    const rsrc_t hist_t = make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs), hist_up = make_rsrc(hist + (int64_t)(t + 1) * hist_step, 4u * Hs);
-    const RowCommit brc{aACC + 256u * (uint32_t)(4 * wave), bsec, 4};
-    part = 0.f;
-    float part_ab = 0.f, part_g = 0.f;
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (plane_on(j)) {
-        // the plane's tables and history values are requested ahead of its walk
-        const u4 fs = bld4u(r_fs, own16, j * kPlane);
-        const f4 ws = bld4(r_ws, own16, j * kPlane);
-        const f4 cp = leaky * bld4(r_pi, own16, j * kPlane);
-        const f4 al = bld4(hist_t, own16, j * kPlane);    // alpha'_t of the owned states
-        const f4 aup = bld4(hist_up, own16, j * kPlane);  // alpha'_{t+1}
-        int fx0 = 0, fx1 = 0;
-        if (p.bwd.nfix) {
-          fx0 = p.bwd.fix_begin[(int)tid * planes + j];
-          fx1 = p.bwd.fix_begin[(int)tid * planes + j + 1];
-        }
-        walk_sub<kA0>(q0, bbase, lane16, c0, sub_chunks(bsubn, 1 + j), bmask, (1 + j) * mstride_b, brc);
-        for (int e = fx0; e < fx1; ++e) fold_row_pw(p.bwd.fix[e], vrow, aACC, Hs);
-        f4 a = own_rows(vrow, 0);
-        a.x = bwd_state<false>(kPB, fs.x, ws.x, bown[j].x, al.x, aup.x, cp.x, a.x, inv_as, asum_up);
-        a.y = bwd_state<false>(kPB, fs.y, ws.y, bown[j].y, al.y, aup.y, cp.y, a.y, inv_as, asum_up);
-        a.z = bwd_state<false>(kPB, fs.z, ws.z, bown[j].z, al.z, aup.z, cp.z, a.z, inv_as, asum_up);
-        a.w = bwd_state<false>(kPB, fs.w, ws.w, bown[j].w, al.w, aup.w, cp.w, a.w, inv_as, asum_up);
-        const f4 b = a * inv_as;  // [K] * inv_arbitrary_scale: beta'_t, which takes beta_{t+1}'s registers
-        part += hsum(cp * b);
-        if (t == 0) part_ab += hsum(al * b);
-        bown[j] = b;
-      }
-    __builtin_amdgcn_s_setprio(0);
-    u4 fsT[JV];  // the forward pdfs again, for the Y update behind the two barriers
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (plane_on(j)) fsT[j] = bld4u(r_fs, own16, j * kPlane);
-    bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
-    {
-      const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
-#pragma unroll
-      for (int v = 0; v < PV; ++v) {
-        const int i0 = 4 * ((int)tid + kThreads * v);
-        if (i0 < Ps) {
-          const u4 gu = lds4u(aGM + 4u * i0);
-          lds4_st(aGM + 4u * i0, mk4(0.f));
-          const f4 g = f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} * kGammaInvScale;
-          if (t == 0) part_g += hsum(g);
-          f4 o = p.deriv_weight * g - p.l2_scale * ycur[v];
-          if (ACCUM) o += row_ld(drow, own16 + v * kPlane, p.d_vec);
-          row_st(drow, own16 + v * kPlane, p.d_vec, o);
-        }
-      }
-      xent_zero_row(t);
-      if (t == 0) {
-        // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
-        const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
-        const float gsum = block_sum_a(part_g, aRed + 8u * kWaves, wave, lane);
-        if (tid == 0) {
-          p.seq_ab[s] = ab;
-          p.seq_gsum[s] = gsum;
-        }
-        return true;
-      }
-    }
-    // exp(y_{t-1}) overwrites exp(y_t) in place -- its readers are behind the reduction's barrier -- and one more barrier
-    // publishes it to the Y update
-#pragma unroll
-    for (int v = 0; v < PV; ++v) {
-      const int i0 = 4 * ((int)tid + kThreads * v);
-      if (i0 < Ps) lds4_st(kPB + 4u * i0, exp4(ynext[v]));
-    }
-    __syncthreads();
-    // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
-#pragma unroll
-    for (int j = 0; j < JV; ++j)
-      if (plane_on(j)) {
-        const f4 b = bown[j] + bsum;
-        bown[j] = b;
-        lds4_st(kA0 + own16 + j * kPlane,
-                f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)), b.z * ldsf(kPB + (fsT[j].z & 0xffffu)),
-                   b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
-      }
-#pragma unroll
-    for (int v = 0; v < PV; ++v) ycur[v] = ynext[v];
     return false;
   }
 };

@@ -1,66 +1,428 @@
 // Fused denominator forward-backward for TIED graphs of 16385..28672 positions on gfx950: the "plane-wise" form of
-// den_tied_kernel.hip (same mapping: one workgroup = one sequence = one CU, owner-computes schedules, the frames of
-// den_tied_frames.h).  This is the size class of the den.fst the reference's recipe really loads (a pruned phone LM with
-// Kaldi's default 2000 extra LM states: example/chime5/train_faster.py:91 -> src/my_lib_example.cpp:129-134 takes any
-// FST), which until round 5 fell onto the streamed kernels (den_slab_kernel.hip: 18 ms per 256 x 150 batch against 1.4 ms
-// for the 8192-state C3 graph).
+// den_tied_kernel.hip (same mapping: one workgroup = one sequence = one CU, owner-computes schedules, the per-state
+// formulas of den_tied_frames.h).  This is the size class of the den.fst the reference's recipe really loads (a pruned
+// phone LM with Kaldi's default 2000 extra LM states: example/chime5/train_faster.py:91 -> src/my_lib_example.cpp:129-134
+// takes any FST), which until round 5 fell onto the streamed kernels (den_slab_kernel.hip: 18 ms per 256 x 150 batch
+// against 1.4 ms for the 8192-state C3 graph).
 //
-// What changes beyond 16384 positions: the gather source alone is 4 bytes per position of the CU's 160 KB (96 KB at 24576
-// positions), so neither the row sums of all states (another 4 bytes per position) nor a second exp(y) buffer nor parked
-// alpha' fit, and a thread owns 20-28 states: held in registers the way the smaller instantiations hold them (alpha_t,
-// beta_{t+1}, alpha'_t, beta'_t, the forward pdfs) they would be ~100 registers.  So the frame is taken a PLANE (one float4
-// of states per thread, 4096 positions) at a time: request the plane's tables and history values, walk the plane's four
-// rows, run its per-state pass; the schedule (schedule_owner.cpp, `planewise`) cuts every wave's stream into sub-streams
-// -- the wave's secondary rows first, then one per plane -- each padded to whole chunks, with row-end mask words of its
-// own, and the row sums of all planes share four accumulator rows per wave.  Cells carry 16-bit POSITIONS (byte offset =
-// one SDWA shift).  See TiedSeq::forward_frame_pw / backward_frame_pw.
+// What changes beyond 16384 positions.  The gather source alone is 4 bytes per position of the CU's 160 KB (96 KB at
+// 24576 positions): neither the row sums of all states (another 4 bytes per position) nor a second exp(y) buffer nor
+// parked alpha' fit, and a thread owns 20-28 states -- held in registers the way the smaller instantiations hold them
+// (alpha_t, beta_{t+1}, alpha'_t, beta'_t, the forward pdfs) they would be ~100 registers, and the walk would have none.
+// So:
+//   * the frame is taken a PLANE (one float4 of states per thread, 4096 positions) at a time.  The schedule
+//     (schedule_owner.cpp, `planewise`) cuts every wave's stream at chunk boundaries into its secondary rows and one
+//     sub-stream per plane; when a plane's sub-stream ends, the wave runs that plane's per-state pass and walks on.  The
+//     row sums of all planes share four accumulator rows per wave.
+//   * NOTHING per-state waits in registers.  What a frame must keep per owned state goes through L2: the forward pass
+//     writes alpha_t (un-dashed) straight into its history row and the frame's tail reads it back to form the gather
+//     source alpha'_t = alpha_t + leaky * pi * asum_t; the backward pass keeps beta'_t in one more row of the history
+//     buffer.  That is 0.1-0.3 MB per frame and CU next to the 1.7-1.9 MB of cells every walk streams.
+//   * the registers go to the stream instead: three chunk buffers, two chunks requested ahead -- the waves of a frame are at
+//     different planes, some in their passes, so the stream path is only busy while enough requests are in flight
+//     (two buffers: 11.2 ms per 256 x 150 batch of the 24000-state R4 graph, profiles/r05).
+//   * cells carry 16-bit POSITIONS (byte offset = one SDWA shift), one row-end byte per chunk.
+// One instantiation serves 5, 6 and 7 planes (the plane index is a wave-uniform run-time value).
 #include "den_tied_frames.h"
 
 namespace tc {
 
 namespace {
 
-// JV = the graph's planes exactly (5, 6 or 7: den_layout.cpp compute_layout_planes)
-template <int JV, bool ACCUM, bool WANT_DERIV>
+template <bool ACCUM>
+struct PlaneSeq {
+  static constexpr uint32_t kPB = 0u;             // exp(y_t)
+  static constexpr uint32_t kA0 = 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
+  static constexpr int kMaxPlanes = kJvPlanes;
+
+  const DenParams &p;
+  const uint32_t tid, lane;
+  const int wave, s;
+  const int H, S, T, Hs, Ps, planes;
+  const uint32_t own16, lane16;
+  const uint32_t aACC, vrow, aGM, aRed, aAsum;
+  const uint32_t row_bytes;
+  const rsrc_t r_pi, r_fs, r_ws;
+  const float leaky;
+  const int64_t hist_step;
+  float *const hist;     // alpha history (un-dashed): frame t at hist + t * hist_step; row T + 1: beta'_t of the running frame
+  // ---- the running direction's stream (wave-uniform first)
+  int total, nfix;
+  uint32_t sec;
+  rsrc_t base;
+  const int32_t *fix_begin;
+  const int2 *fix;
+  // ---- per lane
+  uint32_t vmask, ends;
+  float asum, inv_prev, bsum, part, part_tot, y2;
+  // the next plane's tables and history values, requested a plane ahead
+  u4 fs_n;
+  f4 ws_n, cp_n, al_n, aup_n, bp_n;
+  int fx0_n, fx1_n;
+#ifdef TC_PHASE_STAMPS
+  long long st_prev, st_acc[8];
+#endif
+
+  __device__ __forceinline__ PlaneSeq(const DenParams &pp, int seq)
+      : p(pp), tid(threadIdx.x), lane(threadIdx.x & 63u), wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)), s(seq), H(pp.H), S(pp.S),
+        T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), own16(16u * threadIdx.x), lane16(16u * (threadIdx.x & 63u)),
+        aACC(4u * (uint32_t)pp.L.off_acc),
+        vrow(4u * (uint32_t)pp.L.off_acc + 1024u * (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4u * (threadIdx.x & 63u)),
+        aGM(4u * (uint32_t)pp.L.off_g), aRed(4u * (uint32_t)pp.L.off_red), aAsum(4u * (uint32_t)pp.L.off_asum), row_bytes(4u * (uint32_t)pp.P),
+        r_pi(make_rsrc(pp.pi, 4u * (uint32_t)(pp.L.Hs + 4))), r_fs(make_rsrc(pp.tied_fs, 4u * (uint32_t)(pp.L.Hs + 4))),
+        r_ws(make_rsrc(pp.tied_w, 4u * (uint32_t)(pp.L.Hs + 4))), leaky(pp.leaky), hist_step((int64_t)pp.S * pp.L.Hs),
+        hist(pp.alpha_hist + (int64_t)seq * pp.L.Hs) {}
+
+  __device__ __forceinline__ rsrc_t hist_row(int t) const { return make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs); }
+  __device__ __forceinline__ bool own_pdfs() const { return 4 * (int)tid < Ps; }
+
+  __device__ __forceinline__ void stamps_reset() {
+#ifdef TC_PHASE_STAMPS
+    st_prev = clock64();
+    for (int i = 0; i < 8; ++i) st_acc[i] = 0;
+#endif
+  }
+  __device__ __forceinline__ void stamps_flush(int at) {
+#ifdef TC_PHASE_STAMPS
+    TC_STAMP(0)
+    if (blockIdx.x == 0 && lane == 0)
+      for (int i = 0; i < 8; ++i) p.stamps[at + wave * 8 + i] = st_acc[i];
+#endif
+  }
+
+  __device__ __forceinline__ void xent_zero_row(int t) {
+    if (p.xent_zero && own_pdfs())
+      row_st(make_rsrc(p.xent_zero + ((int64_t)t * S + s) * p.xent_stride, row_bytes), own16, p.x_vec, mk4(0.f));
+  }
+
+  // ---- one direction's stream: descriptor, row-end bytes (four chunks to a word, word i in lane i), the chunk at which each
+  // sub-stream ends (sub-stream i in lane i), the wave's first secondary row
+  __device__ __forceinline__ void stream_begin(const ScheduleDev &sc) {
+    const int subs = planes + 1;
+    const int2 r0 = sc.wave_range[wave * subs], r1 = sc.wave_range[wave * subs + subs - 1];
+    total = __builtin_amdgcn_readfirstlane(r1.y) / kChunk;
+    // (the descriptor covers the look-ahead past the wave's last chunk: the array ends with readable padding)
+    base = make_rsrc(reinterpret_cast<const char *>(sc.cells) + (int64_t)(__builtin_amdgcn_readfirstlane(r0.x) / kChunk) * (3 * 64 * 16),
+                     (uint32_t)(total + kBuffers) * (3 * 64 * 16));
+    vmask = sc.masks[(size_t)wave * sc.mask_stride + lane];  // (the array ends with a register's worth of padding)
+    ends = (int)lane < subs ? (uint32_t)(sc.wave_range[wave * subs + (int)lane].y / kChunk) : 0u;
+    sec = aACC + 256u * (uint32_t)(4 * kWaves + sc.extra_first[wave]);
+    nfix = sc.nfix;
+    fix_begin = sc.fix_begin;
+    fix = sc.fix;
+  }
+  __device__ __forceinline__ uint32_t mask_of(int c) const {
+    return (uint32_t)__builtin_amdgcn_readlane((int)vmask, c >> 2) >> (8 * (c & 3));
+  }
+
+  // The frame's walk: chunks through kBuffers buffers, kBuffers - 1 requested ahead; whenever the sub-stream of a plane ends (at chunk
+  // boundaries, by construction) `pass(plane)` runs.  q0 / q1 arrive requested (chunks 0 and 1: ahead of the frame's barrier).
+#ifndef TC_PW_BUFFERS
+#define TC_PW_BUFFERS 3
+#endif
+  static constexpr int kBuffers = TC_PW_BUFFERS;  // chunk buffers: kBuffers - 1 chunks requested ahead
+  // (the first requests of a frame, ahead of its barrier)
+  __device__ __forceinline__ void request_first(Chunk6 (&q)[kBuffers]) {
+#pragma unroll
+    for (int k = 0; k + 1 < kBuffers; ++k) load_chunk(q[k], base, lane16, k);
+  }
+  template <class Pass>
+  __device__ __forceinline__ void run_stream(Chunk6 (&q)[kBuffers], Pass pass) {
+    int c = 0, sub = 0;
+    int next_end = __builtin_amdgcn_readlane((int)ends, 0);
+    float acc = 0.f;
+    const RowCommit plane_rows{aACC + 1024u * (uint32_t)wave, sec, 4};
+    RowCommit rc{sec, sec, 1 << 30};  // sub-stream 0: the wave's secondary rows, private slots one after the other
+    if (next_end == 0) {              // (none)
+      sub = 1;
+      rc = plane_rows;
+      next_end = __builtin_amdgcn_readlane((int)ends, 1);
+    }
+    while (c < total) {
+#pragma unroll
+      for (int k = 0; k < kBuffers; ++k) {
+        load_chunk(q[(k + kBuffers - 1) % kBuffers], base, lane16, c + kBuffers - 1);
+        chunk_pw<kA0>(q[k], mask_of(c), acc, rc);
+        ++c;
+        if (c == next_end) {  // the sub-stream of a plane (or the secondary rows) ends here
+          if (sub > 0) pass(sub - 1);
+          ++sub;
+          rc = plane_rows;
+          next_end = sub > planes ? -1 : __builtin_amdgcn_readlane((int)ends, sub <= planes ? sub : 0);
+        }
+        if (c >= total) break;
+      }
+    }
+  }
+
+  // the fix-up list of (this thread, plane): secondary rows of its hub states, folded into the plane's row sums
+  __device__ __forceinline__ void request_fix(int j) {
+    fx0_n = fx1_n = 0;
+    if (nfix) {
+      fx0_n = fix_begin[(int)tid * planes + j];
+      fx1_n = fix_begin[(int)tid * planes + j + 1];
+    }
+  }
+
+  // ================================================================================================== forward
+  // ---- t = 0: alpha_0 = pi, alpha'_0 = pi + leaky*pi*sum(pi)   ([K] AlphaFirstFrame + AlphaDash(0))
+  __device__ __forceinline__ void forward_begin() {
+    part = 0.f;
+    for (int j = 0; j < planes; ++j) part += hsum(bld4(r_pi, own16, j * kPlane));
+    asum = block_sum_a(part, aRed, wave, lane);
+    const rsrc_t h0 = hist_row(0);
+    for (int j = 0; j < planes; ++j) {
+      const f4 pi4 = bld4(r_pi, own16, j * kPlane);
+      bst4_aux<0>(h0, own16 + j * kPlane, pi4);  // the history keeps alpha UN-dashed
+      lds4_st(kA0 + own16 + j * kPlane, pi4 + (leaky * pi4) * asum);
+    }
+    y2 = 0.f;
+    if (own_pdfs()) {
+      const f4 yv = row_ld(make_rsrc(p.y + (int64_t)s * p.y_stride, row_bytes), own16, p.y_vec);
+      y2 = hsum(yv * yv);
+      lds4_st(kPB + own16, exp4(yv));
+    }
+    if (tid == 0) ldsf_st(aAsum, asum);
+    inv_prev = __builtin_amdgcn_rcpf(asum);
+    part_tot = 0.f;
+    stream_begin(p.fwd);
+    stamps_reset();
+  }
+
+  // frame t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
+  __device__ __forceinline__ void forward_frame(int t) {
+    Chunk6 q[kBuffers];
+    request_first(q);
+    fs_n = bld4u(r_fs, own16, 0);
+    ws_n = bld4(r_ws, own16, 0);
+    request_fix(0);
+    __syncthreads();  // alpha'_{t-1}, exp(y_{t-1}) ready
+    TC_STAMP(0)
+    f4 yreg = mk4(0.f);
+    if (t < T) yreg = row_ld(make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes), own16, p.y_vec);  // y_t under the walks
+    const rsrc_t hist_t = hist_row(t);
+    part = 0.f;
+    run_stream(q, [&](int j) __attribute__((always_inline)) {
+      TC_STAMP(2)
+      const uint32_t pj = (uint32_t)j * kPlane;
+      const u4 fs = fs_n;
+      const f4 ws = ws_n;
+      const int fx0 = fx0_n, fx1 = fx1_n;
+      for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
+      const f4 F = own_rows(vrow, 0);
+      const f4 al = lds4(kA0 + own16 + pj);  // alpha'_{t-1} of the owned states
+      float unused = 0.f;
+      const f4 a = f4{tied_fwd_state<false>(kPB, aGM, inv_prev, fs.x, ws.x, F.x, al.x, 0.f, 0.f, unused),
+                      tied_fwd_state<false>(kPB, aGM, inv_prev, fs.y, ws.y, F.y, al.y, 0.f, 0.f, unused),
+                      tied_fwd_state<false>(kPB, aGM, inv_prev, fs.z, ws.z, F.z, al.z, 0.f, 0.f, unused),
+                      tied_fwd_state<false>(kPB, aGM, inv_prev, fs.w, ws.w, F.w, al.w, 0.f, 0.f, unused)};
+      part += hsum(a);
+      bst4_aux<0>(hist_t, own16 + pj, a);  // alpha_t: its history row, and where the frame's tail finds it again
+      {  // the next plane's tables (index clamped: every request of the frame is unconditional)
+        const int jn = j + 1 < planes ? j + 1 : j;
+        fs_n = bld4u(r_fs, own16, (uint32_t)jn * kPlane);
+        ws_n = bld4(r_ws, own16, (uint32_t)jn * kPlane);
+        request_fix(jn);
+      }
+      TC_STAMP(3)
+    });
+    // alpha'_t = alpha_t + leaky * pi * asum_t: the values come back from L2 while the block sum forms
+    // (requests of planes the graph does not have lie beyond their descriptors and return zeros: every element of the
+    // arrays is assigned unconditionally -- assigned under a condition, the compiler carries such an array through the
+    // frame as one 28-register value and spills it)
+    f4 av[kMaxPlanes], cp[kMaxPlanes];
+#pragma unroll
+    for (int j = 0; j < kMaxPlanes; ++j) {
+      av[j] = bld4(hist_t, own16, j * kPlane);
+      cp[j] = bld4(r_pi, own16, j * kPlane);
+    }
+    asum = block_sum_a(part, aRed, wave, lane);  // every wave has finished its walks: the gather buffer may change
+    part_tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxPlanes; ++j)
+      if (j < planes) {
+        const f4 a = av[j] + (leaky * cp[j]) * asum;
+        lds4_st(kA0 + own16 + j * kPlane, a);
+        part_tot += hsum(a);
+      }
+    if (t < T && own_pdfs()) {
+      y2 += hsum(yreg * yreg);
+      lds4_st(kPB + own16, exp4(yreg));
+    }
+    if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
+    inv_prev = __builtin_amdgcn_rcpf(asum);
+    TC_STAMP(4)
+  }
+
+  // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h)
+  __device__ __forceinline__ float forward_total() {
+    const float tot = block_sum_a(part_tot, aRed + 4u * kWaves, wave, lane);
+    const double y2d = (double)block_sum_a(y2, aRed + 8u * kWaves, wave, lane);
+    if (tid == 0) {
+      // [K] log-prob = log(tot) + sum over t < T of log(alpha-sum_t): the scales divided out of frames 1..T
+      double logsum = 0.0;
+      for (int t = 0; t < T; ++t) logsum += (double)__logf(ldsf(aAsum + 4u * t));
+      p.seq_logprob[s] = logsum + (double)__logf(tot) + (y2d - y2d);  // (+ 0, or NaN for a NaN / inf input)
+      p.seq_y2[s] = y2d;
+    }
+    return tot;
+  }
+
+  // ================================================================================================== backward
+  // ---- [K] BetaDashLastFrame, Beta(T): beta'_T(h) = 1 / tot on the real states, beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h)
+  __device__ __forceinline__ void backward_begin(float b_T) {
+    part = 0.f;
+    for (int j = 0; j < planes; ++j) part += hsum(leaky * bld4(r_pi, own16, j * kPlane)) * b_T;
+    bsum = block_sum_a(part, aRed + 12u * kWaves, wave, lane);  // also orders the reuse of the gather buffer
+    stream_begin(p.bwd);
+    const rsrc_t brow = hist_row(T + 1);
+    if (own_pdfs()) {
+      lds4_st(kPB + own16, exp4(row_ld(make_rsrc(p.y + ((int64_t)(T - 1) * S + s) * p.y_stride, row_bytes), own16, p.y_vec)));
+      lds4_st(aGM + own16, mk4(0.f));
+    }
+    __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = beta_T(g) * p_{T-1}(f(g))
+    for (int j = 0; j < planes; ++j) {
+      const int h0 = 4 * ((int)tid + kThreads * j);
+      const f4 bd = f4{h0 < H ? b_T : 0.f, h0 + 1 < H ? b_T : 0.f, h0 + 2 < H ? b_T : 0.f, h0 + 3 < H ? b_T : 0.f};
+      bst4_aux<0>(brow, own16 + j * kPlane, bd);  // beta'_T
+      const u4 fs = bld4u(r_fs, own16, j * kPlane);
+      const f4 b = f4{h0 < H ? b_T + bsum : 0.f, h0 + 1 < H ? b_T + bsum : 0.f, h0 + 2 < H ? b_T + bsum : 0.f, h0 + 3 < H ? b_T + bsum : 0.f};
+      lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
+                                           b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
+    }
+    stamps_reset();
+  }
+
+  // the values of plane j a backward pass needs: tables, alpha_t, alpha_{t+1}, beta'_{t+1}
+  __device__ __forceinline__ void request_bwd(int j, const rsrc_t &hist_t, const rsrc_t &hist_up, const rsrc_t &brow) {
+    const uint32_t pj = (uint32_t)j * kPlane;
+    fs_n = bld4u(r_fs, own16, pj);
+    ws_n = bld4(r_ws, own16, pj);
+    cp_n = bld4(r_pi, own16, pj);
+    al_n = bld4(hist_t, own16, pj);
+    aup_n = bld4(hist_up, own16, pj);
+    bp_n = bld4(brow, own16, pj);
+    request_fix(j);
+  }
+
+  // frame t = T-1..0   ([K] BetaDashGeneralFrame(t) + Beta(t)); returns true after frame 0
+  __device__ __forceinline__ bool backward_frame(int t) {
+    Chunk6 q[kBuffers];
+    request_first(q);
+    const rsrc_t hist_t = hist_row(t), hist_up = hist_row(t + 1), brow = hist_row(T + 1);
+    request_bwd(0, hist_t, hist_up, brow);
+    __syncthreads();  // Y, exp(y_t) ready; gamma zero
+    TC_STAMP(0)
+    const float asum_t = ldsf(aAsum + 4u * t);
+    const float inv_as = __builtin_amdgcn_rcpf(asum_t);
+    part = 0.f;
+    float part_ab = 0.f, part_g = 0.f;
+    const float bsum_up = bsum;
+    run_stream(q, [&](int j) __attribute__((always_inline)) {
+      TC_STAMP(2)
+      const uint32_t pj = (uint32_t)j * kPlane;
+      const u4 fs = fs_n;
+      const f4 ws = ws_n, cp = leaky * cp_n, aup = aup_n;
+      const f4 al = al_n + cp * asum_t;  // alpha'_t of the owned states (the history keeps alpha_t)
+      const f4 bo = bp_n + bsum_up;      // beta_{t+1}
+      const int fx0 = fx0_n, fx1 = fx1_n;
+      for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
+      f4 a = own_rows(vrow, 0);
+      a.x = tied_bwd_state<false>(kPB, aGM, fs.x, ws.x, bo.x, al.x, aup.x, 0.f, a.x, inv_as, 0.f);
+      a.y = tied_bwd_state<false>(kPB, aGM, fs.y, ws.y, bo.y, al.y, aup.y, 0.f, a.y, inv_as, 0.f);
+      a.z = tied_bwd_state<false>(kPB, aGM, fs.z, ws.z, bo.z, al.z, aup.z, 0.f, a.z, inv_as, 0.f);
+      a.w = tied_bwd_state<false>(kPB, aGM, fs.w, ws.w, bo.w, al.w, aup.w, 0.f, a.w, inv_as, 0.f);
+      const f4 b = a * inv_as;  // [K] * inv_arbitrary_scale: beta'_t
+      part += hsum(cp * b);
+      if (t == 0) part_ab += hsum(al * b);
+      bst4_aux<0>(brow, own16 + pj, b);  // (beta'_{t+1} of the plane has just been used: this thread's own entries)
+      // the next plane's values, requested behind this plane's arithmetic (both sets at once do not fit the registers) and
+      // a whole sub-stream ahead of their use; index clamped: every request of the frame is unconditional
+      request_bwd(j + 1 < planes ? j + 1 : j, hist_t, hist_up, brow);
+      TC_STAMP(3)
+    });
+    // beta'_t and the forward pdfs again, for the Y update behind the two barriers
+    // y_{t-1} (at t == 0 frame 0 again) for the next frame's exp(y), y_t once more for the derivative row's l2 term (this CU
+    // read it a frame ago: L2) -- requested here rather than held in registers through the walks
+    const f4 ynext = row_ld(make_rsrc(p.y + ((int64_t)(t > 0 ? t - 1 : 0) * S + s) * p.y_stride, row_bytes), own16, p.y_vec);
+    const f4 ynow = row_ld(make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes), own16, p.y_vec);
+    f4 bv[kMaxPlanes];
+    u4 fsT[kMaxPlanes];
+#pragma unroll
+    for (int j = 0; j < kMaxPlanes; ++j) {  // (unconditional: see the forward tail)
+      bv[j] = bld4(brow, own16, j * kPlane);
+      fsT[j] = bld4u(r_fs, own16, j * kPlane);
+    }
+    bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
+    if (own_pdfs()) {
+      const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
+      const u4 gu = lds4u(aGM + own16);
+      lds4_st(aGM + own16, mk4(0.f));
+      const f4 g = f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} * kGammaInvScale;
+      if (t == 0) part_g = hsum(g);
+      f4 o = p.deriv_weight * g - p.l2_scale * ynow;
+      if (ACCUM) o += row_ld(drow, own16, p.d_vec);
+      row_st(drow, own16, p.d_vec, o);
+    }
+    xent_zero_row(t);
+    if (t == 0) {
+      // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
+      const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
+      const float gsum = block_sum_a(part_g, aRed + 8u * kWaves, wave, lane);
+      if (tid == 0) {
+        p.seq_ab[s] = ab;
+        p.seq_gsum[s] = gsum;
+      }
+      return true;
+    }
+    // exp(y_{t-1}) overwrites exp(y_t) in place -- its readers are behind the reduction's barrier -- and one more barrier
+    // publishes it to the Y update
+    if (own_pdfs()) lds4_st(kPB + own16, exp4(ynext));
+    __syncthreads();
+    // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
+#pragma unroll
+    for (int j = 0; j < kMaxPlanes; ++j)
+      if (j < planes) {
+        const f4 b = bv[j] + bsum;
+        lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
+                                             b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
+      }
+    TC_STAMP(4)
+    return false;
+  }
+};
+
+template <bool ACCUM, bool WANT_DERIV>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenParams p) {
-  TiedSeq<JV, kPvSmall, false, ACCUM, 0, 0, false, true> q(p, (int)blockIdx.x, 0);
+  PlaneSeq<ACCUM> q(p, (int)blockIdx.x);
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
   q.forward_begin();
-  for (int t = 1; t <= T; ++t) q.forward_frame_pw(t);
-  q.forward_store_row(T);
-  const float tot = q.forward_total(0.0);
+  for (int t = 1; t <= T; ++t) q.forward_frame(t);
+  q.stamps_flush(0);
+  const float tot = q.forward_total();
   if (!WANT_DERIV) return;
   // ---- backward: beta'_T = 1 / tot, frames T-1..0 with gamma
-  q.template backward_begin<false>(__builtin_amdgcn_rcpf(tot));
-  for (int t = T - 1; t > 0; --t) q.backward_frame_pw(t);
-  q.backward_frame_pw(0);
-}
-
-template <int JV>
-int launch_planes(const DenParams &p, int accumulate, size_t lds, hipStream_t stream) {
-  void (*k)(const DenParams) = nullptr;
-  if (!p.deriv)
-    k = den_tied_planes_kernel<JV, false, false>;
-  else
-    k = accumulate ? den_tied_planes_kernel<JV, true, true> : den_tied_planes_kernel<JV, false, true>;
-  TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds));
-  hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds, stream, p);
-  TC_HIP_CHECK(hipGetLastError());
-  return TC_OK;
+  q.backward_begin(__builtin_amdgcn_rcpf(tot));
+  for (int t = T - 1; t > 0; --t) q.backward_frame(t);
+  q.backward_frame(0);
+  q.stamps_flush(128);
 }
 
 }  // namespace
 
 int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t stream) {
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
-  if (!p.L.planewise || lds > (size_t)kLdsLimitBytes || p.L.PV != kPvSmall) return TC_ERR_UNSUPPORTED;
-  switch (p.L.JV) {
-    case 5: return launch_planes<5>(p, accumulate, lds, stream);
-    case 6: return launch_planes<6>(p, accumulate, lds, stream);
-    case 7: return launch_planes<7>(p, accumulate, lds, stream);
-  }
-  return TC_ERR_UNSUPPORTED;
+  if (!p.L.planewise || lds > (size_t)kLdsLimitBytes || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanes) return TC_ERR_UNSUPPORTED;
+  void (*k)(const DenParams) = nullptr;
+  if (!p.deriv)
+    k = den_tied_planes_kernel<false, false>;
+  else
+    k = accumulate ? den_tied_planes_kernel<true, true> : den_tied_planes_kernel<false, true>;
+  TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds));
+  hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds, stream, p);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
 }
 
 }  // namespace tc

@@ -101,14 +101,31 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
              (!planewise && out->cells.size() / 64 - first < (size_t)kTiedMinChunks * kStreamUnrollTied))
         for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
       row_end.resize((out->cells.size() / 64 - first + 1) / 2, 0);  // the padding cells end no row
-      out->wave_range[(size_t)w * subs + sub] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
       if (debug_flag(kDbgSchedTrace))
-        fprintf(stderr, "[sched] wave %d sub %d: %d cells, %zu rows\n", w, sub, out->wave_range[(size_t)w * subs + sub].y, k1 - k0);
-      auto &mw = wave_masks[(size_t)w * subs + sub];
-      mw.assign((row_end.size() + 7) / 8, 0u);
-      for (size_t i = 0; i < row_end.size(); ++i) {
-        if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
-        if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
+        fprintf(stderr, "[sched] wave %d sub %d: %zu cells, %zu rows\n", w, sub, out->cells.size() / 64 - first, k1 - k0);
+      if (planewise) {
+        // one stream per wave, cut at chunk boundaries: {first cell of the sub-stream, its END counted from the wave's first
+        // cell}, and ONE byte of row-end bits per chunk (bit i: a row ends with cell i), four chunks to a word
+        const size_t wave_first = (size_t)out->wave_range[(size_t)w * subs].x;
+        const size_t rel = sub == 0 ? 0 : first - wave_first;
+        if (sub == 0) out->wave_range[(size_t)w * subs].x = (int)first;
+        out->wave_range[(size_t)w * subs + sub] = make_int2((int)first, (int)(rel + out->cells.size() / 64 - first));
+        auto &mw = wave_masks[(size_t)w * subs];  // (the wave's words: index 0 of its sub-streams)
+        mw.resize((rel + out->cells.size() / 64 - first) / 8 / 4 + 1, 0u);
+        for (size_t i = 0; i < row_end.size(); ++i)
+          for (int half = 0; half < 2; ++half)
+            if (row_end[i] & (half ? 1 : 2)) {  // flag A: the pair's first cell, flag B: its second
+              const size_t cell = rel + 2 * i + half, chunk = cell / 8;
+              mw[chunk / 4] |= 1u << (8 * (chunk % 4) + cell % 8);
+            }
+      } else {
+        out->wave_range[(size_t)w * subs + sub] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
+        auto &mw = wave_masks[(size_t)w * subs + sub];
+        mw.assign((row_end.size() + 7) / 8, 0u);
+        for (size_t i = 0; i < row_end.size(); ++i) {
+          if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
+          if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
+        }
       }
       wave_row_end.push_back(row_end);
     }
@@ -118,8 +135,16 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   for (auto &mw : wave_masks) stride = std::max(stride, mw.size());
   if (!planewise) stride += 2;  // (the walk once prefetched a word ahead)
   out->mask_stride = (int32_t)stride;
-  out->masks.assign(stride * wave_masks.size() + 64, 0u);  // (+ a register's worth: the kernels read 64 words per wave)
-  for (size_t i = 0; i < wave_masks.size(); ++i) std::copy(wave_masks[i].begin(), wave_masks[i].end(), out->masks.begin() + i * stride);
+  if (planewise) {  // [wave][stride]: the wave's words (kept at index 0 of its sub-streams above)
+    out->masks.assign(stride * kWaves + 64, 0u);  // (+ a register's worth: the kernel reads 64 words per wave)
+    for (int w = 0; w < kWaves; ++w) {
+      const auto &mw = wave_masks[(size_t)w * subs];
+      std::copy(mw.begin(), mw.end(), out->masks.begin() + (size_t)w * stride);
+    }
+  } else {
+    out->masks.assign(stride * wave_masks.size() + 64, 0u);
+    for (size_t i = 0; i < wave_masks.size(); ++i) std::copy(wave_masks[i].begin(), wave_masks[i].end(), out->masks.begin() + i * stride);
+  }
   // row-register images (den_tied_rr.hip): cell i of a wave's stream belongs to row (number of row ends before it); rows
   // beyond 15 -- secondary rows of hub states, which that kernel does not take -- are capped
   out->images.clear();
@@ -242,7 +267,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     }
   }
   st.resize(Npos, -1);  // phantom states: no arcs, pi = 0
-  struct Group { int idx, cin, cout; };
+  struct Group { int idx, cin, cout, pin, pout; };  // (pin / pout: steps of the group's own rows, without its secondary rows)
   std::vector<Group> groups(ngroups);
   for (int gi = 0; gi < ngroups; ++gi) {
     int mi = 1, mo = 1;
@@ -252,7 +277,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
       mi = std::max(mi, lin(h));
       mo = std::max(mo, lout(h));
     }
-    groups[gi] = Group{gi, mi, mo};
+    groups[gi] = Group{gi, mi, mo, mi, mo};
     // its states' arcs beyond max_row become secondary rows of the same wave, 64 to a slot
     int64_t over_in = 0, over_out = 0;
     for (int l = 0; l < 64; ++l) {
@@ -265,6 +290,17 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     groups[gi].cout += (int)((over_out + 63) / 64);
   }
   // longest-processing-time deal of the groups to the waves, K per wave, balancing both directions
+  // Plane-wise form: its frames run without issue priorities (den_tied_planes.hip), the CU then serves its OLDER waves
+  // first wherever waves contend, and the walks of the four wave generations proceed at about 1.25 : 1.15 : 0.95 : 0.8 of
+  // the mean (profiles/r05/pw_stamps3.txt); with equal shares the old waves wait for the young ones at every frame's
+  // barrier while the stream path runs half empty, so the shares follow the speeds.
+  double wave_speed[kWaves];
+  {
+    static const double by_gen[4] = {1.25, 1.15, 0.95, 0.8};
+    const char *env = getenv("TC_PW_SKEW");  // (experiments: a factor on the deviation from 1)
+    const double k = env ? atof(env) : 1.0;
+    for (int w = 0; w < kWaves; ++w) wave_speed[w] = planewise ? 1.0 + k * (by_gen[w / 4] - 1.0) : 1.0;
+  }
   std::vector<Group> by_cost(groups);
   std::stable_sort(by_cost.begin(), by_cost.end(), [](const Group &x, const Group &y) { return x.cin + x.cout > y.cin + y.cout; });
   std::vector<std::vector<int>> wave_groups(kWaves);
@@ -273,10 +309,10 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     // (shares skewed towards the older waves of each SIMD, which the CU serves first, were measured: no
     // gain -- the walk is bound by the shared stream path, not by any one wave)
     int best = -1;
-    int64_t best_t = 0;
+    double best_t = 0;
     for (int w = 0; w < kWaves; ++w) {
       if ((int)wave_groups[w].size() >= K) continue;
-      const int64_t tw = std::max(load_in[w] + gr.cin, load_out[w] + gr.cout);
+      const double tw = (double)std::max(load_in[w] + gr.cin, load_out[w] + gr.cout) / wave_speed[w];
       if (best < 0 || tw < best_t) {
         best = w;
         best_t = tw;
@@ -328,7 +364,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
   }
   // ... and the longest streams go to the youngest waves, which the kernels run at the highest issue priority
   // (den_tied_device.h: age_prio_on): every frame waits for its slowest wave
-  {
+  if (!planewise) {
     std::vector<int> order(kWaves);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return load_in[x] + load_out[x] < load_in[y] + load_out[y]; });
@@ -342,6 +378,43 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     wave_groups.swap(wg);
     load_in.swap(li);
     load_out.swap(lo);
+  }
+  // Plane-wise form: a plane's sub-stream is padded to whole chunks in both directions (3.5 steps on average, six or seven
+  // planes per wave and direction: 7 % of R4's forward cells).  Which of a wave's groups share a plane is free: groups
+  // trade planes inside their wave while that lowers the wave's padding.
+  if (planewise) {
+    auto pad8 = [](int x) { return (8 - x % 8) % 8; };
+    for (int w = 0; w < kWaves; ++w) {
+      std::vector<int> &wg = wave_groups[w];
+      const int planes = K / 4;
+      auto plane_cost = [&](int pl) {
+        int si = 0, so = 0;
+        for (int c = 0; c < 4; ++c) {
+          si += groups[wg[4 * pl + c]].pin;
+          so += groups[wg[4 * pl + c]].pout;
+        }
+        return pad8(si) + pad8(so);
+      };
+      bool improved = true;
+      for (int round = 0; round < 20 && improved; ++round) {
+        improved = false;
+        for (int a = 0; a < K; ++a)
+          for (int b = a + 1; b < K; ++b) {
+            if (a / 4 == b / 4) continue;
+            const int before = plane_cost(a / 4) + plane_cost(b / 4);
+            std::swap(wg[a], wg[b]);
+            if (plane_cost(a / 4) + plane_cost(b / 4) < before)
+              improved = true;
+            else
+              std::swap(wg[a], wg[b]);
+          }
+      }
+      if (debug_flag(kDbgSchedTrace)) {
+        int total = 0;
+        for (int pl = 0; pl < planes; ++pl) total += plane_cost(pl);
+        fprintf(stderr, "[sched] wave %d: %d steps of plane padding\n", w, total);
+      }
+    }
   }
   g->pos.assign(H, 0);
   std::vector<int32_t> state_at(Npos, -1);
@@ -542,7 +615,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     out->nfix = (int32_t)out->fix.size();
     if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
     emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise);
-    if (planewise && (int64_t)out->subs * out->mask_stride > 64) return false;  // (a wave's mask words live in one register)
+    if (planewise && out->mask_stride > 64) return false;  // (a wave's mask words live in one register: at most 256 chunks)
   }
   if (planewise ? !compute_layout_planes(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), &g->layout)
                 : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), true, &g->layout))
