@@ -1,10 +1,22 @@
 #!/bin/bash
 # Development aid (runs on the GPU box): one line per workload and kernel family -> profiles/rNN_configs.txt
-for c in C2 C3 C5 R1 R2 R3 X1 X2; do echo "== $c"; python scripts/time_den.py $c 2>&1 | grep -v amdgpu.ids; done
+for c in C2 C3 C5 R1 R2 R3 X1 R4 X2; do echo "== $c"; python scripts/time_den.py $c 2>&1 | grep -v amdgpu.ids; done
 echo "== small batches: forward and backward recursion on two CUs (default) vs the fused kernel (no_phase_split)"
 for c in "C2 1" "C2 16" C2 "C2 128" C5 "R1 64" "R2 64" "R3 64" "X1 64" "X1 128"; do
   echo -n "$c two-CU: "; python scripts/time_den.py $c 2>&1 | tail -1
   echo -n "$c fused:  "; TC_DEBUG=no_phase_split python scripts/time_den.py $c 2>&1 | tail -1
+done
+echo "== R4 (24000 states): plane-wise on-chip kernel (default) vs the streamed path (no_planes), batch 256 / 128 / 64"
+for S in 256 128 64; do
+  a=$(python scripts/time_den.py R4 $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  b=$(TC_DEBUG=no_planes python scripts/time_den.py R4 $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  echo "R4 batch $S: plane-wise $a | streamed $b"
+done
+echo "== plane-wise kernel on random graphs of 5 / 6 / 7 planes (states x arcs per state, 2928 pdfs), batch 256"
+for hd in "18000 12" "24000 12" "28000 10"; do set -- $hd
+  a=$(TC_CFG=H=$1,degree=$2,P=2928 python scripts/time_den.py X2 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  b=$(TC_DEBUG=no_planes TC_CFG=H=$1,degree=$2,P=2928 python scripts/time_den.py X2 2>&1 | tail -1 | grep -o "[0-9.]* ms")
+  echo "H=$1 degree=$2: plane-wise $a | streamed $b"
 done
 echo "== C3 forced general"; TC_DEBUG=force_general python scripts/time_den.py C3 2>&1 | tail -1
 echo "== C3 forced streamed"; TC_DEBUG=force_streamed python scripts/time_den.py C3 2>&1 | tail -1

@@ -43,9 +43,13 @@ def _compare(oracle, cfg, S, T, seed, expect_tied):
 
 
 # ---- the plane-wise on-chip kernel (den_tied_planes.hip): tied graphs of 16385..28672 positions --------------------------
-def test_plane_wise_kernel_small_batches(oracle):
-    """5, 6 and 7 planes, few sequences and frames, against the full objective's oracle (numerator included)."""
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_plane_wise_kernel_small_batches(oracle, kernel_family, form):
+    """5, 6 and 7 planes, few sequences and frames, against the full objective's oracle (numerator included) -- in the form
+    batches of at most half the CUs take by default (two workgroups per sequence meeting in the middle) and in the fused kernel."""
     from helpers import hip_chain
+    if form == "fused":
+        kernel_family("no_phase_split")
     for H, deg, P, S, T in ((17000, 3, 900, 2, 7), (24000, 4, 2000, 3, 5), (28000, 5, 2928, 2, 6)):
         fst = synth.random_den_fst(H, deg, P, seed=H)
         g = oracle.DenGraph(fst)
@@ -61,14 +65,20 @@ def test_plane_wise_kernel_small_batches(oracle):
         assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL, H
 
 
-@pytest.mark.parametrize("S,T", [(64, 150), (256, 30)])
-def test_plane_wise_kernel_at_size(oracle, S, T):
-    """R4 on its default path: on chip (tied == 1), log-prob, derivative matrix-wise and element-wise, row sums."""
+@pytest.mark.parametrize("S,T,form", [(64, 150, "two_cu"), (64, 150, "fused"), (256, 30, "fused"), (128, 31, "two_cu")])
+def test_plane_wise_kernel_at_size(oracle, kernel_family, S, T, form):
+    """R4 on its default path: on chip (tied == 1), log-prob, derivative matrix-wise and element-wise, row sums.  Batches of
+    up to 128 sequences take the two-workgroup form (an odd T: the roles' halves differ), 256 the fused kernel."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     _compare(oracle, "R4", S, T, seed=511, expect_tied=1)
 
 
-def test_plane_wise_kernel_accumulate_and_no_deriv(oracle):
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_plane_wise_kernel_accumulate_and_no_deriv(oracle, kernel_family, form):
     """[K] Backward(deriv_weight, &deriv) adds into deriv; the forward-only call gives the same log-prob."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     fst = synth.random_den_fst(20000, 3, 700, seed=31)
     S, T = 3, 9
     y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=41)
@@ -81,8 +91,11 @@ def test_plane_wise_kernel_accumulate_and_no_deriv(oracle):
     assert abs(out2["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
 
 
-def test_plane_wise_kernel_is_bitwise_reproducible_and_slices():
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_plane_wise_kernel_is_bitwise_reproducible_and_slices(kernel_family, form):
     """Sequences never interact: a 5-sequence call's rows equal the rows of the same sequences in an 8-sequence call."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     fst = synth.config_den_fst("R4")
     P = synth.CONFIGS["R4"]["P"]
     S, T = 8, 12
@@ -94,6 +107,18 @@ def test_plane_wise_kernel_is_bitwise_reproducible_and_slices():
     sub = np.ascontiguousarray(y.reshape(T, S, P)[:, :5].reshape(T * 5, P))
     c = hip_den(fst, sub, 5, leaky=0.1, graph=g)
     assert np.array_equal(c["deriv"].reshape(T, 5, P), a["deriv"].reshape(T, S, P)[:, :5])
+
+
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+@pytest.mark.parametrize("scale,leaky", [(10.0, 1e-5), (10.0, 0.1), (20.0, 0.1)])
+def test_plane_wise_kernel_peaky_outputs(oracle, kernel_family, scale, leaky, form):
+    """y ~ N(0, scale^2), 150 frames, against the float64 log-semiring formulation with tests/test_gpu_peaky.py's bounds
+    (absolute 1e-5 on posteriors, element-wise by magnitude class, and no further from the Kaldi-style float32 oracle than
+    that oracle is from the truth) -- the plane-wise kernel keeps alpha UN-dashed in its history and beta' in L2."""
+    from test_gpu_peaky import _check
+    if form == "fused":
+        kernel_family("no_phase_split")
+    _check(oracle, synth.random_den_fst(17000, 3, 600, seed=77), 1, 150, scale, leaky)
 
 
 @pytest.mark.parametrize("width", ["slab_narrow", "slab_wide"])

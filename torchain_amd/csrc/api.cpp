@@ -47,7 +47,7 @@ int big_g(const tc_den_graph *g) { return g->big ? g->big_G : 16; }
 int big_hb(const tc_den_graph *g) { return g->big ? g->big_hb : 0; }
 // Batches the tied on-chip kernel may run as two CUs per sequence get room for the second history.  (Whether
 // they do is decided at launch: device size, layout for this T, diagnostic switch.)
-bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq && !(g->layout_ok && g->layout.planewise); }
+bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq; }
 // Tied on-chip graphs of at most 8192 positions may run two sequences per workgroup (den_tied_pair.hip): two more
 // history rows, the two roles' normalisers and the pairing words.
 // ... and the plane-wise kernel of 16385..28672 positions keeps one more history row (den_tied_planes.hip)

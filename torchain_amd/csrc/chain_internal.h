@@ -372,6 +372,9 @@ int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip
 int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_planes.hip
+// ... two workgroups per sequence meeting in the middle (batches of at most half the CUs)
+bool planes_mitm_fits(const DenParams &p);
+int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t stream);
 // den_tied_rr.hip: the fused kernel with the row sums in registers and one more chunk of the stream in LDS (graphs without
 // hub states, 8 states and 4 pdfs per thread)
 bool rr_fits(const DenParams &p);

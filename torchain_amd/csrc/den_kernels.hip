@@ -478,8 +478,14 @@ static bool pair_wanted(const DenParams &p, int num_cus) {
   return p.pair_choice > 0 && 2 * p.S > num_cus;
 }
 
+// plane-wise kernel: two workgroups per sequence (meeting in the middle) while they fit the chip
+static bool planes_two_cus(const DenParams &p, int num_cus) {
+  return p.L.planewise && planes_mitm_fits(p) && 2 * p.S <= num_cus && !debug_flag(kDbgNoPhaseSplit) && !debug_flag(kDbgNoMitm);
+}
+
 int den_cus_used(const DenParams &p, int num_cus) {
   if (p.big.in.rows) return num_cus;
+  if (p.L.planewise) return planes_two_cus(p, num_cus) ? 2 * p.S : (p.S < num_cus ? p.S : num_cus);
   if (pair_wanted(p, num_cus)) return std::min(num_cus, 2 * ((p.S + 1) / 2));
   if (split_wanted(p) && 2 * p.S <= num_cus) return 2 * p.S;
   return p.S < num_cus ? p.S : num_cus;
@@ -490,6 +496,7 @@ int den_cus_used(const DenParams &p, int num_cus) {
 bool den_zeroes_xent(const DenParams &p, int num_cus) {
   if (p.big.in.rows || !p.tied_fs || !p.deriv) return false;
   if ((size_t)layout_lds_bytes(p.L, p.T) > (size_t)kLdsLimitBytes) return false;
+  if (p.L.planewise) return true;  // (both forms of den_tied_planes.hip write the rows)
   if (pair_wanted(p, num_cus)) return false;
   if (split_wanted(p) && 2 * p.S <= num_cus) return mitm_wanted(p);
   DenParams pq = p;
@@ -507,7 +514,10 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
     SideStreams *c = nullptr;
     const int src = side_streams(stream, &c);
     if (src != TC_OK) return src;
-    if (p.L.planewise) return launch_den_tied_planes(p, accumulate, stream);  // den_tied_planes.hip
+    if (p.L.planewise) {  // den_tied_planes.hip
+      if (planes_two_cus(p, c->num_cus)) return launch_den_tied_planes_mitm(p, accumulate, stream);
+      return launch_den_tied_planes(p, accumulate, stream);
+    }
     if (pair_wanted(p, c->num_cus)) return launch_den_tied_pair(p, p.pair_extra_slots, accumulate, stream);
     if (split_wanted(p)) {
       if (2 * p.S <= c->num_cus) {

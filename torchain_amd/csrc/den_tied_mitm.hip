@@ -19,54 +19,12 @@
 // The frames are den_tied_frames.h's, the ones the fused kernel runs (same LDS layout, same resident chunks): role F =
 // forward_frame<GAMMA>, role B = backward_frame<PURE>; this file holds the pairing, the hand-over and the two drivers.  [K] = kaldi chain-denominator.cc, reached by the reference through
 // src/my_lib_chain.cpp:129-131.
+#include "den_handover.h"
 #include "den_tied_frames.h"
 
 namespace tc {
 
 namespace {
-
-struct MitmParams {
-  uint32_t *sync;    // [0] ticket counter, [4 + 2 s + role] hand-over flags
-  int M;             // meeting frame
-  uint32_t aScr;     // 16 bytes of LDS scratch behind the fused layout: ticket, hand-over result
-};
-
-typedef __attribute__((address_space(1))) uint32_t gu32;
-typedef __attribute__((address_space(3))) uint32_t lds_u;
-
-constexpr uint32_t kSpinSleep = 16;        // s_sleep units (64 cycles each) between two polls
-constexpr uint32_t kSpinLimit = 8u << 20;  // seconds
-
-// "everything this workgroup stored so far may be read by the partner" (MI355X_MICROARCH.md, valid forms: plain stores
-// -> vmcnt(0) -> barrier -> release -> vmcnt(0) -> relaxed agent flag store)
-__device__ __forceinline__ void publish(uint32_t *flag, uint32_t tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store((gu32 *)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// (relaxed poll -> acquire -> vmcnt(0) -> barrier); false if the partner never arrived
-__device__ __forceinline__ bool await(uint32_t *flag, uint32_t tid, uint32_t scratch) {
-  if (tid == 0) {
-    uint32_t spins = 0, ok = 1;
-    while (__hip_atomic_load((gu32 *)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-      __builtin_amdgcn_s_sleep(kSpinSleep);
-      if (++spins > kSpinLimit) {
-        ok = 0;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *reinterpret_cast<lds_u *>(scratch) = ok;
-  }
-  __syncthreads();
-  return *reinterpret_cast<lds_u *>(scratch) != 0u;
-}
 
 // =========================================================================================================
 // ROLE F: the forward frame (den_tied_frames.h); frames M+1..T also form gamma_{t-1}.
@@ -151,11 +109,7 @@ __device__ __forceinline__ void mitm_backward(const DenParams &p, const MitmPara
 
 template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, int RESF, int RESB>
 __global__ __launch_bounds__(kThreads) void den_tied_mitm_kernel(const DenParams p, const MitmParams q) {
-  // ticket -> (sequence, role): whoever starts next becomes the partner of the last unpaired workgroup
-  if (threadIdx.x == 0)
-    *reinterpret_cast<lds_u *>(q.aScr) = __hip_atomic_fetch_add((gu32 *)q.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const uint32_t ticket = __builtin_amdgcn_readfirstlane(*reinterpret_cast<lds_u *>(q.aScr));
+  const uint32_t ticket = take_ticket(q);
   const int s = (int)(ticket >> 1);
   if (s >= p.S) return;
   if ((ticket & 1u) == 0u)

@@ -23,6 +23,12 @@
 //     (two buffers: 11.2 ms per 256 x 150 batch of the 24000-state R4 graph, profiles/r05).
 //   * cells carry 16-bit POSITIONS (byte offset = one SDWA shift), one row-end byte per chunk.
 // One instantiation serves 5, 6 and 7 planes (the plane index is a wave-uniform run-time value).
+//
+// Batches of at most half the CUs run TWO workgroups per sequence that meet in the middle (den_tied_mitm.hip's scheme
+// with these frames): role F = the forward frame, from the meeting frame on forming gamma_{t-1} from the stored B_t;
+// role B = the backward frame with normalisers of its own and no gamma down to the meeting frame, then as in the fused
+// kernel.  forward_frame<GAMMA> / backward_frame<PURE> below.
+#include "den_handover.h"
 #include "den_tied_frames.h"
 
 namespace tc {
@@ -46,6 +52,10 @@ struct PlaneSeq {
   const float leaky;
   const int64_t hist_step;
   float *const hist;     // alpha history (un-dashed): frame t at hist + t * hist_step; row T + 1: beta'_t of the running frame
+  // two-workgroup form only (null in the fused kernel)
+  float *const fn;       // [T + 2] asum_0..T (role F writes, role B reads)
+  float *const bn;       // [T + 1] role B's normalisers
+  float *const bhist;    // B history
   // ---- the running direction's stream (wave-uniform first)
   int total, nfix;
   uint32_t sec;
@@ -55,6 +65,8 @@ struct PlaneSeq {
   // ---- per lane
   uint32_t vmask, ends;
   float asum, inv_prev, bsum, part, part_tot, y2;
+  float chat;  // c^_t: the scale the fixed-point adds of the running GAMMA frame use
+  f4 bt_n;     // GAMMA frames: B_t of the next plane's owned states
   // the next plane's tables and history values, requested a plane ahead
   u4 fs_n;
   f4 ws_n, cp_n, al_n, aup_n, bp_n;
@@ -71,9 +83,12 @@ struct PlaneSeq {
         aGM(4u * (uint32_t)pp.L.off_g), aRed(4u * (uint32_t)pp.L.off_red), aAsum(4u * (uint32_t)pp.L.off_asum), row_bytes(4u * (uint32_t)pp.P),
         r_pi(make_rsrc(pp.pi, 4u * (uint32_t)(pp.L.Hs + 4))), r_fs(make_rsrc(pp.tied_fs, 4u * (uint32_t)(pp.L.Hs + 4))),
         r_ws(make_rsrc(pp.tied_w, 4u * (uint32_t)(pp.L.Hs + 4))), leaky(pp.leaky), hist_step((int64_t)pp.S * pp.L.Hs),
-        hist(pp.alpha_hist + (int64_t)seq * pp.L.Hs) {}
+        hist(pp.alpha_hist + (int64_t)seq * pp.L.Hs), fn(pp.fwd_norm ? pp.fwd_norm + (int64_t)seq * (pp.T + 2) : nullptr),
+        bn(pp.bwd_norm ? pp.bwd_norm + (int64_t)seq * (pp.T + 1) : nullptr),
+        bhist(pp.beta_hist ? pp.beta_hist + (int64_t)seq * pp.L.Hs : nullptr) {}
 
   __device__ __forceinline__ rsrc_t hist_row(int t) const { return make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs); }
+  __device__ __forceinline__ rsrc_t bhist_row(int t) const { return make_rsrc(bhist + (int64_t)t * hist_step, 4u * Hs); }
   __device__ __forceinline__ bool own_pdfs() const { return 4 * (int)tid < Ps; }
 
   __device__ __forceinline__ void stamps_reset() {
@@ -182,20 +197,33 @@ struct PlaneSeq {
       y2 = hsum(yv * yv);
       lds4_st(kPB + own16, exp4(yv));
     }
-    if (tid == 0) ldsf_st(aAsum, asum);
+    if (tid == 0) {
+      ldsf_st(aAsum, asum);
+      if (fn) fn[0] = asum;
+    }
     inv_prev = __builtin_amdgcn_rcpf(asum);
     part_tot = 0.f;
+    chat = 0.f;
+    bt_n = mk4(0.f);
     stream_begin(p.fwd);
     stamps_reset();
   }
 
-  // frame t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t))
+  // frame t = 1..T   ([K] AlphaGeneralFrame(t) + AlphaDash(t)).  GAMMA (role F behind the meeting frame): the two parts of
+  // alpha_t(g) times the stored B_t(g) are the occupations in frame t-1 of the forward-class arcs into g and of its self-loop
+  template <bool GAMMA>
   __device__ __forceinline__ void forward_frame(int t) {
     Chunk6 q[kBuffers];
     request_first(q);
     fs_n = bld4u(r_fs, own16, 0);
     ws_n = bld4(r_ws, own16, 0);
     request_fix(0);
+    const rsrc_t brow = GAMMA ? bhist_row(t) : make_rsrc(hist, 0u);
+    if (GAMMA) bt_n = bld4(brow, own16, 0);
+    float n_t = 1.f;
+    if (GAMMA && t < T) n_t = vload_f32(bn + t);  // for c^_{t+1}
+    const float gs = kGammaScale * chat;
+    float dpart = 0.f;
     __syncthreads();  // alpha'_{t-1}, exp(y_{t-1}) ready
     TC_STAMP(0)
     f4 yreg = mk4(0.f);
@@ -211,17 +239,18 @@ struct PlaneSeq {
       for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
       const f4 F = own_rows(vrow, 0);
       const f4 al = lds4(kA0 + own16 + pj);  // alpha'_{t-1} of the owned states
-      float unused = 0.f;
-      const f4 a = f4{tied_fwd_state<false>(kPB, aGM, inv_prev, fs.x, ws.x, F.x, al.x, 0.f, 0.f, unused),
-                      tied_fwd_state<false>(kPB, aGM, inv_prev, fs.y, ws.y, F.y, al.y, 0.f, 0.f, unused),
-                      tied_fwd_state<false>(kPB, aGM, inv_prev, fs.z, ws.z, F.z, al.z, 0.f, 0.f, unused),
-                      tied_fwd_state<false>(kPB, aGM, inv_prev, fs.w, ws.w, F.w, al.w, 0.f, 0.f, unused)};
+      const f4 bt = bt_n;
+      const f4 a = f4{tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.x, ws.x, F.x, al.x, bt.x, gs, dpart),
+                      tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.y, ws.y, F.y, al.y, bt.y, gs, dpart),
+                      tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.z, ws.z, F.z, al.z, bt.z, gs, dpart),
+                      tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.w, ws.w, F.w, al.w, bt.w, gs, dpart)};
       part += hsum(a);
       bst4_aux<0>(hist_t, own16 + pj, a);  // alpha_t: its history row, and where the frame's tail finds it again
       {  // the next plane's tables (index clamped: every request of the frame is unconditional)
         const int jn = j + 1 < planes ? j + 1 : j;
         fs_n = bld4u(r_fs, own16, (uint32_t)jn * kPlane);
         ws_n = bld4(r_ws, own16, (uint32_t)jn * kPlane);
+        if (GAMMA) bt_n = bld4(brow, own16, (uint32_t)jn * kPlane);
         request_fix(jn);
       }
       TC_STAMP(3)
@@ -236,7 +265,14 @@ struct PlaneSeq {
       av[j] = bld4(hist_t, own16, j * kPlane);
       cp[j] = bld4(r_pi, own16, j * kPlane);
     }
-    asum = block_sum_a(part, aRed, wave, lane);  // every wave has finished its walks: the gather buffer may change
+    f4 yp = mk4(0.f);
+    if (GAMMA) {  // y_{t-1} for the derivative row's l2 term (this CU read the row a frame ago: L2)
+      yp = row_ld(make_rsrc(p.y + ((int64_t)(t - 1) * S + s) * p.y_stride, row_bytes), own16, p.y_vec);
+      block_sum2(part, dpart, aRed, wave, lane);  // its barrier also completes gamma_{t-1}
+      asum = part;
+    } else {
+      asum = block_sum_a(part, aRed, wave, lane);  // every wave has finished its walks: the gather buffer may change
+    }
     part_tot = 0.f;
 #pragma unroll
     for (int j = 0; j < kMaxPlanes; ++j)
@@ -245,24 +281,42 @@ struct PlaneSeq {
         lds4_st(kA0 + own16 + j * kPlane, a);
         part_tot += hsum(a);
       }
+    if (GAMMA) {
+      // the derivative row of frame t-1: gamma_{t-1} * (c_t / c^_t)
+      const float c = __builtin_amdgcn_rcpf(dpart);
+      const float sa = p.deriv_weight * (kGammaInvScale * (c * __builtin_amdgcn_rcpf(chat)));
+      if (own_pdfs()) {
+        const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)(t - 1) * S + s) * p.deriv_stride, row_bytes);
+        const u4 gu = lds4u(aGM + own16);
+        lds4_st(aGM + own16, mk4(0.f));
+        f4 o = sa * f4{(float)gu.x, (float)gu.y, (float)gu.z, (float)gu.w} - p.l2_scale * yp;
+        if (ACCUM) o += row_ld(drow, own16, p.d_vec);
+        row_st(drow, own16, p.d_vec, o);
+      }
+      xent_zero_row(t - 1);
+      chat = c * asum * __builtin_amdgcn_rcpf(n_t);  // c^_{t+1} = c_t asum_t / n_t
+    }
     if (t < T && own_pdfs()) {
       y2 += hsum(yreg * yreg);
       lds4_st(kPB + own16, exp4(yreg));
     }
-    if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
+    if (tid == 0) {
+      ldsf_st(aAsum + 4u * t, asum);
+      if (fn) fn[t] = asum;
+    }
     inv_prev = __builtin_amdgcn_rcpf(asum);
     TC_STAMP(4)
   }
 
   // ---- total probability ([K] ComputeTotLogLike): tot = sum_h alpha'_T(h)
-  __device__ __forceinline__ float forward_total() {
+  __device__ __forceinline__ float forward_total(double bad = 0.0) {
     const float tot = block_sum_a(part_tot, aRed + 4u * kWaves, wave, lane);
     const double y2d = (double)block_sum_a(y2, aRed + 8u * kWaves, wave, lane);
     if (tid == 0) {
       // [K] log-prob = log(tot) + sum over t < T of log(alpha-sum_t): the scales divided out of frames 1..T
       double logsum = 0.0;
       for (int t = 0; t < T; ++t) logsum += (double)__logf(ldsf(aAsum + 4u * t));
-      p.seq_logprob[s] = logsum + (double)__logf(tot) + (y2d - y2d);  // (+ 0, or NaN for a NaN / inf input)
+      p.seq_logprob[s] = logsum + (double)__logf(tot) + (y2d - y2d) + bad;  // (+ 0, or NaN for a NaN / inf input)
       p.seq_y2[s] = y2d;
     }
     return tot;
@@ -270,6 +324,8 @@ struct PlaneSeq {
 
   // ================================================================================================== backward
   // ---- [K] BetaDashLastFrame, Beta(T): beta'_T(h) = 1 / tot on the real states, beta_T = beta'_T + leaky * sum_h pi(h) beta'_T(h)
+  // (PURE: b_T = 1, a recursion with normalisers of its own; B_T goes to the B history for the partner's gamma_{T-1})
+  template <bool PURE>
   __device__ __forceinline__ void backward_begin(float b_T) {
     part = 0.f;
     for (int j = 0; j < planes; ++j) part += hsum(leaky * bld4(r_pi, own16, j * kPlane)) * b_T;
@@ -284,9 +340,12 @@ struct PlaneSeq {
     for (int j = 0; j < planes; ++j) {
       const int h0 = 4 * ((int)tid + kThreads * j);
       const f4 bd = f4{h0 < H ? b_T : 0.f, h0 + 1 < H ? b_T : 0.f, h0 + 2 < H ? b_T : 0.f, h0 + 3 < H ? b_T : 0.f};
-      bst4_aux<0>(brow, own16 + j * kPlane, bd);  // beta'_T
       const u4 fs = bld4u(r_fs, own16, j * kPlane);
       const f4 b = f4{h0 < H ? b_T + bsum : 0.f, h0 + 1 < H ? b_T + bsum : 0.f, h0 + 2 < H ? b_T + bsum : 0.f, h0 + 3 < H ? b_T + bsum : 0.f};
+      if (PURE)
+        bst4_aux<0>(bhist_row(T), own16 + j * kPlane, b);  // B_T
+      else
+        bst4_aux<0>(brow, own16 + j * kPlane, bd);  // beta'_T
       lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
                                            b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
     }
@@ -294,51 +353,59 @@ struct PlaneSeq {
   }
 
   // the values of plane j a backward pass needs: tables, alpha_t, alpha_{t+1}, beta'_{t+1}
+  // (PURE: no alpha; `brow` is then the B history's row t + 1)
+  template <bool PURE>
   __device__ __forceinline__ void request_bwd(int j, const rsrc_t &hist_t, const rsrc_t &hist_up, const rsrc_t &brow) {
     const uint32_t pj = (uint32_t)j * kPlane;
     fs_n = bld4u(r_fs, own16, pj);
     ws_n = bld4(r_ws, own16, pj);
     cp_n = bld4(r_pi, own16, pj);
-    al_n = bld4(hist_t, own16, pj);
-    aup_n = bld4(hist_up, own16, pj);
+    if (!PURE) {
+      al_n = bld4(hist_t, own16, pj);
+      aup_n = bld4(hist_up, own16, pj);
+    }
     bp_n = bld4(brow, own16, pj);
     request_fix(j);
   }
 
-  // frame t = T-1..0   ([K] BetaDashGeneralFrame(t) + Beta(t)); returns true after frame 0
+  // frame t = T-1..0   ([K] BetaDashGeneralFrame(t) + Beta(t)); returns true after frame 0.
+  // PURE (role B above the meeting frame, B'_T = 1): no gamma, normaliser n_t = sum_h U_t(h) / H, B_t to the B history
+  template <bool PURE>
   __device__ __forceinline__ bool backward_frame(int t) {
     Chunk6 q[kBuffers];
     request_first(q);
     const rsrc_t hist_t = hist_row(t), hist_up = hist_row(t + 1), brow = hist_row(T + 1);
-    request_bwd(0, hist_t, hist_up, brow);
+    const rsrc_t bsrc = PURE ? bhist_row(t + 1) : brow;  // beta_{t+1}: B_{t+1} itself, or beta'_{t+1} (+ its leaky sum)
+    request_bwd<PURE>(0, hist_t, hist_up, bsrc);
     __syncthreads();  // Y, exp(y_t) ready; gamma zero
     TC_STAMP(0)
-    const float asum_t = ldsf(aAsum + 4u * t);
+    const float asum_t = PURE ? 1.f : ldsf(aAsum + 4u * t);
     const float inv_as = __builtin_amdgcn_rcpf(asum_t);
     part = 0.f;
-    float part_ab = 0.f, part_g = 0.f;
-    const float bsum_up = bsum;
+    float part_ab = 0.f, part_g = 0.f, part_u = 0.f;
+    const float bsum_up = PURE ? 0.f : bsum;
     run_stream(q, [&](int j) __attribute__((always_inline)) {
       TC_STAMP(2)
       const uint32_t pj = (uint32_t)j * kPlane;
       const u4 fs = fs_n;
-      const f4 ws = ws_n, cp = leaky * cp_n, aup = aup_n;
-      const f4 al = al_n + cp * asum_t;  // alpha'_t of the owned states (the history keeps alpha_t)
-      const f4 bo = bp_n + bsum_up;      // beta_{t+1}
+      const f4 ws = ws_n, cp = leaky * cp_n, aup = PURE ? mk4(0.f) : aup_n;
+      const f4 al = PURE ? mk4(0.f) : al_n + cp * asum_t;  // alpha'_t of the owned states (the history keeps alpha_t)
+      const f4 bo = bp_n + bsum_up;                        // beta_{t+1}
       const int fx0 = fx0_n, fx1 = fx1_n;
       for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
       f4 a = own_rows(vrow, 0);
-      a.x = tied_bwd_state<false>(kPB, aGM, fs.x, ws.x, bo.x, al.x, aup.x, 0.f, a.x, inv_as, 0.f);
-      a.y = tied_bwd_state<false>(kPB, aGM, fs.y, ws.y, bo.y, al.y, aup.y, 0.f, a.y, inv_as, 0.f);
-      a.z = tied_bwd_state<false>(kPB, aGM, fs.z, ws.z, bo.z, al.z, aup.z, 0.f, a.z, inv_as, 0.f);
-      a.w = tied_bwd_state<false>(kPB, aGM, fs.w, ws.w, bo.w, al.w, aup.w, 0.f, a.w, inv_as, 0.f);
-      const f4 b = a * inv_as;  // [K] * inv_arbitrary_scale: beta'_t
+      a.x = tied_bwd_state<PURE>(kPB, aGM, fs.x, ws.x, bo.x, al.x, aup.x, 0.f, a.x, inv_as, 0.f);
+      a.y = tied_bwd_state<PURE>(kPB, aGM, fs.y, ws.y, bo.y, al.y, aup.y, 0.f, a.y, inv_as, 0.f);
+      a.z = tied_bwd_state<PURE>(kPB, aGM, fs.z, ws.z, bo.z, al.z, aup.z, 0.f, a.z, inv_as, 0.f);
+      a.w = tied_bwd_state<PURE>(kPB, aGM, fs.w, ws.w, bo.w, al.w, aup.w, 0.f, a.w, inv_as, 0.f);
+      const f4 b = PURE ? a : a * inv_as;  // [K] * inv_arbitrary_scale: beta'_t (PURE: U_t)
       part += hsum(cp * b);
-      if (t == 0) part_ab += hsum(al * b);
-      bst4_aux<0>(brow, own16 + pj, b);  // (beta'_{t+1} of the plane has just been used: this thread's own entries)
+      if (PURE) part_u += hsum(a);
+      if (!PURE && t == 0) part_ab += hsum(al * b);
+      bst4_aux<0>(brow, own16 + pj, b);  // (row T + 1: this thread's own entries; beta'_{t+1} of the plane has just been used)
       // the next plane's values, requested behind this plane's arithmetic (both sets at once do not fit the registers) and
       // a whole sub-stream ahead of their use; index clamped: every request of the frame is unconditional
-      request_bwd(j + 1 < planes ? j + 1 : j, hist_t, hist_up, brow);
+      request_bwd<PURE>(j + 1 < planes ? j + 1 : j, hist_t, hist_up, bsrc);
       TC_STAMP(3)
     });
     // beta'_t and the forward pdfs again, for the Y update behind the two barriers
@@ -353,8 +420,18 @@ struct PlaneSeq {
       bv[j] = bld4(brow, own16, j * kPlane);
       fsT[j] = bld4u(r_fs, own16, j * kPlane);
     }
-    bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
-    if (own_pdfs()) {
+    float inv_n = 1.f;
+    if (PURE) {
+      // n_t = sum_h U_t(h) / H; B'_t = U_t / n_t; leaky sum of B'_t
+      block_sum2(part, part_u, aRed, wave, lane);
+      const float n = part_u * (1.0f / (float)H);
+      inv_n = __builtin_amdgcn_rcpf(n);
+      bsum = part * inv_n;
+      if (tid == 0) bn[t] = __builtin_amdgcn_rcpf(inv_n);  // (the normaliser actually applied)
+    } else {
+      bsum = block_sum_a(part, aRed, wave, lane);  // its barrier also completes gamma_t
+    }
+    if (!PURE && own_pdfs()) {
       const rsrc_t drow = make_rsrc(p.deriv + ((int64_t)t * S + s) * p.deriv_stride, row_bytes);
       const u4 gu = lds4u(aGM + own16);
       lds4_st(aGM + own16, mk4(0.f));
@@ -364,8 +441,8 @@ struct PlaneSeq {
       if (ACCUM) o += row_ld(drow, own16, p.d_vec);
       row_st(drow, own16, p.d_vec, o);
     }
-    xent_zero_row(t);
-    if (t == 0) {
+    if (!PURE) xent_zero_row(t);
+    if (!PURE && t == 0) {
       // [K] BetaGeneralFrameDebug(0): alpha'.beta' and sum(gamma) must both be ~1 per sequence
       const float ab = block_sum_a(part_ab, aRed + 4u * kWaves, wave, lane);
       const float gsum = block_sum_a(part_g, aRed + 8u * kWaves, wave, lane);
@@ -383,7 +460,8 @@ struct PlaneSeq {
 #pragma unroll
     for (int j = 0; j < kMaxPlanes; ++j)
       if (j < planes) {
-        const f4 b = bv[j] + bsum;
+        const f4 b = PURE ? bv[j] * inv_n + bsum : bv[j] + bsum;
+        if (PURE) bst4_aux<0>(bhist_row(t), own16 + j * kPlane, b);  // B_t for the partner (and this role's next frame)
         lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
                                              b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
       }
@@ -398,18 +476,102 @@ __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenPara
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
   q.forward_begin();
-  for (int t = 1; t <= T; ++t) q.forward_frame(t);
+  for (int t = 1; t <= T; ++t) q.template forward_frame<false>(t);
   q.stamps_flush(0);
   const float tot = q.forward_total();
   if (!WANT_DERIV) return;
   // ---- backward: beta'_T = 1 / tot, frames T-1..0 with gamma
-  q.backward_begin(__builtin_amdgcn_rcpf(tot));
-  for (int t = T - 1; t > 0; --t) q.backward_frame(t);
-  q.backward_frame(0);
+  q.template backward_begin<false>(__builtin_amdgcn_rcpf(tot));
+  for (int t = T - 1; t > 0; --t) q.template backward_frame<false>(t);
+  q.template backward_frame<false>(0);
   q.stamps_flush(128);
 }
 
+// =========================================================================================================
+// Two workgroups per sequence that meet in the middle (batches of at most half the CUs): den_tied_mitm.hip's scheme
+// =========================================================================================================
+// ROLE F: alpha forward over frames 1..M exactly as the fused kernel, the hand-over, then frames M+1..T with gamma_{t-1}
+template <bool ACCUM>
+__device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const MitmParams &mq, int s) {
+  PlaneSeq<ACCUM> q(p, s);
+  const int T = q.T, M = mq.M;
+  q.forward_begin();
+  for (int t = 1; t <= M; ++t) q.template forward_frame<false>(t);
+  publish(mq.sync + 4 + 2 * s, q.tid);
+  const bool partner_ok = await(mq.sync + 4 + 2 * s + 1, q.tid, mq.aScr + 4u);
+  if (q.own_pdfs()) lds4_st(q.aGM + q.own16, mk4(0.f));  // gamma starts at zero (the block sum below publishes it)
+  {
+    // c_M = 1 / sum_g alpha_M(g) B_M(g);  c^_{M+1} = c_M asum_M / n_M
+    const rsrc_t aM = q.hist_row(M), bM = q.bhist_row(M);
+    float d = 0.f;
+    for (int j = 0; j < q.planes; ++j) d += hsum(bld4(aM, q.own16, j * kPlane) * bld4(bM, q.own16, j * kPlane));
+    d = block_sum_a(d, q.aRed + 4u * kWaves, q.wave, q.lane);
+    q.chat = __builtin_amdgcn_rcpf(d) * q.asum * __builtin_amdgcn_rcpf(vload_f32(q.bn + M));
+  }
+  for (int t = M + 1; t <= T; ++t) q.template forward_frame<true>(t);
+  q.forward_total(partner_ok ? 0.0 : (double)__builtin_nanf(""));
+}
+
+// ROLE B: frames T-1..M with normalisers of its own and no gamma, the hand-over, then the fused kernel's backward frame
+template <bool ACCUM>
+__device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const MitmParams &mq, int s) {
+  PlaneSeq<ACCUM> q(p, s);
+  const int T = q.T, M = mq.M;
+  q.template backward_begin<true>(1.0f);  // B'_T = 1
+  for (int t = T - 1; t >= M; --t) q.template backward_frame<true>(t);
+  publish(mq.sync + 4 + 2 * s + 1, q.tid);
+  const bool partner_ok = await(mq.sync + 4 + 2 * s, q.tid, mq.aScr + 4u);
+  {
+    // asum_0..M from role F; c_M = 1 / sum_g alpha_M(g) B_M(g); from here on beta = c_M B: Kaldi's scale
+    for (int i = (int)q.tid; i <= M; i += kThreads) ldsf_st(q.aAsum + 4u * (uint32_t)i, vload_f32(q.fn + i));
+    const rsrc_t aM = q.hist_row(M), bM = q.bhist_row(M), brow = q.hist_row(T + 1);
+    float d = 0.f;
+    for (int j = 0; j < q.planes; ++j) d += hsum(bld4(aM, q.own16, j * kPlane) * bld4(bM, q.own16, j * kPlane));
+    d = block_sum_a(d, q.aRed + 4u * kWaves, q.wave, q.lane);  // (its barrier also publishes the frame sums)
+    const float c = __builtin_amdgcn_rcpf(d);
+    for (int j = 0; j < q.planes; ++j) {
+      bst4_aux<0>(brow, q.own16 + j * kPlane, bld4(bM, q.own16, j * kPlane) * c);  // beta_M where frame M-1 looks for beta'_M ...
+      lds4_st(q.kA0 + q.own16 + j * kPlane, lds4(q.kA0 + q.own16 + j * kPlane) * c);  // Y_{M-1}
+    }
+    q.bsum = 0.f;  // ... with its leaky sum already in
+  }
+  for (int t = M - 1; t >= 0; --t)
+    if (q.template backward_frame<false>(t)) break;
+  if (!partner_ok && q.tid == 0) p.seq_ab[s] = __builtin_nanf("");
+}
+
+template <bool ACCUM>
+__global__ __launch_bounds__(kThreads) void den_tied_planes_mitm_kernel(const DenParams p, const MitmParams q) {
+  const uint32_t ticket = take_ticket(q);
+  const int s = (int)(ticket >> 1);
+  if (s >= p.S) return;
+  if ((ticket & 1u) == 0u)
+    planes_mitm_forward<ACCUM>(p, q, s);
+  else
+    planes_mitm_backward<ACCUM>(p, q, s);
+}
+
 }  // namespace
+
+bool planes_mitm_fits(const DenParams &p) {
+  return p.L.planewise && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
+         (size_t)layout_lds_bytes(p.L, p.T) + 16u <= (size_t)kLdsLimitBytes;
+}
+
+int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t stream) {
+  if (!planes_mitm_fits(p) || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanes) return TC_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)layout_lds_bytes(p.L, p.T) + 16u;
+  MitmParams q;
+  q.sync = p.mitm_sync;
+  q.M = p.T / 2;
+  q.aScr = (uint32_t)layout_lds_bytes(p.L, p.T);
+  TC_HIP_CHECK(hipMemsetAsync(p.mitm_sync, 0, mitm_sync_bytes(p.S), stream));
+  void (*k)(const DenParams, const MitmParams) = accumulate ? den_tied_planes_mitm_kernel<true> : den_tied_planes_mitm_kernel<false>;
+  TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds));
+  hipLaunchKernelGGL(k, dim3(2 * p.S), dim3(kThreads), lds, stream, p, q);
+  TC_HIP_CHECK(hipGetLastError());
+  return TC_OK;
+}
 
 int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t stream) {
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
