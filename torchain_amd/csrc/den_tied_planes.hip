@@ -361,8 +361,13 @@ struct PlaneSeq {
     ws_n = bld4(r_ws, own16, pj);
     cp_n = bld4(r_pi, own16, pj);
     if (!PURE) {
+#ifdef TC_PW_NT_HIST
+      al_n = bld4_aux<2>(hist_t, own16 + pj);
+      aup_n = bld4_aux<2>(hist_up, own16 + pj);
+#else
       al_n = bld4(hist_t, own16, pj);
       aup_n = bld4(hist_up, own16, pj);
+#endif
     }
     bp_n = bld4(brow, own16, pj);
     request_fix(j);
