@@ -149,7 +149,30 @@ def extras(graph, fst, cfg, S, T, P, dev):
     steps = {"train_step_bct_ms": train_step(False, True), "train_step_bct_xent_kaldi_way_ms": train_step(True, True),
              "train_step_bct_xent_reference_way_ms": train_step(True, False)}
 
-    out = {"full_objective_ms": full, "objf_per_frame": float(res.data[0] / res.data[2]), **steps,
+    # A graph of the size a chain recipe's own den.fst has (synth R4: 24000 states, 312000 arcs, in-degrees to 200;
+    # example/chime5/train_faster.py:91 hands the recipe's den.fst to src/my_lib_example.cpp:129-134): the plane-wise on-chip
+    # kernel (csrc/den_tied_planes.hip) at the headline batch and, as two workgroups per sequence, at the recipe's batch.
+    def big_graph_ms():
+        import ctypes as C
+        from torchain_amd._lib import check, lib
+        c4 = synth.CONFIGS["R4"]
+        f4 = synth.config_den_fst("R4")
+        g4 = io.DenominatorGraph(f4, c4["P"]).prepare(dev)
+        y4 = torch.randn(S * T, c4["P"], device=dev)
+        d4 = torch.empty_like(y4)
+        st = torch.cuda.current_stream().cuda_stream
+        res4 = {"r4_kernel_family": g4.stats()["tied"]}
+        for S4 in (S, 64):
+            nb = lib.tc_chain_workspace_bytes(g4.ptr, S4, T)
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            res4["r4_den_batch%d_ms" % S4] = timeit(lambda: check(lib.tc_den_forward_backward(
+                g4.ptr, S4, C.c_void_p(y4.data_ptr()), S4 * T, c4["P"], y4.stride(0), c4["leaky"], -1.0, 0.0, 0,
+                C.c_void_p(d4.data_ptr()), d4.stride(0), None, None, C.c_void_p(ws.data_ptr()), nb, dev.index or 0,
+                C.c_void_p(st)), "den"), n=5, warm=5)
+            del ws
+        return res4
+
+    out = {"full_objective_ms": full, "objf_per_frame": float(res.data[0] / res.data[2]), **steps, **big_graph_ms(),
            "batch64_den_ms": den_ms(64, False), "batch64_den_fused_kernel_ms": den_ms(64, True),
            "to2d_hip_ms": timeit(lambda: to2d_hip(x)), "to2d_torch_ms": timeit(lambda: to2d(x)),
            "from2d_neg_hip_ms": timeit(lambda: from2d_hip(y, (S, P, T), -1.0)),

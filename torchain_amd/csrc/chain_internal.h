@@ -246,6 +246,8 @@ struct tc_den_graph {
   bool tied = false;
   std::vector<uint32_t> tied_fs;      // position order once build_owner has run
   std::vector<float> tied_w;
+  std::vector<uint32_t> tied_fs_state;  // ... and in work-state order, as detect_tied left them (build_owner starts from these)
+  std::vector<float> tied_w_state;
   // The graph the tied schedules are built from: the FST itself, or -- when a few states are entered
   // through arcs of more than one pdf -- its "tied-ified" version in which such a state is split into one
   // copy per entering pdf (schedule_owner.cpp: make_work_graph).  copy_first[h] .. copy_first[h+1] are the work
@@ -352,7 +354,8 @@ int build_schedules(tc_den_graph *g);                                           
 void build_general(tc_den_graph *g);                                                   // schedule_general.cpp
 bool detect_tied(tc_den_graph *g, std::vector<char> *special);                         // schedule_owner.cpp
 bool make_work_graph(tc_den_graph *g);                                                 // schedule_owner.cpp
-bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row);      // schedule_owner.cpp
+// (count_only: fills fwd / bwd.padded_arcs and the layout alone -- what a candidate row cut would cost)
+bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row, bool count_only = false);  // schedule_owner.cpp
 int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
                  const int32_t *pdf, std::vector<std::vector<int>> *pos_out);          // den_layout.cpp
 // ... one gather per cell (tied schedules): step by step, a matching of lanes to banks that keeps the half-slot on its

@@ -293,11 +293,32 @@ int build_schedules(tc_den_graph *g) {
     // with many popular states (real phone-LM graphs: in-degrees of a hundred and more) and close to the 16384-state
     // limit may have no room for them, so the home rows are allowed to grow before the graph is given up to the
     // streamed kernels (8x slower per arc).
-    for (int max_row = kMaxRowLen; max_row <= 8 * kMaxRowLen; max_row *= 2)
-      if (build_owner(g, special, max_row)) {
-        g->layout_ok = true;
-        return TC_OK;
+    // Which cut?  The first that fits (counting passes: no placement work) -- and for the plane-wise form, whose row sums
+    // share four rows per wave so that a long home row costs no LDS while every secondary row costs its wave a 64-lane slot
+    // that is mostly padding when the wave has few of them (R4: 7 % of the forward cells with rows cut at 32), the cut that
+    // leaves the fewest cells.
+    int fit_row = 0;
+    {
+      int64_t best_cells = -1;
+      for (int max_row = kMaxRowLen; max_row <= 8 * kMaxRowLen; max_row *= 2) {
+        if (!build_owner(g, special, max_row, true)) continue;
+        const int64_t cells = g->fwd.padded_arcs + g->bwd.padded_arcs;
+        if (best_cells < 0 || cells < best_cells) {
+          best_cells = cells;
+          fit_row = max_row;
+        }
+        if (!g->layout.planewise) break;
       }
+      if (fit_row && !build_owner(g, special, fit_row)) {
+        fit_row = 0;  // (a full build can still fail where the count fitted: more than 256 chunks per wave)
+        for (int max_row = kMaxRowLen; max_row <= 8 * kMaxRowLen && !fit_row; max_row *= 2)
+          if (build_owner(g, special, max_row)) fit_row = max_row;
+      }
+    }
+    if (fit_row) {
+      g->layout_ok = true;
+      return TC_OK;
+    }
     if (split_made) {
       // The graph became tied only through state splitting, and the enlarged work graph does not fit the owner-computes
       // layouts.  Before it is given up to the streamed kernels (~8x slower per arc), the ORIGINAL graph gets its

@@ -34,8 +34,27 @@ struct OwnerTask {
 
 static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std::vector<OwnerTask>>> &slots,
                               const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
-                              ScheduleHost *out, bool planewise) {
-  // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows
+                              ScheduleHost *out, bool planewise, bool count_only) {
+  // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows.  count_only: the number of cells alone (padded_arcs)
+  if (count_only) {
+    int64_t cells = 0;
+    for (int w = 0; w < kWaves; ++w) {
+      int64_t in_sub = 0;
+      auto close_sub = [&]() {
+        cells += (in_sub + kStreamUnrollTied - 1) / kStreamUnrollTied * kStreamUnrollTied * 64;
+        in_sub = 0;
+      };
+      for (size_t k = 0; k < slots[w].size(); ++k) {
+        int steps = 1;
+        for (const OwnerTask &t : slots[w][k]) steps = std::max(steps, t.len);
+        in_sub += steps;
+        if (planewise && (k + 1 == slots[w].size() || ((int)k < K && k % 4 == 3))) close_sub();
+      }
+      close_sub();
+    }
+    out->padded_arcs = cells;
+    return;
+  }
   out->conflict_cost = out->conflict_free_cost = out->conflict_bound = 0;
   out->cells.clear();
   // plane-wise form: per wave, sub-stream 0 = its secondary rows, sub-stream 1 + j = the four rows of plane j
@@ -193,8 +212,12 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
 
 // Returns false when the graph cannot use the owner-computes kernel (too many states for the 16-bit
 // offsets or the working set does not fit LDS); the caller then falls back to the general kernel.
-bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row) {
+bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row, bool count_only) {
   const int H = g->work_H;  // states of the work graph (tc_den_graph::work_*)
+  // (the per-state tables in work-state order: a successful build leaves them in position order, and a graph may be built
+  // more than once -- den_graph.cpp tries several row cuts)
+  g->tied_fs = g->tied_fs_state;
+  g->tied_w = g->tied_w_state;
   const int Npos = 4096 * ((H + 4095) / 4096);
   // beyond 16384 positions: the plane-wise form (chain_internal.h: kJvPlanes), whose rows need not be short either
   const bool planewise = Npos > kMaxIndex;
@@ -229,10 +252,35 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
   auto lout = [&](int h) { return std::min(deg(out_first, h), max_row); };
   std::stable_sort(st.begin(), st.end(), [&](int x, int y) { return lin(x) > lin(y); });
   const int ngroups = Npos / 64;
-  const int nbucket = std::max(1, (int)std::lround(std::sqrt((double)std::max(1, (H + 63) / 64))));
-  for (int b = 0; b < nbucket; ++b) {
-    const size_t lo = (size_t)H * b / nbucket, hi = (size_t)H * (b + 1) / nbucket;
-    std::stable_sort(st.begin() + lo, st.begin() + hi, [&](int x, int y) { return lout(x) > lout(y); });
+  // How many super-buckets: few make the out-lengths of a group uniform, many the in-lengths.  Which matters depends on the
+  // graph (a phone-LM graph has near-constant out-degrees and in-degrees from 1 to hundreds: sqrt(groups) buckets left 7 % of
+  // its forward cells as padding), so a handful of counts is tried and the one with the fewest padded steps kept.
+  {
+    const std::vector<int32_t> by_in(st);
+    const int root = std::max(1, (int)std::lround(std::sqrt((double)std::max(1, (H + 63) / 64))));
+    int64_t best_steps = -1;
+    std::vector<int32_t> best;
+    for (int nbucket : {1, std::max(1, root / 2), root, 2 * root, 4 * root, 8 * root, 16 * root, std::max(1, (H + 63) / 64)}) {
+      std::vector<int32_t> cand(by_in);
+      for (int b = 0; b < nbucket; ++b) {
+        const size_t lo = (size_t)H * b / nbucket, hi = (size_t)H * (b + 1) / nbucket;
+        std::stable_sort(cand.begin() + lo, cand.begin() + hi, [&](int x, int y) { return lout(x) > lout(y); });
+      }
+      int64_t steps = 0;
+      for (size_t g0 = 0; g0 < cand.size(); g0 += 64) {
+        int mi = 1, mo = 1;
+        for (size_t i = g0; i < std::min(cand.size(), g0 + 64); ++i) {
+          mi = std::max(mi, lin(cand[i]));
+          mo = std::max(mo, lout(cand[i]));
+        }
+        steps += mi + mo;
+      }
+      if (best_steps < 0 || steps < best_steps) {
+        best_steps = steps;
+        best.swap(cand);
+      }
+    }
+    st.swap(best);
   }
   // Inside runs of equal (in, out) length the order is free: use it so that every 32 consecutive states --
   // one half-slot, i.e. the 32 lanes that gather exp(y) at f(g) / s(g) and add gamma there in ONE
@@ -436,7 +484,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
   // swap lanes WITHIN their half-slot (their own rows stay where they are; only the banks they present
   // to the rows that gather them change) under a greedy local search on sum_b hist[b]^2 over all
   // half-slots of both directions.
-  if (!debug_flag(kDbgNoBankSearch)) {
+  if (!debug_flag(kDbgNoBankSearch) && !count_only) {
     const int nhalf = kWaves * K * 2;
     auto half_of = [&](int p) {
       const int tid = (p >> 2) % kThreads, k = 4 * (p / (4 * kThreads)) + (p & 3);
@@ -614,12 +662,14 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row)
     }
     out->nfix = (int32_t)out->fix.size();
     if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
-    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise);
+    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise, count_only);
+    if (count_only) continue;
     if (planewise && out->mask_stride > 64) return false;  // (a wave's mask words live in one register: at most 256 chunks)
   }
   if (planewise ? !compute_layout_planes(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), &g->layout)
                 : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), true, &g->layout))
     return false;
+  if (count_only) return true;
   // per-state tables in position order
   std::vector<uint32_t> fs(Npos + 4, 0u);
   std::vector<float> ws(Npos + 4, 0.f);
@@ -673,6 +723,8 @@ bool detect_tied(tc_den_graph *g, std::vector<char> *special) {
     g->tied_fs[h] = (uint32_t)(std::max(fpdf[h], 0) * 4) | ((uint32_t)(std::max(spdf[h], 0) * 4) << 16);
     g->tied_w[h] = wself[h];
   }
+  g->tied_fs_state = g->tied_fs;
+  g->tied_w_state = g->tied_w;
   return true;
 }
 
