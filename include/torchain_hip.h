@@ -371,9 +371,9 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
  *   "exp_per_frame"  (1: the streamed path transposes exp(y) one frame at a time, as it does when all frames would take
  *                     more than 1 GB of workspace)
- *   "reg_rows"       (1: den_tied_rr.hip -- row sums of the arc walks in registers, one more chunk of every wave's stream
- *                     in LDS -- where it fits: graphs without hub states, 8 states and 4 pdfs per thread, aligned rows.
- *                     Measured slower than the default kernel at C3; kept selectable for that record)
+ *   "old_arrange"    (1: the greedy placement of a half-slot's cells that rounds 1-4 used, instead of the matching of
+ *                     round 5: DESIGN.md 4.1e)       "no_planes" (1: tied graphs of 16385..28672 positions take the streamed
+ *                     path instead of the plane-wise on-chip kernel)
  * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):
  *   "no_pair"        (1: never the two-sequence kernel)        "no_tune" (1: no timing launches; the fused kernel)
  * The same switches can be set from the environment when the library is loaded:

@@ -86,10 +86,6 @@ struct ScheduleHost {
   int32_t mask_stride = 0;
   std::vector<int32_t> extra_first;   // per wave: index of its first secondary-row slot group
   int32_t nfix = 0;                   // number of fix-up entries (0: no barrier after the walk)
-  // [wave][img_stride chunks][4]: for each of a chunk's eight cells the 16-bit image of M0 under which the cell's FMA
-  // finds its row register in GPR-index mode, 0xC000 | row index (den_tied_rr.hip); two cells per word
-  std::vector<uint32_t> images;
-  int32_t img_stride = 0, max_chunks = 0;  // max_chunks: the longest wave stream, in chunks
   // plane-wise form (kMaxIndex < positions <= kMaxPlanePositions): a wave's stream is `subs` sub-streams -- its secondary
   // rows, then one per plane -- each padded to whole chunks, with mask words of its own: wave_range[wave * subs + sub],
   // masks[(wave * subs + sub) * mask_stride ...]; fix_begin is [thread][plane] (+ 1)
@@ -105,8 +101,6 @@ struct ScheduleDev {
   const int32_t *extra_first = nullptr;
   int32_t mask_stride = 0, nfix = 0;
   const void *cells_pair = nullptr;     // tied graphs of at most 8192 positions: the stream with offsets = position * 8
-  const uint32_t *images = nullptr;     // owner-computes schedules: row-register images per chunk (ScheduleHost::images)
-  int32_t img_stride = 0, max_chunks = 0;
   int32_t subs = 0;                     // plane-wise form: sub-streams per wave (ScheduleHost::subs), else 0
 };
 
@@ -378,10 +372,6 @@ int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t strea
 // ... two workgroups per sequence meeting in the middle (batches of at most half the CUs)
 bool planes_mitm_fits(const DenParams &p);
 int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t stream);
-// den_tied_rr.hip: the fused kernel with the row sums in registers and one more chunk of the stream in LDS (graphs without
-// hub states, 8 states and 4 pdfs per thread)
-bool rr_fits(const DenParams &p);
-int launch_den_tied_rr(const DenParams &p, int accumulate, hipStream_t stream);
 // den_tied_split.hip: the backward recursion alone (to run beside a forward-only launch_den_tied), and the pass
 // that forms gamma / the derivative from the two histories
 int launch_den_tied_backward_only(const DenParams &p, hipStream_t stream);
@@ -441,7 +431,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgRegRows, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

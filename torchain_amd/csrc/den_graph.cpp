@@ -386,7 +386,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "reg_rows", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -940,8 +940,6 @@ static int upload_den_graph(tc_den_graph *g, int device) {
       {g->bwd.extra_first.empty() ? no_extra.data() : g->bwd.extra_first.data(), kWaves * 4, 0},
       {want_pair ? pair_cells[0].data() : no_pair.data(), (want_pair ? pair_cells[0].size() : no_pair.size()) * 4, 0},
       {want_pair ? pair_cells[1].data() : no_pair.data(), (want_pair ? pair_cells[1].size() : no_pair.size()) * 4, 0},
-      {g->fwd.images.empty() ? no_pair.data() : g->fwd.images.data(), std::max<size_t>(4, g->fwd.images.size()) * 4, 0},
-      {g->bwd.images.empty() ? no_pair.data() : g->bwd.images.data(), std::max<size_t>(4, g->bwd.images.size()) * 4, 0},
   };
   size_t total = 0;
   for (auto &p : parts) {
@@ -981,14 +979,6 @@ static int upload_den_graph(tc_den_graph *g, int device) {
   if (want_pair) {
     d.fwd.cells_pair = blob + parts[15].off;
     d.bwd.cells_pair = blob + parts[16].off;
-  }
-  if (!g->fwd.images.empty() && !g->bwd.images.empty()) {
-    d.fwd.images = (const uint32_t *)(blob + parts[17].off);
-    d.bwd.images = (const uint32_t *)(blob + parts[18].off);
-    d.fwd.img_stride = g->fwd.img_stride;
-    d.bwd.img_stride = g->bwd.img_stride;
-    d.fwd.max_chunks = g->fwd.max_chunks;
-    d.bwd.max_chunks = g->bwd.max_chunks;
   }
   g->dev[device] = d;
   return TC_OK;

@@ -499,9 +499,7 @@ bool den_zeroes_xent(const DenParams &p, int num_cus) {
   if (p.L.planewise) return true;  // (both forms of den_tied_planes.hip write the rows)
   if (pair_wanted(p, num_cus)) return false;
   if (split_wanted(p) && 2 * p.S <= num_cus) return mitm_wanted(p);
-  DenParams pq = p;
-  pq.fwd_norm = nullptr;
-  return !rr_fits(pq);
+  return true;
 }
 
 // accumulate != 0 selects Kaldi's "deriv += deriv_weight * gamma" form
@@ -528,7 +526,6 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
     }
     DenParams pq = p;
     pq.fwd_norm = nullptr;
-    if (rr_fits(pq)) return launch_den_tied_rr(pq, accumulate, stream);  // den_tied_rr.hip
     return launch_den_tied(pq, accumulate, stream);  // den_tied_kernel.hip
   }
 #define TC_DISPATCH(J, V) \

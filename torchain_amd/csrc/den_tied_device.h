@@ -321,89 +321,6 @@ __device__ __forceinline__ void chunk_pw(const Chunk6 &q, uint32_t m8, float &ac
   }
 }
 
-// ---- row sums in REGISTERS (round 4; den_tied_rr.hip) ---------------------------------------------------------
-// What the row ends cost the walk above (profiles/microbench/walk_variants.hip, walk_gpridx.hip): one s_bitcmp +
-// s_cbranch per cell and, per row, a commit sequence that carries the sum to LDS -- 5474 cycles per walk of 57344
-// cells at ~1.5-way bank conflicts against 3952 with no row ends at all.  All 64 lanes of a wave are at the same
-// row index, so the FMA of a cell can accumulate straight into "row register number k": in GPR-index mode
-// (s_set_gpr_idx_on, VSRC2_REL | VDST_REL) v_fma_f32 v[ROW0], a, w, v[ROW0] reads and writes v[ROW0 + M0[7:0]], and a
-// row end is M0 += 1 on the scalar unit (s_bitcmp1 + s_addc): no branch, no commit, no LDS traffic for the row
-// sums, and the per-state passes read them from registers (4183 cycles in the same microbenchmark).
-//
-// The mode indexes EVERY vector instruction while it is on, so a chunk's eight FMAs form one asm block and the row
-// registers are pinned (the block names v[ROW0] literally): K <= 8 own rows in v[118:125] and one more that takes the
-// zero-weight padding cells behind a wave's last row end.
-typedef float f8 __attribute__((ext_vector_type(8)));
-struct RegRows8 {
-  f8 r;        // own rows 0..7 of this lane: v[118:125]
-  float dump;  // row "8": v126
-};
-#define TC_ROWS8_OPS(R) "+{v[118:125]}"((R).r), "+{v126}"((R).dump)
-__device__ __forceinline__ void rows_clear(RegRows8 &R) {
-  R.r = f8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  R.dump = 0.f;
-}
-__device__ __forceinline__ f4 reg_rows(const RegRows8 &R, int j) {
-  return j == 0 ? f4{R.r[0], R.r[1], R.r[2], R.r[3]} : f4{R.r[4], R.r[5], R.r[6], R.r[7]};
-}
-
-// s_set_gpr_idx_on directly followed by an indexed v_fma fails now and then on gfx950 (measured, scripts/debug_rr.py:
-// once in a few thousand blocks the first FMA of a block misses its row -- one wave's row sum of one frame -- and
-// the recursion carries the error on; with one wait state behind s_set_gpr_idx_on never, in 200 k blocks).  Two.
-#ifndef TC_RR_NOP_ON
-#define TC_RR_NOP_ON "s_nop 1\n\t"
-#endif
-// rows[row(i)] += w_i * SRC[off_i] over one chunk.  img = the chunk's four words of the schedule's row-register images
-// (schedule_owner.cpp: for every cell the 16-bit value of M0 under which its FMA finds its row, 0xC000 | row, two cells
-// per word): one scalar move per cell, and nothing is carried from cell to cell or from block to block -- the first
-// version advanced M0 behind every cell with s_bitcmp1 + s_addc on the schedule's row-end bits, a chain of three
-// dependent issues per cell (~480 cycles per chunk for a wave running alone) -- so a wave may take its chunks in any
-// order.  Eight gathers in flight per wait and one mode switch per eight cells: what a wave does between two waits is
-// what the other three waves of its SIMD have to hide (four cells per block were measured in the kernel: slower).
-#define TC_RR_CELL(i, set) set "\n\tv_fma_f32 v118, %[a" #i "], %[w" #i "], v118\n\t"
-template <uint32_t SRC>
-__device__ __forceinline__ void chunk_rr(const Chunk6 &q, u4 img, RegRows8 &R) {
-  const uint32_t o0 = lo16(q.oc.x), o1 = hi16(q.oc.x), o2 = lo16(q.oc.y), o3 = hi16(q.oc.y);
-  const uint32_t o4 = lo16(q.oc.z), o5 = hi16(q.oc.z), o6 = lo16(q.oc.w), o7 = hi16(q.oc.w);
-#ifdef TC_ABL_NOGATHER
-  const float a0 = __uint_as_float(o0), a1 = __uint_as_float(o1), a2 = __uint_as_float(o2), a3 = __uint_as_float(o3);
-  const float a4 = __uint_as_float(o4), a5 = __uint_as_float(o5), a6 = __uint_as_float(o6), a7 = __uint_as_float(o7);
-#else
-  const float a0 = ldsf(SRC + o0), a1 = ldsf(SRC + o1), a2 = ldsf(SRC + o2), a3 = ldsf(SRC + o3);
-  const float a4 = ldsf(SRC + o4), a5 = ldsf(SRC + o5), a6 = ldsf(SRC + o6), a7 = ldsf(SRC + o7);
-#endif
-#ifdef TC_ABL_NOFMA
-  asm volatile("; no fma" : TC_ROWS8_OPS(R) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "s"(img.x), "v"(q.wa.x), "v"(q.wb.x));
-  return;
-#endif
-  asm volatile("s_set_gpr_idx_on %[i0], 0xc\n\t" TC_RR_NOP_ON  //
-               TC_RR_CELL(0, "s_mov_b32 m0, %[i0]") TC_RR_CELL(1, "s_lshr_b32 m0, %[i0], 16") TC_RR_CELL(2, "s_mov_b32 m0, %[i1]")
-               TC_RR_CELL(3, "s_lshr_b32 m0, %[i1], 16") TC_RR_CELL(4, "s_mov_b32 m0, %[i2]") TC_RR_CELL(5, "s_lshr_b32 m0, %[i2], 16")
-               TC_RR_CELL(6, "s_mov_b32 m0, %[i3]") TC_RR_CELL(7, "s_lshr_b32 m0, %[i3], 16")  //
-               "s_set_gpr_idx_off"
-               : TC_ROWS8_OPS(R)
-               : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [a4] "v"(a4), [a5] "v"(a5), [a6] "v"(a6), [a7] "v"(a7),
-                 [w0] "v"(q.wa.x), [w1] "v"(q.wa.y), [w2] "v"(q.wa.z), [w3] "v"(q.wa.w), [w4] "v"(q.wb.x), [w5] "v"(q.wb.y), [w6] "v"(q.wb.z),
-                 [w7] "v"(q.wb.w), [i0] "s"(img.x), [i1] "s"(img.y), [i2] "s"(img.z), [i3] "s"(img.w)
-               : "m0", "scc");
-}
-
-// ... and over half a chunk (w = the half's four weights, o01 / o23 its two offset words, i0 / i1 its two image words):
-// the form a chunk kept in LDS is taken in, 10 registers in flight instead of 20
-template <uint32_t SRC>
-__device__ __forceinline__ void quad_rr(u4 w, uint32_t o01, uint32_t o23, uint32_t i0, uint32_t i1, RegRows8 &R) {
-  const uint32_t o0 = lo16(o01), o1 = hi16(o01), o2 = lo16(o23), o3 = hi16(o23);
-  const float a0 = ldsf(SRC + o0), a1 = ldsf(SRC + o1), a2 = ldsf(SRC + o2), a3 = ldsf(SRC + o3);
-  asm volatile("s_set_gpr_idx_on %[i0], 0xc\n\t" TC_RR_NOP_ON  //
-               TC_RR_CELL(0, "s_mov_b32 m0, %[i0]") TC_RR_CELL(1, "s_lshr_b32 m0, %[i0], 16") TC_RR_CELL(2, "s_mov_b32 m0, %[i1]")
-               TC_RR_CELL(3, "s_lshr_b32 m0, %[i1], 16")  //
-               "s_set_gpr_idx_off"
-               : TC_ROWS8_OPS(R)
-               : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [w0] "v"(w.x), [w1] "v"(w.y), [w2] "v"(w.z), [w3] "v"(w.w), [i0] "s"(i0),
-                 [i1] "s"(i1)
-               : "m0", "scc");
-}
-
 // The CU serves older waves first wherever waves contend, so the youngest wave of each SIMD finishes its
 // walk last and every frame waits for it: during the walks the four wave generations run at issue
 // priorities 0..3, youngest highest.

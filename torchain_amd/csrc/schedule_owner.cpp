@@ -63,7 +63,6 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   out->subs = planewise ? subs : 0;
   out->wave_range.assign((size_t)kWaves * subs, make_int2(0, 0));
   std::vector<std::vector<uint32_t>> wave_masks((size_t)kWaves * subs);
-  std::vector<std::vector<char>> wave_row_end;  // per wave and pair of cells: flags A | B
   int64_t arc_cells = 0;
   int nrows = 0;
   for (int w = 0; w < kWaves; ++w)
@@ -146,7 +145,6 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
           if (row_end[i] & 2) mw[i / 8] |= 1u << (8 + i % 8);    // A flags: bits 8..15
         }
       }
-      wave_row_end.push_back(row_end);
     }
   // readable padding: the kernels request up to four chunks past a wave's range
   for (int i = 0; i < 64 * 32; ++i) out->cells.push_back(ArcRec{0.f, 0u});
@@ -163,27 +161,6 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   } else {
     out->masks.assign(stride * wave_masks.size() + 64, 0u);
     for (size_t i = 0; i < wave_masks.size(); ++i) std::copy(wave_masks[i].begin(), wave_masks[i].end(), out->masks.begin() + i * stride);
-  }
-  // row-register images (den_tied_rr.hip): cell i of a wave's stream belongs to row (number of row ends before it); rows
-  // beyond 15 -- secondary rows of hub states, which that kernel does not take -- are capped
-  out->images.clear();
-  out->img_stride = out->max_chunks = 0;
-  if (!planewise) {
-    size_t max_chunks = 1;
-    for (auto &re : wave_row_end) max_chunks = std::max(max_chunks, (re.size() + 3) / 4);
-    out->img_stride = (int32_t)std::max<size_t>(max_chunks + 4, 16);  // (+ the chunks a walk may request ahead; a register's worth)
-    out->max_chunks = (int32_t)max_chunks;
-    out->images.assign((size_t)kWaves * out->img_stride * 4, 0xC000C000u);
-    for (int w = 0; w < kWaves; ++w) {
-      int row = 0;
-      for (size_t pr = 0; pr < wave_row_end[w].size(); ++pr) {
-        const uint32_t first = 0xC000u | (uint32_t)std::min(row, 15);
-        if (wave_row_end[w][pr] & 2) ++row;  // the row ends with the pair's first cell
-        const uint32_t second = 0xC000u | (uint32_t)std::min(row, 15);
-        if (wave_row_end[w][pr] & 1) ++row;
-        out->images[((size_t)w * out->img_stride + pr / 4) * 4 + pr % 4] = first | second << 16;
-      }
-    }
   }
   if (debug_flag(kDbgSchedTrace))
     fprintf(stderr, "[sched] gathers: %lld LDS cycles as placed, bound %lld, conflict-free %lld\n", (long long)out->conflict_cost,
