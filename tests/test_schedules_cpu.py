@@ -110,7 +110,10 @@ def test_phone_lm_graph_near_the_state_limit_stays_on_chip():
     fst = synth.config_den_fst("R2")
     stats = io.DenominatorGraph(fst, fst.num_pdfs).stats()
     assert stats["tied"] == 1 and 0 < stats["lds_bytes"] <= 160 * 1024 + 1024  # (lds_bytes is quoted for T = 256)
-    assert stats["fwd_rows"] >= fst.num_states and stats["bwd_rows"] == fst.num_states
+    # (rows = non-empty arc lists: since round 5 the builder takes the row cut that leaves the fewest cells -- here one
+    # without any secondary row, so the forward rows are the states that have in-arcs at all)
+    has_in = len(set(int(d) for s_, d in zip(fst.src, fst.dst) if s_ != d))
+    assert stats["fwd_rows"] >= has_in and stats["bwd_rows"] == fst.num_states
 
 
 def test_split_graph_that_does_not_fit_goes_back_to_the_general_kernel():

@@ -293,10 +293,9 @@ int build_schedules(tc_den_graph *g) {
     // with many popular states (real phone-LM graphs: in-degrees of a hundred and more) and close to the 16384-state
     // limit may have no room for them, so the home rows are allowed to grow before the graph is given up to the
     // streamed kernels (8x slower per arc).
-    // Which cut?  The first that fits (counting passes: no placement work) -- and for the plane-wise form, whose row sums
-    // share four rows per wave so that a long home row costs no LDS while every secondary row costs its wave a 64-lane slot
-    // that is mostly padding when the wave has few of them (R4: 7 % of the forward cells with rows cut at 32), the cut that
-    // leaves the fewest cells.
+    // Which cut?  Of those that fit (counting passes: no placement work) the one that leaves the fewest cells: every
+    // secondary row costs its wave a 64-lane slot that is mostly padding when the wave has few of them (R4: 7 % of the forward
+    // cells with rows cut at 32, R3: 5 %), a long home row pads the 63 rows that run in lockstep with it.
     int fit_row = 0;
     {
       int64_t best_cells = -1;
@@ -307,7 +306,8 @@ int build_schedules(tc_den_graph *g) {
           best_cells = cells;
           fit_row = max_row;
         }
-        if (!g->layout.planewise) break;
+        if (debug_flag(kDbgSchedTrace)) fprintf(stderr, "[sched] rows cut at %d: %lld cells, %d bytes of LDS\n", max_row, (long long)cells, 4 * g->layout.total_floats);
+        if (getenv("TC_ROWCUT_FIRST")) break;  // (experiments: the first cut that fits, as rounds 2-4 took it)
       }
       if (fit_row && !build_owner(g, special, fit_row)) {
         fit_row = 0;  // (a full build can still fail where the count fitted: more than 256 chunks per wave)
