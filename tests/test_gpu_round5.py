@@ -152,3 +152,111 @@ def test_streamed_path_gamma_sums_at_256x150(kernel_family, cfg):
     rows = out["deriv"].sum(axis=1, dtype=np.float64)
     assert np.abs(rows - 1.0).max() <= 1e-4, np.abs(rows - 1.0).max()
     assert abs(rows.sum() - S * T) <= 1e-5 * S * T
+
+
+def test_kernel_choice_cache_below_the_python_layer(tmp_path, monkeypatch):
+    """a caller of the C ABI alone -- tc_den_graph_create + tc_den_graph_prepare through ctypes, no
+    io.DenominatorGraph -- gets the measured kernel choice of an earlier handle from the library's cache without any timing
+    launch (both times reported as zero), and the file holds the entry under hash + device name."""
+    import ctypes as C
+    import json
+
+    import torch
+    from torchain_amd._lib import check, lib
+    path = tmp_path / "tuning.json"
+    monkeypatch.setenv("TORCHAIN_TUNING_CACHE", str(path))
+    fst = synth.config_den_fst("R1")
+    P = synth.CONFIGS["R1"]["P"]
+
+    def make():
+        h = C.c_void_p()
+        src, dst, il = (np.ascontiguousarray(a, np.int32) for a in (fst.src, fst.dst, fst.ilabel))
+        w, fin = (np.ascontiguousarray(a, np.float32) for a in (fst.weight, fst.final))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        check(lib.tc_den_graph_create(C.byref(h), int(fst.num_states), len(src), p(src), p(dst), p(il), p(w), p(fin), int(fst.start), P),
+              "tc_den_graph_create")
+        return h
+
+    def tuning(h):
+        choice, a, b = C.c_int32(-1), C.c_float(-1), C.c_float(-1)
+        check(lib.tc_den_graph_tuning(h, 0, C.byref(choice), C.byref(a), C.byref(b)), "tc_den_graph_tuning")
+        return choice.value, a.value, b.value
+
+    g1 = make()
+    check(lib.tc_den_graph_prepare(g1, 0), "tc_den_graph_prepare")
+    c1, f1, t1 = tuning(g1)
+    assert f1 > 0.0 and t1 > 0.0  # really timed: nothing was cached
+    key = "%016x:%s" % (int(lib.tc_den_graph_hash(g1)), torch.cuda.get_device_name(0))
+    table = json.load(open(path))
+    assert table[key]["two_sequence_kernel"] == c1 and table[key]["fused_ms"] == pytest.approx(f1, rel=1e-6)
+    g2 = make()
+    check(lib.tc_den_graph_prepare(g2, 0), "tc_den_graph_prepare")
+    assert tuning(g2) == (c1, 0.0, 0.0)  # the cached choice, no timing launches
+    # a choice shipped through tc_tuning_cache_put wins over nothing being cached for a third handle of another process
+    assert lib.tc_tuning_cache_put(int(lib.tc_den_graph_hash(g1)), torch.cuda.get_device_name(0).encode(), 1 - c1, 1.0, 1.0) == 0
+    g3 = make()
+    check(lib.tc_den_graph_prepare(g3, 0), "tc_den_graph_prepare")
+    assert tuning(g3)[0] == 1 - c1
+    for h in (g1, g2, g3):
+        lib.tc_den_graph_free(h)
+
+
+def test_plane_wise_kernel_long_utterance(oracle, kernel_family):
+    """400 frames (the frame sums live in LDS: round4(T + 1) floats behind the layout), both forms, log-prob and row sums."""
+    fst = synth.random_den_fst(17000, 3, 500, seed=91)
+    S, T = 2, 400
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=92)
+    ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=0.1, deriv_weight=1.0)
+    for form in ("two_cu", "fused"):
+        kernel_family("no_phase_split", 1 if form == "fused" else 0)
+        out = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0)
+        assert out["status"] == 0 and out["graph"].stats()["tied"] == 1
+        assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"]), form
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL, form
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_plane_wise_kernel_fuzz(oracle, chunk):
+    """Seeded sweep over the plane-wise kernel's graphs: random chain-structured graphs, graphs with hub states (secondary
+    rows folded per plane, or home rows cut longer), nearly chain-structured graphs the library splits into 16385..28672
+    positions, phone-LM structure; 5 to 7 planes, 1 to 5 sequences (two workgroups per sequence, or the fused kernel), 1 to 12
+    frames, through the full objective (tests/test_gpu_fuzz.py's bounds)."""
+    from helpers import hip_chain
+    from torchain_amd._lib import lib
+    rng = np.random.default_rng(4200 + chunk)
+    for _ in range(6):
+        kind = str(rng.choice(["tied", "hubs", "nearly", "phone_lm"]))
+        seed = int(rng.integers(0, 10000))
+        P = int(rng.choice([64, 700, 2928, 4096]))
+        if kind == "tied":
+            fst = synth.random_den_fst(int(rng.integers(16500, 28600)), int(rng.integers(2, 7)), P, seed=seed)
+        elif kind == "hubs":
+            H = int(rng.integers(16500, 27000))
+            fst = synth.skewed_tied_den_fst(H, H * int(rng.integers(3, 8)), P, seed=seed, hub_fraction=float(rng.choice([0.002, 0.01])))
+        elif kind == "nearly":
+            fst = synth.nearly_tied_den_fst(int(rng.integers(9000, 13000)), int(rng.integers(3, 6)), P, seed=seed, fraction=float(rng.uniform(0.3, 0.8)))
+        else:
+            fst = synth.phone_lm_den_fst(num_histories=int(rng.integers(1500, 2300)), branching=int(rng.integers(9, 13)), num_pdfs=max(P, 200), seed=seed)
+        S, T = int(rng.integers(1, 6)), int(rng.integers(1, 13))
+        leaky, l2 = float(rng.choice([1e-5, 0.05, 0.2])), float(rng.choice([0.0, 1e-4]))
+        fused = bool(rng.integers(0, 2))
+        lib.tc_debug_set(b"no_phase_split", 1 if fused else 0)
+        try:
+            g = oracle.DenGraph(fst)
+            sup = synth.random_supervision(fst, S, T, 2, seed=seed + 1, initial_probs=g.initial_probs())
+            y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=seed + 2, scale=float(rng.choice([1.0, 3.0])))
+            ref = oracle.compute_chain_objf_and_deriv(g, sup, y, l2, leaky, want_xent=True)
+            out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True)
+        finally:
+            lib.tc_debug_set(b"no_phase_split", 0)
+        st = out["graph"].stats()
+        desc = "%s H=%d A=%d P=%d S=%d T=%d leaky=%g l2=%g fused=%d kernel=%d lds=%d" % (
+            kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, fused, st["tied"], st["lds_bytes"])
+        res = out["results"]
+        assert abs(res[0] - ref["objf"]) / max(abs(ref["objf"]), 0.05 * S * T) <= REL, desc
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL, desc
+        assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL, desc
+        assert res[2] == ref["weight"], desc
+        # (seven planes fit the LDS only beside at most ~3000 pdfs: 112 KB of gather source + exp(y) + gamma + 16 KB of row sums)
+        if kind in ("tied", "phone_lm") and 16384 < fst.num_states <= 24576 and fst.num_pdfs <= 4096:
+            assert st["tied"] == 1, desc  # (on chip: the plane-wise kernel)
