@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../torchain_amd/csrc"
 name=$1; shift
 mkdir -p ../../scratch_abl
-all="den_kernels den_tied_kernel den_tied_planes den_tied_split den_tied_pair den_tied_mitm den_slab_kernel"
+all="den_kernels den_general_owner den_tied_kernel den_tied_planes den_tied_split den_tied_pair den_tied_mitm den_slab_kernel"
 only=${ONLY:-$all}
 objs=""
 for f in $all; do

@@ -260,3 +260,63 @@ def test_plane_wise_kernel_fuzz(oracle, chunk):
         # (seven planes fit the LDS only beside at most ~3000 pdfs: 112 KB of gather source + exp(y) + gamma + 16 KB of row sums)
         if kind in ("tied", "phone_lm") and 16384 < fst.num_states <= 24576 and fst.num_pdfs <= 4096:
             assert st["tied"] == 1, desc  # (on chip: the plane-wise kernel)
+
+
+# ---- the general on-chip kernel on owner-computes schedules (den_general_owner.hip) ---------------------------------------
+@pytest.mark.parametrize("which", ["forced", "skewed", "three_planes_of_pdfs"])
+def test_general_owner_kernel_against_round1_kernel_and_oracle(oracle, kernel_family, which):
+    """General graphs of at most 8192 states take round 5's kernel (owner-computes schedules, 8-byte cells, two barriers per
+    frame); `old_general` keeps round 1's.  Both against the oracle through the full objective; Kaldi's accumulate form; the
+    forward-only call."""
+    from helpers import hip_chain
+    if which == "forced":
+        kernel_family("force_general")
+        fst = synth.random_den_fst(5000, 6, 900, seed=21)
+    elif which == "skewed":
+        fst = synth.skewed_den_fst(1500, 12000, 400, seed=22)
+    else:
+        kernel_family("force_general")
+        fst = synth.random_den_fst(3000, 4, 9000, seed=23)
+    S, T = 5, 17
+    g = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, S, T, 2, seed=31, initial_probs=g.initial_probs())
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=32)
+    ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1, want_xent=True)
+    outs = []
+    for old in (0, 1):
+        kernel_family("old_general", old)
+        out = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, xent=True)
+        assert out["graph"].stats()["tied"] == 0
+        res = out["results"]
+        assert abs(res[0] - ref["objf"]) <= REL * max(abs(ref["objf"]), 0.05 * S * T), (which, old, res, ref["results"])
+        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL, (which, old)
+        assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL, (which, old)
+        outs.append(out)
+    assert not np.array_equal(outs[0]["deriv"], outs[1]["deriv"])  # (they ARE two kernels)
+    kernel_family("old_general", 0)
+    dref = oracle.den_forward_backward(g, y, S, leaky=0.05, deriv_weight=1.0)
+    acc = hip_den(fst, y, S, leaky=0.05, deriv_weight=1.0, accumulate=True, init=0.5)
+    assert abs(acc["logprob"] - dref["logprob"]) <= REL * abs(dref["logprob"]) and acc["status"] == 0
+    assert rel_err(acc["deriv"] - 0.5, dref["deriv"]) <= REL
+    again = hip_den(fst, y, S, leaky=0.05, deriv_weight=1.0, accumulate=True, init=0.5)
+    assert np.array_equal(acc["deriv"], again["deriv"]) and acc["logprob"] == again["logprob"]  # bitwise reproducible
+    fwd = hip_den(fst, y, S, leaky=0.05, want_deriv=False)
+    assert abs(fwd["logprob"] - dref["logprob"]) <= REL * abs(dref["logprob"])
+
+
+def test_general_owner_kernel_full_size_and_peaky(oracle, kernel_family):
+    """The C3 graph forced onto the general kernel at 64 x 150 against the oracle (element-wise bounds), and a peaky T = 150
+    sequence against the float64 formulation (tests/test_gpu_peaky.py's rule)."""
+    from test_gpu_peaky import _check
+    kernel_family("force_general")
+    c = synth.CONFIGS["C3"]
+    fst = synth.config_den_fst("C3")
+    S, T = 64, 150
+    y = synth.random_nnet_output(S, T, c["P"], seed=1241)
+    out = hip_den(fst, y, S, leaky=c["leaky"], deriv_weight=1.0)
+    assert out["graph"].stats()["tied"] == 0 and out["status"] == 0
+    ref_lp, ref = _oracle_den(oracle, fst, y, S, T, c["leaky"])
+    assert abs(out["logprob"] - ref_lp) <= REL * abs(ref_lp)
+    assert rel_err(out["deriv"], ref, floor=1.0) <= REL
+    elementwise(out["deriv"], ref, "C3 forced general")
+    _check(oracle, synth.config_den_fst("C2"), 1, 150, 10.0, 0.1)

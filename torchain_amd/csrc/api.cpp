@@ -39,7 +39,7 @@ struct Workspace {
 // Hs: stored states per frame of the alpha history (layout positions for tied graphs: build_owner)
 int hist_states(const tc_den_graph *g) {
   if (g->big) return ((g->tied ? g->work_H : g->H) + 3) & ~3;
-  return g->tied ? g->layout.Hs : ((g->H + 3) & ~3);
+  return g->tied || g->gen_owner ? g->layout.Hs : ((g->H + 3) & ~3);
 }
 int big_p(const tc_den_graph *g) { return g->big ? g->P : 0; }
 int big_h(const tc_den_graph *g) { return g->big ? (g->tied ? g->work_H : g->H) : 0; }  // tied: work-graph states
@@ -132,7 +132,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   }
   bool tied = g->tied;
   // tied graphs address states by layout position (a multiple of 4096 of them, phantoms included)
-  const int nstates = g->big ? (tied ? g->work_H : g->H) : (tied ? g->layout.Hs : g->H);
+  const int nstates = g->big ? (tied ? g->work_H : g->H) : (tied || g->gen_owner ? g->layout.Hs : g->H);
   if (g->big) {
     p->L = DenLayout();
     p->L.Hs = (nstates + 3) & ~3;
@@ -160,6 +160,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->pair_choice = d.pair_choice > 0 ? 1 : 0;
   p->big_Sp = (S + g->big_G - 1) / g->big_G * g->big_G;
   p->big_sum_pi = g->big_sum_pi;
+  p->gen_owner = !g->big && g->gen_owner ? 1 : 0;
   p->tied_fs = tied ? d.tied_fs : nullptr;
   p->tied_w = tied ? d.tied_w : nullptr;
   p->fwd = d.fwd;

@@ -198,6 +198,7 @@ struct DenParams {
   DenLayout L;
   const uint32_t *tied_fs;  // non-null selects the tied-graph kernel (see tc_den_graph below)
   const float *tied_w;
+  int gen_owner = 0;        // general graph on owner-computes schedules: den_general_owner.hip
   BigDev big;           // streamed path only
   float *big_expy;      // [slab][P][16]  exp(y_t) of the current frame, transposed; or [T][slab][P][16], every frame (big_exp_stride)
   int64_t big_exp_stride = 0;  // floats between consecutive frames of big_expy (0: one frame at a time)
@@ -238,6 +239,9 @@ struct tc_den_graph {
   // non-self-loop arcs, the forward walk gathers alpha' alone, the backward walk gathers
   // Y(g) = beta(g) * p(f(g)) alone, and the self-loops are applied per state by the owning thread.
   bool tied = false;
+  // GENERAL graph on the owner-computes schedules (den_general_owner.hip, round 5): states addressed by layout position as
+  // for tied graphs, 8-byte cells with the arc's pdf, no per-state tables
+  bool gen_owner = false;
   std::vector<uint32_t> tied_fs;      // position order once build_owner has run
   std::vector<float> tied_w;
   std::vector<uint32_t> tied_fs_state;  // ... and in work-state order, as detect_tied left them (build_owner starts from these)
@@ -349,7 +353,8 @@ void build_general(tc_den_graph *g);                                            
 bool detect_tied(tc_den_graph *g, std::vector<char> *special);                         // schedule_owner.cpp
 bool make_work_graph(tc_den_graph *g);                                                 // schedule_owner.cpp
 // (count_only: fills fwd / bwd.padded_arcs and the layout alone -- what a candidate row cut would cost)
-bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row, bool count_only = false);  // schedule_owner.cpp
+// (general: owner-computes schedules of a graph that is not chain-structured -- every arc, its pdf in the cell)
+bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row, bool count_only = false, bool general = false);  // schedule_owner.cpp
 int arrange_half(const std::vector<std::vector<int64_t>> &lane_arcs, int steps, const int32_t *other,
                  const int32_t *pdf, std::vector<std::vector<int>> *pos_out);          // den_layout.cpp
 // ... one gather per cell (tied schedules): step by step, a matching of lanes to banks that keeps the half-slot on its
@@ -368,6 +373,7 @@ hipError_t allow_dynamic_lds(const void *kernel, size_t lds_bytes);             
 int launch_den(const DenParams &p, hipStream_t stream);
 int launch_den_big(const DenParams &p, int accumulate, hipStream_t stream);
 int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_kernel.hip
+int launch_den_general_owner(const DenParams &p, int accumulate, hipStream_t stream);  // den_general_owner.hip
 int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t stream);  // den_tied_planes.hip
 // ... two workgroups per sequence meeting in the middle (batches of at most half the CUs)
 bool planes_mitm_fits(const DenParams &p);
@@ -431,7 +437,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -283,10 +283,37 @@ int build_schedules(tc_den_graph *g) {
     g->copy_first.resize(g->H + 1);
     std::iota(g->copy_first.begin(), g->copy_first.end(), 0);
     g->tied = false;
+    g->gen_owner = false;
     g->tied_fs.clear();
     g->tied_w.clear();
     g->fwd = ScheduleHost();
     g->bwd = ScheduleHost();
+  };
+  // General graphs of at most 8192 states (round 5): the owner-computes schedules of the tied kernels with the arc's pdf in
+  // the cell (den_general_owner.hip) -- no in-band row cells, no barrier between walk and per-state pass, resident chunks.
+  // What it does not take (rows of other lanes in the backward walk: out-degrees beyond 256; more than 8192 states; a
+  // layout without alpha' in LDS) stays with round 1's kernel (den_kernels.hip).
+  auto general_owner = [&]() {
+    if (debug_flag(kDbgOldGeneral)) return false;
+    const std::vector<char> none(g->work_src.size(), 0);
+    int fit_row = 0;
+    int64_t best_cells = -1;
+    for (int max_row = kMaxRowLen; max_row <= 8 * kMaxRowLen; max_row *= 2) {
+      if (!build_owner(g, none, max_row, true, true)) continue;
+      const int64_t cells = g->fwd.padded_arcs + g->bwd.padded_arcs;
+      if (best_cells < 0 || cells < best_cells) {
+        best_cells = cells;
+        fit_row = max_row;
+      }
+    }
+    if (!fit_row || !build_owner(g, none, fit_row, false, true)) {
+      g->fwd = ScheduleHost();
+      g->bwd = ScheduleHost();
+      return false;
+    }
+    g->gen_owner = true;
+    g->layout_ok = true;
+    return true;
   };
   if (!want_big && g->tied) {
     // Rows longer than kMaxRowLen spill into secondary rows, each with a private accumulator slot in LDS; a graph
@@ -329,6 +356,7 @@ int build_schedules(tc_den_graph *g) {
       std::vector<uint32_t> tfs = g->tied_fs;
       const int32_t wH = g->work_H;
       restore_unsplit();
+      if (general_owner()) return TC_OK;
       build_general(g);
       g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
       if (g->layout_ok) return TC_OK;
@@ -350,6 +378,8 @@ int build_schedules(tc_den_graph *g) {
     want_big = true;  // tied but beyond the on-chip layouts: the streamed kernels keep the tied factorisation
   }
   if (!want_big) {
+    if (g->work_H != g->H) restore_unsplit();  // (a split that did not make the graph chain-structured)
+    if (general_owner()) return TC_OK;
     build_general(g);
     g->layout_ok = compute_layout(g->H, g->P, 256, std::max(g->fwd.extra_slots, g->bwd.extra_slots), false, &g->layout);
     if (g->layout_ok) return TC_OK;
@@ -386,7 +416,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -710,6 +740,40 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   const int Hs = g->layout.Hs;
   // (plane-wise form: the replay keeps one accumulator per position, where the kernel reuses four rows per wave)
   std::vector<float> acc((size_t)std::max(g->layout.acc_floats, Hs + 4 + sc.extra_slots) + 64, 0.f);
+  if (g->gen_owner) {
+    // owner-computes schedules of a general graph: 8-byte cells {w, position * 4 | pdf * 4 << 16}, [chunk][4 blocks][lane]
+    const int K = Hs / kThreads;
+    std::vector<float> src_pos((size_t)Hs + 4, 0.f);
+    for (int h = 0; h < H; ++h) src_pos[g->pos[h]] = gather[h];
+    for (int w = 0; w < kWaves; ++w) {
+      const int first = sc.wave_range[w].x, n = sc.wave_range[w].y;
+      for (int l = 0; l < 64; ++l) {
+        const int tid = 64 * w + l;
+        int k = 0;
+        float a = 0.f;
+        auto slot = [&]() { return k < K ? 4 * (tid + kThreads * (k >> 2)) + (k & 3) : Hs + 4 + 64 * (sc.extra_first[w] + (k - K)) + l; };
+        for (int i = 0; i < n; ++i) {
+          const size_t c = (size_t)first + i, chunk = c / 8, q = c % 8;
+          const uint32_t *base = &sc.cells6[chunk * 4 * 64 * 4];
+          const uint32_t x = base[((q / 4) * 64 + l) * 4 + (q % 4)], idx = base[((2 + q / 4) * 64 + l) * 4 + (q % 4)];
+          float wgt;
+          memcpy(&wgt, &x, 4);
+          a += wgt * src_pos[(idx & 0xffffu) >> 2] * pdf_factor[idx >> 18];
+          const uint32_t m = sc.masks[(size_t)w * sc.mask_stride + (i / 2) / 8];
+          const int bit = (i / 2) % 8;
+          if ((m >> ((i & 1) ? bit : 8 + bit)) & 1u) {  // flag B: the pair's second cell ends a row, flag A: its first
+            acc[slot()] = a;
+            ++k;
+            a = 0.f;
+          }
+        }
+      }
+    }
+    for (size_t t = 0; t + 1 < sc.fix_begin.size(); ++t)
+      for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) acc[sc.fix[e].x] += acc[sc.fix[e].y];
+    for (int h = 0; h < H; ++h) out[h] = acc[g->pos[h]];
+    return TC_OK;
+  }
   if (g->tied) {
     const int K = Hs / kThreads;
     const bool pw = g->layout.planewise;
@@ -902,7 +966,7 @@ static int upload_den_graph(tc_den_graph *g, int device) {
   }
   std::vector<float> pi_pad(Hs + 4, 0.f);
   std::copy(g->initial_probs.begin(), g->initial_probs.end(), pi_pad.begin());
-  if (g->tied) pi_pad = g->pi_pos;  // position order (build_owner)
+  if (g->tied || g->gen_owner) pi_pad = g->pi_pos;  // position order (build_owner)
   const std::vector<uint32_t> no_mask(1, 0u);
   const std::vector<int32_t> no_extra(kWaves, 0);
   // den_tied_pair.hip gathers from a [position][2 sequences] array: the same streams with offsets = position * 8,

@@ -528,6 +528,7 @@ int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
     pq.fwd_norm = nullptr;
     return launch_den_tied(pq, accumulate, stream);  // den_tied_kernel.hip
   }
+  if (p.gen_owner) return launch_den_general_owner(p, accumulate, stream);  // den_general_owner.hip
 #define TC_DISPATCH(J, V) \
   if (JV == J && PV == V) return launch_jp<J, V>(p, accumulate, lds, stream);
   TC_DISPATCH(kJvSmall, kPvSmall)

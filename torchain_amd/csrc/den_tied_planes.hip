@@ -245,7 +245,11 @@ struct PlaneSeq {
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.z, ws.z, F.z, al.z, bt.z, gs, dpart),
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.w, ws.w, F.w, al.w, bt.w, gs, dpart)};
       part += hsum(a);
+#ifdef TC_PW_NT_STORE
+      bst4_aux<2>(hist_t, own16 + pj, a);
+#else
       bst4_aux<0>(hist_t, own16 + pj, a);  // alpha_t: its history row, and where the frame's tail finds it again
+#endif
       {  // the next plane's tables (index clamped: every request of the frame is unconditional)
         const int jn = j + 1 < planes ? j + 1 : j;
         fs_n = bld4u(r_fs, own16, (uint32_t)jn * kPlane);

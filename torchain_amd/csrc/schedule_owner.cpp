@@ -32,9 +32,11 @@ struct OwnerTask {
   int32_t len;
 };
 
+// pdf != nullptr: GENERAL graphs (den_general_owner.hip) -- a cell also carries the LDS offset of its arc's pdf in exp(y)
+// (8-byte cells: {w, position * 4 | pdf * 4 << 16}), and the placement inside a half-slot weighs both gathers' banks.
 static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std::vector<OwnerTask>>> &slots,
                               const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
-                              ScheduleHost *out, bool planewise, bool count_only) {
+                              ScheduleHost *out, bool planewise, bool count_only, const int32_t *pdf = nullptr) {
   // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows.  count_only: the number of cells alone (padded_arcs)
   if (count_only) {
     int64_t cells = 0;
@@ -87,7 +89,10 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
             if (t.len > 0) ++nrows;
           }
           std::vector<std::vector<int>> pos, padb;
-          if (debug_flag(kDbgOldArrange)) {
+          if (pdf) {
+            out->conflict_cost += arrange_half(lane_arcs, steps, opos, pdf, &pos);
+            out->conflict_free_cost += steps;  // (two gathers per cell)
+          } else if (debug_flag(kDbgOldArrange)) {
             out->conflict_cost += arrange_half(lane_arcs, steps, opos, nullptr, &pos);
           } else {
             int lb = 0;
@@ -102,9 +107,11 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
               if (pos[l][i] >= 0) {
                 const int64_t a = lane_arcs[l][pos[l][i]];
                 cell = ArcRec{prob[a], (uint32_t)opos[a] << off_shift};
+                if (pdf) cell.idx = ((uint32_t)opos[a] << 2) | ((uint32_t)pdf[a] << 18);
               } else {
                 // padding: w = 0, gathered from a bank that is idle in this step
                 cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? (padb.empty() ? l : padb[l][i]) : 0) << off_shift};
+                if (pdf) cell.idx = (uint32_t)(Npos >= 32 ? l : 0) << 2;  // (pdf 0: any finite exp(y) times w = 0)
               }
             }
           }
@@ -168,8 +175,25 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
   out->real_arcs = (int64_t)order.size();
   out->padded_arcs = arc_cells;
   out->rows = nrows;
-  // 6-byte cells, [chunk of 8 cells][3 blocks][lane]{16 bytes}: {w0..w3}, {w4..w7}, {off01, off23, off45, off67}
   const size_t ncell = out->cells.size() / 64;
+  if (pdf) {
+    // 8-byte cells, [chunk of 8 cells][4 blocks][lane]{16 bytes}: {w0..w3}, {w4..w7}, {idx0..idx3}, {idx4..idx7}
+    out->cells6.assign(ncell / 8 * 4 * 64 * 4, 0u);
+    for (size_t c = 0; c < ncell; ++c)
+      for (int l = 0; l < 64; ++l) {
+        const ArcRec &cell = out->cells[c * 64 + l];
+        uint32_t x;
+        memcpy(&x, &cell.w, 4);
+        const size_t chunk = c / 8, i = c % 8;
+        uint32_t *base = &out->cells6[chunk * 4 * 64 * 4];
+        base[((i / 4) * 64 + l) * 4 + (i % 4)] = x;
+        base[((2 + i / 4) * 64 + l) * 4 + (i % 4)] = cell.idx;
+      }
+    out->cells.clear();
+    out->cells.shrink_to_fit();
+    return;
+  }
+  // 6-byte cells, [chunk of 8 cells][3 blocks][lane]{16 bytes}: {w0..w3}, {w4..w7}, {off01, off23, off45, off67}
   out->cells6.assign(ncell / 8 * 3 * 64 * 4, 0u);
   for (size_t c = 0; c < ncell; ++c)
     for (int l = 0; l < 64; ++l) {
@@ -189,24 +213,29 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
 
 // Returns false when the graph cannot use the owner-computes kernel (too many states for the 16-bit
 // offsets or the working set does not fit LDS); the caller then falls back to the general kernel.
-bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row, bool count_only) {
+bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row, bool count_only, bool general) {
   const int H = g->work_H;  // states of the work graph (tc_den_graph::work_*)
   // (the per-state tables in work-state order: a successful build leaves them in position order, and a graph may be built
   // more than once -- den_graph.cpp tries several row cuts)
-  g->tied_fs = g->tied_fs_state;
-  g->tied_w = g->tied_w_state;
+  if (!general) {
+    g->tied_fs = g->tied_fs_state;
+    g->tied_w = g->tied_w_state;
+  }
   const int Npos = 4096 * ((H + 4095) / 4096);
   // beyond 16384 positions: the plane-wise form (chain_internal.h: kJvPlanes), whose rows need not be short either
   const bool planewise = Npos > kMaxIndex;
   if (Npos > kMaxPlanePositions || (planewise && debug_flag(kDbgNoPlanes))) return false;
+  // general graphs (den_general_owner.hip): 8 states per thread, alpha'_t of the owned states in LDS
+  if (general && Npos > 4 * kThreads * kJvSmall) return false;
   const int K = Npos / kThreads;
-  std::vector<int32_t> src, dst;
+  std::vector<int32_t> src, dst, apdf;
   std::vector<float> prob;
   for (int64_t a = 0; a < (int64_t)g->work_src.size(); ++a)
-    if (!special[a]) {
+    if (general || !special[a]) {
       src.push_back(g->work_src[a]);
       dst.push_back(g->work_dst[a]);
       prob.push_back(g->work_prob[a]);
+      if (general) apdf.push_back(g->work_pdf[a]);
     }
   const int64_t A2 = (int64_t)src.size();
   auto sort_by = [&](const std::vector<int32_t> &key, std::vector<int64_t> *first, std::vector<int64_t> *order) {
@@ -262,7 +291,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   // Inside runs of equal (in, out) length the order is free: use it so that every 32 consecutive states --
   // one half-slot, i.e. the 32 lanes that gather exp(y) at f(g) / s(g) and add gamma there in ONE
   // instruction of the per-state passes -- have distinct pdf banks (greedy, first fit).
-  if (!debug_flag(kDbgNoPdfBanks)) {
+  if (!debug_flag(kDbgNoPdfBanks) && !general) {
     auto key = [&](int h) { return lin(h) * 64 + lout(h); };
     int used_f[32], used_s[32];
     size_t run_end = 0;
@@ -639,13 +668,21 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
     }
     out->nfix = (int32_t)out->fix.size();
     if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
-    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise, count_only);
+    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise, count_only, general ? apdf.data() : nullptr);
     if (count_only) continue;
     if (planewise && out->mask_stride > 64) return false;  // (a wave's mask words live in one register: at most 256 chunks)
   }
   if (planewise ? !compute_layout_planes(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), &g->layout)
-                : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), true, &g->layout))
+                : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), !general, &g->layout))
     return false;
+  if (general) {
+    // the walk takes a row's alpha'_t from LDS (one value per row and lane), rows of other lanes would need their owner's
+    if (!g->layout.alpha_in_lds || g->layout.JV != kJvSmall || extra_total[1] != 0) return false;
+    if (count_only) return true;
+    g->pi_pos.assign(Npos + 4, 0.f);
+    for (int h = 0; h < H; ++h) g->pi_pos[g->pos[h]] = g->work_pi[h];
+    return true;
+  }
   if (count_only) return true;
   // per-state tables in position order
   std::vector<uint32_t> fs(Npos + 4, 0u);
