@@ -36,7 +36,7 @@ struct OwnerTask {
 // (8-byte cells: {w, position * 4 | pdf * 4 << 16}), and the placement inside a half-slot weighs both gathers' banks.
 static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std::vector<OwnerTask>>> &slots,
                               const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
-                              ScheduleHost *out, bool planewise, bool count_only, const int32_t *pdf = nullptr) {
+                              ScheduleHost *out, bool planewise, bool count_only, const int32_t *pdf = nullptr, int num_pdfs = 1) {
   // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows.  count_only: the number of cells alone (padded_arcs)
   if (count_only) {
     int64_t cells = 0;
@@ -111,7 +111,9 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
               } else {
                 // padding: w = 0, gathered from a bank that is idle in this step
                 cell = ArcRec{0.f, (uint32_t)(Npos >= 32 ? (padb.empty() ? l : padb[l][i]) : 0) << off_shift};
-                if (pdf) cell.idx = (uint32_t)(Npos >= 32 ? l : 0) << 2;  // (pdf 0: any finite exp(y) times w = 0)
+                // (general cells: w = 0 adds nothing, but the backward walk still issues the cell's gamma atomic -- 64 lanes
+                // on ONE address serialise, and a short stream is half padding: every lane gets a pdf of its own)
+                if (pdf) cell.idx = ((uint32_t)(Npos >= 32 ? l : 0) << 2) | ((uint32_t)((half * 32 + l) % std::max(1, num_pdfs)) << 18);
               }
             }
           }
@@ -124,7 +126,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
       // whole chunks, and (one stream per wave) at least kTiedMinChunks of them: the walks keep a prefix in registers
       while ((out->cells.size() / 64 - first) % kStreamUnrollTied != 0 ||
              (!planewise && out->cells.size() / 64 - first < (size_t)kTiedMinChunks * kStreamUnrollTied))
-        for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, 0u});
+        for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, pdf ? ((uint32_t)l << 2) | ((uint32_t)(l % std::max(1, num_pdfs)) << 18) : 0u});
       row_end.resize((out->cells.size() / 64 - first + 1) / 2, 0);  // the padding cells end no row
       if (debug_flag(kDbgSchedTrace))
         fprintf(stderr, "[sched] wave %d sub %d: %zu cells, %zu rows\n", w, sub, out->cells.size() / 64 - first, k1 - k0);
@@ -668,7 +670,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
     }
     out->nfix = (int32_t)out->fix.size();
     if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
-    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise, count_only, general ? apdf.data() : nullptr);
+    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise, count_only, general ? apdf.data() : nullptr, g->P);
     if (count_only) continue;
     if (planewise && out->mask_stride > 64) return false;  // (a wave's mask words live in one register: at most 256 chunks)
   }
