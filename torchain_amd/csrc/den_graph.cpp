@@ -315,44 +315,11 @@ int build_schedules(tc_den_graph *g) {
     g->layout_ok = true;
     return true;
   };
-  // A graph that is chain-structured only after state splitting has two on-chip options since round 5: the tied kernels on
-  // the split graph (every arc replicated from every copy of its source; 12 or 16 states per thread beyond 8192 positions)
-  // or the general kernel above on the graph as it is (two gathers and a gamma atomic per arc).  Measured at 256 x 150
-  // (profiles/r05_split_vs_general.txt): 3000 states, 60 % entered through 2-3 pdfs: 1.76 vs 1.46 ms; 6000 states, 60 %:
-  // 2.09 vs 1.88; 8000 states, 30 %: 2.08 vs 2.19; and the phone-LM graph R3 (7722 states, 42 of them entered through up
-  // to 42 pdfs, in-degrees in the hundreds): 3.45 vs 4.50 -- popular pdfs serialise the general kernel's atomics.  So the
-  // unsplit graph is preferred when the split costs a layout class or most of a factor of two in states, and only for
-  // graphs without popular states.
-  if (!want_big && g->tied && split_made && g->H <= 4 * kThreads * kJvSmall && !debug_flag(kDbgOldGeneral)) {
-    std::vector<int32_t> indeg(g->H, 0);
-    for (int64_t a = 0; a < g->A; ++a) indeg[g->arc_dst[a]]++;
-    const int max_in = g->H ? *std::max_element(indeg.begin(), indeg.end()) : 0;
-    const bool heavy_split = g->work_H > 4 * kThreads * kJvSmall || 10 * (int64_t)g->work_H >= 18 * (int64_t)g->H;
-    if (heavy_split && max_in <= 2 * kMaxRowLen) {
-      const std::vector<char> special_split = special;
-      const std::vector<int32_t> ws = g->work_src, wd = g->work_dst, wp = g->work_pdf, cf = g->copy_first, tf = g->tied_f, ts = g->tied_s;
-      const std::vector<float> wpr = g->work_prob, wpi = g->work_pi, tw = g->tied_w, tws = g->tied_w_state;
-      const std::vector<uint32_t> tfs = g->tied_fs, tfss = g->tied_fs_state;
-      const int32_t wH = g->work_H;
-      restore_unsplit();
-      if (general_owner()) return TC_OK;
-      g->work_H = wH;
-      g->work_src = ws;
-      g->work_dst = wd;
-      g->work_pdf = wp;
-      g->work_prob = wpr;
-      g->work_pi = wpi;
-      g->copy_first = cf;
-      g->tied_f = tf;
-      g->tied_s = ts;
-      g->tied_w = tw;
-      g->tied_fs = tfs;
-      g->tied_w_state = tws;
-      g->tied_fs_state = tfss;
-      g->tied = true;
-      special = special_split;
-    }
-  }
+  // (A graph that is chain-structured only after state splitting could also run UNSPLIT on the general kernel above.  Measured at
+  // 256 x 150, profiles/r05_split_vs_general.txt: 3000 states with 60 % of them entered through 2-3 pdfs 1.76 (split) vs 1.46 ms,
+  // 6000 states 2.09 vs 1.88, 8000 states with 30 %: 2.08 vs 2.19, the phone-LM graph R3 3.45 vs 4.50 -- popular pdfs serialise the
+  // general kernel's atomics.  Never more than 17 % either way at 256 sequences, while batches of at most 128 run the tied kernels
+  // on two CUs per sequence, which the general kernel has no form of: the split stays the rule.)
   if (!want_big && g->tied) {
     // Rows longer than kMaxRowLen spill into secondary rows, each with a private accumulator slot in LDS; a graph
     // with many popular states (real phone-LM graphs: in-degrees of a hundred and more) and close to the 16384-state
