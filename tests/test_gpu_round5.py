@@ -320,3 +320,53 @@ def test_general_owner_kernel_full_size_and_peaky(oracle, kernel_family):
     assert rel_err(out["deriv"], ref, floor=1.0) <= REL
     elementwise(out["deriv"], ref, "C3 forced general")
     _check(oracle, synth.config_den_fst("C2"), 1, 150, 10.0, 0.1)
+
+
+def test_plane_wise_pairs_with_a_co_tenant():
+    """The plane-wise kernel's two-workgroup form pairs workgroups by ticket and hands rows over through flags in global
+    memory, like den_tied_mitm.hip (tests/test_gpu_round4.py: test_paired_workgroups_with_a_co_tenant).  With large GEMMs of
+    another stream keeping the GPU busy the pairs' workgroups are no longer co-resident by default: no hand-over may fail
+    and the results must equal an undisturbed run's bit for bit."""
+    import torch
+    from test_gpu_round4 import _occupy_half_the_cus
+    fst = synth.random_den_fst(17000, 3, 500, seed=61)
+    S, T = 96, 40
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=62)
+    graph = io.DenominatorGraph(fst, fst.num_pdfs)
+    quiet = hip_den(fst, y, S, leaky=0.1, graph=graph)
+    assert quiet["status"] == 0 and np.isfinite(quiet["logprob"]) and graph.stats()["tied"] == 1
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        busy = _occupy_half_the_cus(side, 40)
+        out = hip_den(fst, y, S, leaky=0.1, graph=graph)
+        side.synchronize()
+        assert out["status"] == 0 and out["logprob"] == quiet["logprob"], rep
+        assert np.array_equal(out["deriv"], quiet["deriv"]), rep
+        del busy
+
+
+def test_plane_wise_graph_through_chain_loss(oracle):
+    """The drop-in call on a graph of the plane-wise class: chain_loss(x (B, C, T), den_graph, supervision) -> loss, results and
+    loss.backward() (one tc_chain_step), with the cross-entropy regulariser, against the oracle (torchain/functions.py:62-138)."""
+    import torch
+    from torchain_amd.functions import chain_loss
+    fst = synth.random_den_fst(18000, 3, 400, seed=71)
+    B, T, P = 3, 11, fst.num_pdfs
+    og = oracle.DenGraph(fst)
+    sup = synth.random_supervision(fst, B, T, 2, seed=72, initial_probs=og.initial_probs())
+    y = synth.random_nnet_output(B, T, P, seed=73)  # rows t * B + b
+    ref = oracle.compute_chain_objf_and_deriv(og, sup, y, 5e-5, 0.1, want_xent=True)
+    den = io.DenominatorGraph(fst, P)
+    assert den.stats()["tied"] == 1 and den.stats()["lds_bytes"] > 100 * 1024
+    x = torch.from_numpy(np.ascontiguousarray(y.reshape(T, B, P).transpose(1, 2, 0))).to("cuda:0").requires_grad_(True)
+    xe = torch.zeros_like(x).requires_grad_(True)
+    loss, results = chain_loss(x, den, io.Supervision.from_synth(sup), l2_regularize=5e-5, leaky_hmm_coefficient=0.1,
+                               xent_regularize=0.1, xent_input=xe, kaldi_way=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = results.data.numpy()
+    assert abs(got[0] - ref["objf"]) <= REL * max(abs(ref["objf"]), 0.05 * B * T) and got[2] == ref["weight"]
+    grad = x.grad.cpu().numpy().transpose(2, 0, 1).reshape(T * B, P)
+    assert rel_err(-grad, ref["deriv"], floor=1.0) <= REL
+    xgrad = xe.grad.cpu().numpy().transpose(2, 0, 1).reshape(T * B, P)
+    assert rel_err(-xgrad, 0.1 * ref["xent_deriv"], floor=0.1) <= REL
