@@ -225,6 +225,8 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   }
   const int Npos = 4096 * ((H + 4095) / 4096);
   // beyond 16384 positions: the plane-wise form (chain_internal.h: kJvPlanes), whose rows need not be short either
+  // (measured on graphs the 12- / 16-states-per-thread kernels hold: the plane-wise form is 40 % slower there -- X1 6.6 vs 4.7 ms,
+  // R2 6.3 vs 4.5, R3 4.9 vs 3.4 --, its per-state values go through L2 where theirs sit in registers)
   const bool planewise = Npos > kMaxIndex;
   if (Npos > kMaxPlanePositions || (planewise && debug_flag(kDbgNoPlanes))) return false;
   // general graphs (den_general_owner.hip): 8 states per thread, alpha'_t of the owned states in LDS
