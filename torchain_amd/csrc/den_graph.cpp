@@ -339,7 +339,6 @@ int build_schedules(tc_den_graph *g) {
           fit_row = max_row;
         }
         if (debug_flag(kDbgSchedTrace)) fprintf(stderr, "[sched] rows cut at %d: %lld cells, %d bytes of LDS\n", max_row, (long long)cells, 4 * g->layout.total_floats);
-        if (getenv("TC_ROWCUT_FIRST")) break;  // (experiments: the first cut that fits, as rounds 2-4 took it)
       }
       if (fit_row && !build_owner(g, special, fit_row)) {
         fit_row = 0;  // (a full build can still fail where the count fitted: more than 256 chunks per wave)

@@ -355,9 +355,8 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   double wave_speed[kWaves];
   {
     static const double by_gen[4] = {1.25, 1.15, 0.95, 0.8};
-    const char *env = getenv("TC_PW_SKEW");  // (experiments: a factor on the deviation from 1)
-    const double k = env ? atof(env) : 1.0;
-    for (int w = 0; w < kWaves; ++w) wave_speed[w] = planewise ? 1.0 + k * (by_gen[w / 4] - 1.0) : 1.0;
+    // (measured with the deviations scaled by 0 / 0.5 / 1 / 1.5: 9.87 / 9.78 / 9.73 / 9.68 ms on R4, profiles/r05/r05_pw_skew.txt)
+    for (int w = 0; w < kWaves; ++w) wave_speed[w] = planewise ? by_gen[w / 4] : 1.0;
   }
   std::vector<Group> by_cost(groups);
   std::stable_sort(by_cost.begin(), by_cost.end(), [](const Group &x, const Group &y) { return x.cin + x.cout > y.cin + y.cout; });
@@ -508,16 +507,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
       H_(0, half_of(g->pos[dst[a]]), bank_of(g->pos[src[a]]))++;
       H_(1, half_of(g->pos[src[a]]), bank_of(g->pos[dst[a]]))++;
     }
-    static const int kPhiMode = getenv("TC_PHI") ? atoi(getenv("TC_PHI")) : 0;
-    static const int kPhiT = getenv("TC_PHIT") ? atoi(getenv("TC_PHIT")) : 8;
-    static const int kPropMul = getenv("TC_PROP") ? atoi(getenv("TC_PROP")) : 200;
-    auto phi = [&](int h) -> int64_t {
-      if (kPhiMode == 0) return (int64_t)h * h;
-      const int e = std::max(0, h - kPhiT);
-      if (kPhiMode == 1) return (int64_t)h * h + 64ll * e * e;
-      if (kPhiMode == 2) return (int64_t)h * h * h;
-      return (int64_t)1 << std::min(h, 40);
-    };
+    auto phi = [](int h) -> int64_t { return (int64_t)h * h; };
     // moving state u from bank b1 to bank b2 changes sum h^2 by the sum over the rows gathering u
     auto move_delta = [&](int u, int b1, int b2) {
       int64_t d = 0;
@@ -544,7 +534,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
       rng ^= rng << 17;
       return rng;
     };
-    const int64_t proposals = (int64_t)Npos * kPropMul;
+    const int64_t proposals = (int64_t)Npos * 200;
     int64_t accepted = 0;
     for (int64_t it = 0; it < proposals; ++it) {
       const uint64_t r = next();
