@@ -302,8 +302,9 @@ int tc_xent_objf(const float *xent_output, int64_t num_rows, int32_t num_cols, i
  * kernel for this graph, out[3]=threads per workgroup, out[4]=forward rows, out[5]=backward rows,
  * out[6], out[7] = forward / backward LDS bank-conflict factor of the placed arc gathers x 1000, where
  * 1000 means conflict-free; out[8] = 1 when the graph is "tied" -- all non-self-loop arcs entering a
- * state carry one pdf -- and runs the factorised kernel, 2 when the graph is too large for the on-chip
- * layout and runs the streamed kernel, 0 for the general on-chip kernel). */
+ * state carry one pdf, possibly after state splitting -- and runs a factorised on-chip kernel (one-stream forms up to
+ * 16384 layout positions, the plane-wise form up to 28672), 2 when the graph is too large for the on-chip layouts and
+ * runs the streamed kernel, 0 for a general on-chip kernel (up to 8192 states: on owner-computes schedules). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
 /* Kernel choice of batches above one sequence per two CUs.  Tied on-chip graphs of up to 8192 positions have two
@@ -361,9 +362,13 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "no_split"       (1: do not tied-ify nearly tied graphs)                     beyond the on-chip layouts)
  *   "no_pdf_banks", "no_bank_search" (1: skip those placement passes)   "sched_trace" (1: builder statistics on stderr)
  *   "slab_wide" / "slab_narrow" (1: the streamed path cuts the batch into slabs of 32 / 16 sequences whatever the graph's size)
+ *   "old_arrange"    (1: the greedy placement of a half-slot's cells that rounds 1-4 used, instead of round 5's matching:
+ *                     DESIGN.md 4.1e)
+ *   "no_planes"      (1: tied graphs of 16385..28672 positions take the streamed path, not the plane-wise on-chip kernel)
+ *   "old_general"    (1: general graphs take round 1's on-chip kernel, not the one on owner-computes schedules)
  * Read at launch (one relaxed atomic load):
  *   "no_phase_split" (1: batches of at most 128 sequences of tied on-chip graphs take the fused kernel instead of
- *                     running forward and backward recursion on two CUs at once)
+ *                     running forward and backward recursion on two CUs at once; the plane-wise kernel likewise)
  *   "no_num_overlap" (1: the numerator always follows the denominator on the caller's stream; by default it runs
  *                     beside it on a side stream when the denominator leaves CUs idle)
  *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
@@ -371,9 +376,6 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
  *   "exp_per_frame"  (1: the streamed path transposes exp(y) one frame at a time, as it does when all frames would take
  *                     more than 1 GB of workspace)
- *   "old_arrange"    (1: the greedy placement of a half-slot's cells that rounds 1-4 used, instead of the matching of
- *                     round 5: DESIGN.md 4.1e)       "no_planes" (1: tied graphs of 16385..28672 positions take the streamed
- *                     path instead of the plane-wise on-chip kernel)
  * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):
  *   "no_pair"        (1: never the two-sequence kernel)        "no_tune" (1: no timing launches; the fused kernel)
  * The same switches can be set from the environment when the library is loaded:
