@@ -265,6 +265,9 @@ __global__ __launch_bounds__(kThreads) void den_general_owner_kernel(const DenPa
     ldsf_st(vocc + 256u * (4 * j + 2), a.z);
     ldsf_st(vocc + 256u * (4 * j + 3), a.w);
   };
+  // (behind a wave's last row the walk looks one row further for the padding cells' factor, which multiplies zeros: the last
+  // wave then reads the four floats behind the rows, which nothing else writes)
+  if (tid < 4) ldsf_st(aOCC + 4u * (uint32_t)Hs + 4u * tid, 0.f);
   f4 ycur[PV];
   {
     const rsrc_t hist_up = hist_row(T - 1);
