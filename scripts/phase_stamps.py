@@ -27,10 +27,10 @@ a256 = lambda x: (x + 255) & ~255
 # the stamp area is the 4 KB "scalar" block of the workspace (api.cpp: carve): the last block for batches
 # beyond 128 sequences of on-chip graphs
 assert S > 128, "batches of at most 128 sequences carry the second history behind the stamp area"
-# api.cpp carve(): history ((T + 2) rows when the two-sequence kernel fits the graph), three double[S], two float[S], 256 B
+# api.cpp carve(): history ((T + 2) rows when the two-sequence kernel fits the graph), four double[S], two float[S], 256 B
 Hs = int(os.environ.get("TC_HS", 8192))
 rows = T + 2 if os.environ.get("TC_PAIR_ROOM", "1") == "1" else T + 1
-off = a256(rows * S * Hs * 4) + 3 * a256(S * 8) + 2 * a256(S * 4) + 256
+off = a256(rows * S * Hs * 4) + 4 * a256(S * 8) + 2 * a256(S * 4) + 256
 names = ["tail", "barrier1", "walk", "barrier2", "pass1+reduce"]
 for _ in range(2):
     rc = lib.tc_den_forward_backward(

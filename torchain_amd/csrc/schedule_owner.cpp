@@ -1,6 +1,7 @@
 // Schedules of the tied on-chip kernel (owner-computes), the tied test and the state splitting that
 // makes nearly tied graphs tied.
 #include <algorithm>
+#include <map>
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -356,14 +357,19 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   {
     static const double by_gen[4] = {1.25, 1.15, 0.95, 0.8};
     // (measured with the deviations scaled by 0 / 0.5 / 1 / 1.5: 9.87 / 9.78 / 9.73 / 9.68 ms on R4, profiles/r05/r05_pw_skew.txt)
-    for (int w = 0; w < kWaves; ++w) wave_speed[w] = planewise ? by_gen[w / 4] : 1.0;
+    // The one-stream kernels do run issue priorities, youngest generation first (den_tied_device.h: age_prio_on), and there the
+    // young waves are the fast ones: forward walks of 21.6 / 17.2 / 15.4 / 14.6 k cycles by generation on R2 with equal shares
+    // (profiles/r05_ablations.txt §4).  Equal finishing times are not the aim -- the early waves' per-state passes run beside the
+    // late waves' walks -- but a share of 0.7 : 1 : 1.15 : 1.2 is worth 2-4 % on graphs with ten or more chunks per wave.
+    static const double by_gen_prio[4] = {0.7, 1.0, 1.15, 1.2};
+    for (int w = 0; w < kWaves; ++w) wave_speed[w] = planewise ? by_gen[w / 4] : general ? 1.0 : by_gen_prio[w / 4];
   }
   std::vector<Group> by_cost(groups);
   std::stable_sort(by_cost.begin(), by_cost.end(), [](const Group &x, const Group &y) { return x.cin + x.cout > y.cin + y.cout; });
   std::vector<std::vector<int>> wave_groups(kWaves);
   std::vector<int64_t> load_in(kWaves, 0), load_out(kWaves, 0);
   for (const Group &gr : by_cost) {
-    // (shares skewed towards the older waves of each SIMD, which the CU serves first, were measured: no
+    // (round 3, before the issue priorities: shares skewed towards the older waves of each SIMD, which the CU serves first, were measured: no
     // gain -- the walk is bound by the shared stream path, not by any one wave)
     int best = -1;
     double best_t = 0;
@@ -385,13 +391,14 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   if (!planewise) {
     auto chunks = [](int64_t steps) { return (std::max<int64_t>(steps, (int64_t)kTiedMinChunks * kStreamUnrollTied) + kStreamUnrollTied - 1) / kStreamUnrollTied; };
     auto cost = [&]() {
-      int64_t mx_in = 0, mx_out = 0, sum = 0;
+      double mx_in = 0, mx_out = 0;
+      int64_t sum = 0;
       for (int w = 0; w < kWaves; ++w) {
-        mx_in = std::max(mx_in, chunks(load_in[w]));
-        mx_out = std::max(mx_out, chunks(load_out[w]));
+        mx_in = std::max(mx_in, (double)chunks(load_in[w]) / wave_speed[w]);
+        mx_out = std::max(mx_out, (double)chunks(load_out[w]) / wave_speed[w]);
         sum += chunks(load_in[w]) + chunks(load_out[w]);
       }
-      return (mx_in + mx_out) * 1000 + sum;
+      return (int64_t)std::llround((mx_in + mx_out) * 1000.0) * 1000 + sum;
     };
     bool improved = true;
     for (int round = 0; round < 50 && improved; ++round) {
@@ -682,6 +689,15 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   std::vector<uint32_t> fs(Npos + 4, 0u);
   std::vector<float> ws(Npos + 4, 0.f);
   g->pi_pos.assign(Npos + 4, 0.f);
+  // Phantom positions (the last plane is rarely full) run the per-state passes like any other: their values are zero, and so
+  // are their gamma adds -- but 64 adds of zero to ONE address (pdf 0) are still 64 turns of the LDS atomic unit.  They get the
+  // pdf of their lane: distinct banks, nothing added anywhere.  (X1: 2384 phantom positions, 4.8 k cycles of every backward
+  // frame: profiles/r05_ablations.txt §4.)
+  if (!debug_flag(kDbgPhantomPdf0))
+    for (int p = 0; p < Npos; ++p) {
+      const uint32_t pdf = (uint32_t)(((p >> 2) % 64) % g->P);
+      fs[p] = (pdf * 4u) | ((pdf * 4u) << 16);
+    }
   for (int h = 0; h < H; ++h) {
     fs[g->pos[h]] = g->tied_fs[h];
     ws[g->pos[h]] = g->tied_w[h];
@@ -689,6 +705,53 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   }
   g->tied_fs.swap(fs);
   g->tied_w.swap(ws);
+  if (debug_flag(kDbgSchedTrace)) {
+    // the per-state passes' exp(y) gathers and gamma adds: one instruction = the 64 states of a (wave, k) group, served a
+    // half at a time in (most loaded bank) cycles -- and an add cannot share an address
+    int64_t gather_f = 0, gather_s = 0, add_f = 0, add_s = 0, halves = 0, same_f = 0, same_s = 0;
+    for (int w = 0; w < kWaves; ++w)
+      for (int k = 0; k < K; ++k)
+        for (int hb = 0; hb < 2; ++hb) {
+          int nf[32] = {0}, ns[32] = {0};
+          std::vector<uint32_t> af[32], as[32];
+          for (int l = hb * 32; l < hb * 32 + 32; ++l) {
+            const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
+            const uint32_t v = g->tied_fs[p], f = (v & 0xffffu) >> 2, s2 = v >> 18;
+            nf[f & 31]++;
+            ns[s2 & 31]++;
+            if (std::find(af[f & 31].begin(), af[f & 31].end(), f) == af[f & 31].end()) af[f & 31].push_back(f);
+            if (std::find(as[s2 & 31].begin(), as[s2 & 31].end(), s2) == as[s2 & 31].end()) as[s2 & 31].push_back(s2);
+          }
+          int mf = 0, ms = 0, gf = 0, gs2 = 0;
+          {
+            std::map<uint32_t, int> cf, cs;
+            for (int l = hb * 32; l < hb * 32 + 32; ++l) {
+              const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
+              const uint32_t v = g->tied_fs[p];
+              cf[(v & 0xffffu) >> 2]++;
+              cs[v >> 18]++;
+            }
+            int a = 0, b2 = 0;
+            for (auto &kv : cf) a = std::max(a, kv.second);
+            for (auto &kv : cs) b2 = std::max(b2, kv.second);
+            same_f += a;
+            same_s += b2;
+          }
+          for (int b = 0; b < 32; ++b) {
+            mf = std::max(mf, nf[b]);
+            ms = std::max(ms, ns[b]);
+            gf = std::max(gf, (int)af[b].size());
+            gs2 = std::max(gs2, (int)as[b].size());
+          }
+          add_f += mf;
+          add_s += ms;
+          gather_f += gf;
+          gather_s += gs2;
+          ++halves;
+        }
+    fprintf(stderr, "[sched] per-state passes, %lld half-slots: gamma adds %lld (forward pdf) + %lld (self-loop pdf) cycles, exp(y) gathers %lld + %lld; most frequent pdf of a half-slot, summed: %lld + %lld\n",
+            (long long)halves, (long long)add_f, (long long)add_s, (long long)gather_f, (long long)gather_s, (long long)same_f, (long long)same_s);
+  }
   return true;
 }
 
