@@ -370,3 +370,24 @@ def test_plane_wise_graph_through_chain_loss(oracle):
     assert rel_err(-grad, ref["deriv"], floor=1.0) <= REL
     xgrad = xe.grad.cpu().numpy().transpose(2, 0, 1).reshape(T * B, P)
     assert rel_err(-xgrad, 0.1 * ref["xent_deriv"], floor=0.1) <= REL
+
+
+# ---- positions a tied layout leaves unused (schedule_owner.cpp: phantom positions carry the pdf of their lane) -----------
+@pytest.mark.parametrize("H,deg,P,S,T", [(9000, 6, 1500, 5, 9), (13000, 5, 2928, 130, 4), (5000, 8, 40, 3, 8), (18000, 4, 2000, 2, 6)])
+def test_unused_positions_add_nothing(oracle, kernel_family, H, deg, P, S, T):
+    """A graph whose last plane of 4096 positions is mostly empty (3288 / 3384 / 3192 / 2480 unused positions; 12, 16 and 8 states
+    per thread and the plane-wise kernel; one batch above 128 sequences for the fused form; 40 pdfs: fewer than lanes) gives the
+    oracle's derivative, and bit for bit the derivative it gave when the unused positions all pointed at pdf 0: they add zero
+    wherever they point -- what changed is that 64 lanes no longer queue on one LDS address."""
+    fst = synth.random_den_fst(H, deg, P, seed=H + 5)
+    y = synth.random_nnet_output(S, T, P, seed=H + 6)
+    out = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0)
+    assert out["graph"].stats()["tied"] == 1 and out["status"] == 0
+    ref_lp, ref = _oracle_den(oracle, fst, y, S, T, 0.1)
+    assert abs(out["logprob"] - ref_lp) <= REL * abs(ref_lp)
+    assert rel_err(out["deriv"], ref, floor=1.0) <= REL
+    elementwise(out["deriv"], ref, "unused positions %d" % H)
+    kernel_family("phantom_pdf0")
+    old = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0)
+    assert old["logprob"] == out["logprob"]
+    assert np.array_equal(old["deriv"], out["deriv"])

@@ -356,7 +356,8 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   double wave_speed[kWaves];
   {
     static const double by_gen[4] = {1.25, 1.15, 0.95, 0.8};
-    // (measured with the deviations scaled by 0 / 0.5 / 1 / 1.5: 9.87 / 9.78 / 9.73 / 9.68 ms on R4, profiles/r05/r05_pw_skew.txt)
+    // (measured with the deviations scaled by 0 / 0.5 / 1 / 1.5: 9.87 / 9.78 / 9.73 / 9.68 ms on R4, profiles/r05/r05_pw_skew.txt; steeper
+    // ladders move R4 by -2 .. +0.5 % without order and a random 28000-state graph not at all: profiles/r05/ab_pw_shares.txt)
     // The one-stream kernels do run issue priorities, youngest generation first (den_tied_device.h: age_prio_on), and there the
     // young waves are the fast ones: forward walks of 21.6 / 17.2 / 15.4 / 14.6 k cycles by generation on R2 with equal shares
     // (profiles/r05_ablations.txt §4).  Equal finishing times are not the aim -- the early waves' per-state passes run beside the
