@@ -360,7 +360,7 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  * a kernel family it would not normally take.  Read when a graph is BUILT (tc_den_graph_create / _read):
  *   "force_general"  (1: never use the tied-graph kernel)      "force_streamed" (1: alpha/beta in HBM, as for graphs
  *   "no_split"       (1: do not tied-ify nearly tied graphs)                     beyond the on-chip layouts)
- *   "no_pdf_banks", "no_bank_search" (1: skip those placement passes)   "phantom_pdf0" (1: unused positions of a tied layout on pdf 0, as before round 5)
+ *   "no_pdf_banks", "no_pdf_search", "no_bank_search" (1: skip those placement passes)   "phantom_pdf0" (1: unused positions of a tied layout on pdf 0, as before round 5)
  *     "sched_trace" (1: builder statistics on stderr)
  *   "slab_wide" / "slab_narrow" (1: the streamed path cuts the batch into slabs of 32 / 16 sequences whatever the graph's size)
  *   "old_arrange"    (1: the greedy placement of a half-slot's cells that rounds 1-4 used, instead of round 5's matching:

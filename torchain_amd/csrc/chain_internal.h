@@ -437,7 +437,7 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -420,7 +420,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {

@@ -325,6 +325,100 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
       used_s[(fs >> 18) & 31]++;
     }
   }
+  // ... then a local search on what the instructions really cost.  A half-slot's gather or add takes as many LDS turns as its
+  // most loaded bank holds states; first fit leaves C3 at 2.04 turns per half-slot and instruction where the banks' totals would
+  // allow 1.3, and the gamma adds alone are 0.1 ms of C3's launch (profiles/r05_ablations.txt §1b).  Two states of different
+  // half-slots trade places when neither has longer rows than the other's group already walks (so no walk gains a step) and
+  // 64 * (sum over half-slots of max f-bank load + max s-bank load) + (sum of squared loads) does not rise; plateau moves are
+  // taken, the squares pull the loads flat so that the maxima can fall later.
+  if (!debug_flag(kDbgNoPdfBanks) && !debug_flag(kDbgNoPdfSearch) && !general && H > 64) {
+    const int nhalf = (H + 31) / 32, ngr = (H + 63) / 64;
+    std::vector<int> mi(ngr, 1), mo(ngr, 1);
+    for (int i = 0; i < H; ++i) {
+      mi[i / 64] = std::max(mi[i / 64], lin(st[i]));
+      mo[i / 64] = std::max(mo[i / 64], lout(st[i]));
+    }
+    struct Half {
+      uint8_t cnt[2][32];
+      uint8_t lvl[2][34];  // number of banks holding c states
+      uint8_t mx[2];
+    };
+    std::vector<Half> hv(nhalf);
+    for (auto &h : hv) {
+      memset(&h, 0, sizeof(h));
+      h.lvl[0][0] = h.lvl[1][0] = 32;
+    }
+    int64_t sum_max = 0, sum_sq = 0;
+    auto adjust = [&](int half, int which, int bank, int delta) {
+      Half &h = hv[half];
+      const int old = h.cnt[which][bank], now = old + delta;
+      h.cnt[which][bank] = (uint8_t)now;
+      h.lvl[which][old]--;
+      h.lvl[which][now]++;
+      sum_sq += (int64_t)now * now - (int64_t)old * old;
+      if (now > h.mx[which]) {
+        sum_max += now - h.mx[which];
+        h.mx[which] = (uint8_t)now;
+      } else if (old == h.mx[which] && h.lvl[which][old] == 0) {
+        sum_max -= 1;
+        h.mx[which] = (uint8_t)now;
+      }
+    };
+    auto fb = [&](int h) { return (int)(((g->tied_fs[h] & 0xffffu) >> 2) & 31u); };
+    auto sb = [&](int h) { return (int)((g->tied_fs[h] >> 18) & 31u); };
+    for (int i = 0; i < H; ++i) {
+      adjust(i / 32, 0, fb(st[i]), 1);
+      adjust(i / 32, 1, sb(st[i]), 1);
+    }
+    const int64_t max_before = sum_max;
+    auto hub = [&](int h) { return deg(in_first, h) > max_row || deg(out_first, h) > max_row; };
+    uint64_t rng = 0xD1B54A32D192ED03ull;
+    auto next = [&]() {
+      rng ^= rng << 13;
+      rng ^= rng >> 7;
+      rng ^= rng << 17;
+      return rng;
+    };
+    const int span = std::min(H, 4096);
+    const int64_t proposals = (int64_t)H * 200;
+    int64_t accepted = 0;
+    for (int64_t it = 0; it < proposals; ++it) {
+      const uint64_t r = next();
+      const int i = (int)(r % (uint64_t)H);
+      const int u = st[i], hi = i / 32;
+      // only a state that sits on a most loaded bank of its half-slot can lower a maximum by leaving
+      if (!((hv[hi].mx[0] > 1 && hv[hi].cnt[0][fb(u)] == hv[hi].mx[0]) || (hv[hi].mx[1] > 1 && hv[hi].cnt[1][sb(u)] == hv[hi].mx[1]))) continue;
+      const int j = i + (int)((r >> 32) % (uint64_t)(2 * span)) - span;
+      if (j < 0 || j >= H || j / 32 == hi) continue;
+      const int v = st[j], hj = j / 32;
+      if (lin(u) > mi[j / 64] || lout(u) > mo[j / 64] || lin(v) > mi[i / 64] || lout(v) > mo[i / 64] || hub(u) || hub(v)) continue;
+      const int64_t before = 64 * sum_max + sum_sq;
+      adjust(hi, 0, fb(u), -1);
+      adjust(hi, 1, sb(u), -1);
+      adjust(hj, 0, fb(v), -1);
+      adjust(hj, 1, sb(v), -1);
+      adjust(hj, 0, fb(u), 1);
+      adjust(hj, 1, sb(u), 1);
+      adjust(hi, 0, fb(v), 1);
+      adjust(hi, 1, sb(v), 1);
+      if (64 * sum_max + sum_sq <= before) {
+        std::swap(st[i], st[j]);
+        ++accepted;
+      } else {
+        adjust(hi, 0, fb(v), -1);
+        adjust(hi, 1, sb(v), -1);
+        adjust(hj, 0, fb(u), -1);
+        adjust(hj, 1, sb(u), -1);
+        adjust(hj, 0, fb(v), 1);
+        adjust(hj, 1, sb(v), 1);
+        adjust(hi, 0, fb(u), 1);
+        adjust(hi, 1, sb(u), 1);
+      }
+    }
+    if (debug_flag(kDbgSchedTrace))
+      fprintf(stderr, "[sched] pdf-bank search: %lld of %lld swaps taken, bank turns of the per-state instructions %lld -> %lld (%d half-slots x 2)\n",
+              (long long)accepted, (long long)proposals, (long long)max_before, (long long)sum_max, nhalf);
+  }
   st.resize(Npos, -1);  // phantom states: no arcs, pi = 0
   struct Group { int idx, cin, cout, pin, pout; };  // (pin / pout: steps of the group's own rows, without its secondary rows)
   std::vector<Group> groups(ngroups);
