@@ -420,3 +420,29 @@ def test_derivative_elementwise_against_float64(kernel_family, cfg, S, T, form):
             assert m.sum() > 1000
             worst = float((np.abs(got[m] - ref[m]) / ref[m]).max())
             assert worst <= tol, (cfg, form, leaky, "entries above %g: worst relative error %.3g > %g" % (floor, worst, tol))
+
+
+@pytest.mark.parametrize("cfg,S,T,flags", [("R4", 2, 40, ()), ("R4", 2, 40, ("no_phase_split",)), ("R4", 2, 40, ("no_planes",)),
+                                           ("C2", 2, 60, ("force_general",)), ("C2", 2, 60, ("force_general", "old_general")),
+                                           ("C2", 2, 60, ("force_streamed",)), ("C5", 2, 60, ()), ("C5", 2, 60, ("no_phase_split",))])
+def test_derivative_elementwise_against_float64_other_kernels(kernel_family, cfg, S, T, flags):
+    """The same reading for the other kernel families: the plane-wise kernel in both forms and the streamed path on the 24000-state
+    graph, the two general on-chip kernels and the streamed path on the metric's graph, three planes of pdfs (C5).  Measured: at most
+    5.9e-5 on entries above 1e-4 and 2.7e-5 on entries above 1e-3 (profiles/r05_gamma_accuracy.txt, last block)."""
+    from oracle import independent_f64 as ind
+    from oracle import pyoracle
+    fst = synth.config_den_fst(cfg)
+    pi = pyoracle.DenGraph(fst).initial_probs()
+    for f in flags:
+        kernel_family(f)
+    for leaky in (0.1, 1e-5):
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=11)
+        lp, gam = ind.den_logprob_and_deriv(fst, pi, np.clip(y, -30, 30), S, leaky)
+        out = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0)
+        assert out["status"] == 0 and abs(out["logprob"] - lp) <= 1e-6 * abs(lp)
+        got, ref = np.asarray(out["deriv"], np.float64), np.asarray(gam, np.float64)
+        for floor, tol in ((1e-4, 1e-4), (1e-3, 5e-5)):
+            m = ref > floor
+            assert m.sum() > 1000
+            worst = float((np.abs(got[m] - ref[m]) / ref[m]).max())
+            assert worst <= tol, (cfg, flags, leaky, "entries above %g: worst relative error %.3g > %g" % (floor, worst, tol))
