@@ -67,11 +67,6 @@ __device__ __forceinline__ void bst4_aux(rsrc_t r, uint32_t voff, f4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
                                          r, (int)voff, 0, AUX);
 }
-template <int AUX>
-__device__ __forceinline__ f4 bld4_aux(rsrc_t r, uint32_t voff) {
-  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, AUX);
-  return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-}
 
 __device__ __forceinline__ f4 mk4(float x) { return f4{x, x, x, x}; }
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
@@ -325,26 +320,12 @@ __device__ __forceinline__ void chunk_pw(const Chunk6 &q, uint32_t m8, float &ac
 // walk last and every frame waits for it: during the walks the four wave generations run at issue
 // priorities 0..3, youngest highest.
 __device__ __forceinline__ void age_prio_on(int wave) {
-#ifndef TC_PRIO_MODE
-#define TC_PRIO_MODE 0
-#endif
-#if TC_PRIO_MODE == 0
   if (wave >= 12)
     __builtin_amdgcn_s_setprio(3);
   else if (wave >= 8)
     __builtin_amdgcn_s_setprio(2);
   else if (wave >= 4)
     __builtin_amdgcn_s_setprio(1);
-#elif TC_PRIO_MODE == 1
-  (void)wave;
-#elif TC_PRIO_MODE == 2
-  if (wave >= 8) __builtin_amdgcn_s_setprio(1);
-#elif TC_PRIO_MODE == 3
-  if (wave >= 12)
-    __builtin_amdgcn_s_setprio(2);
-  else if (wave >= 4)
-    __builtin_amdgcn_s_setprio(1);
-#endif
 }
 
 // fs = forward-pdf*4 | self-loop-pdf*4 << 16 (LDS byte offsets into exp(y)), ws = self-loop probability

@@ -298,17 +298,8 @@ struct TiedSeq {
     f4 yreg[PV];
     if (t < T) {  // y_t under the arc walk
       const rsrc_t yrow = make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes);
-#if defined(TC_LATE_CACHED) && !defined(TC_LATE_STORES_ONLY)
-      // (experiment: the rows the backward pass will not find in the Infinity Cache anyway are read past it)
-      if (t < T - TC_LATE_CACHED) {
 #pragma unroll
-        for (int v = 0; v < PV; ++v) yreg[v] = bld4_aux<2>(yrow, own16 + v * kPlane);
-      } else
-#endif
-      {
-#pragma unroll
-        for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
-      }
+      for (int v = 0; v < PV; ++v) yreg[v] = row_ld(yrow, own16 + v * kPlane, p.y_vec);
     }
     float n_t = 1.f;
     if (GAMMA && t < T) n_t = vload_f32(bn + t);  // for c^_{t+1}
@@ -327,14 +318,7 @@ struct TiedSeq {
 #ifndef TC_ABL_NOHIST
 #pragma unroll
         for (int j = 0; j < JV; ++j)  // alpha'_{t-1} of the owned states: still in the gather buffer
-          if (plane_on(j)) {
-#ifdef TC_LATE_CACHED
-            if (t - 1 >= T - TC_LATE_CACHED)
-              bst4_aux<0>(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
-            else
-#endif
-              bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
-          }
+          if (plane_on(j)) bst4(hist_prev, own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane));
 #endif
       }
     } TC_WALK_PASS);

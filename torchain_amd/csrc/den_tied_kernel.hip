@@ -29,12 +29,6 @@ namespace {
 // (the frames themselves: den_tied_frames.h, shared with den_tied_mitm.hip)
 template <int JV, int PV, bool ALPHA_LDS, bool ACCUM, bool WANT_DERIV, int RESF, int RESB>
 __global__ __launch_bounds__(kThreads) void den_tied_kernel(const DenParams p) {
-#ifdef TC_STAGGER
-  // All workgroups run the same phases in lockstep, so every CU issues its history / derivative stores and its
-  // y / history loads at the same instant: the memory system sees bursts.  A start offset of a fraction of a
-  // frame per workgroup spreads them over the frame period.
-  for (int i = 0; i < (int)(blockIdx.x % TC_STAGGER); ++i) __builtin_amdgcn_s_sleep(TC_STAGGER_SLEEP);
-#endif
   TiedSeq<JV, PV, ALPHA_LDS, ACCUM, RESF, RESB, false> q(p, (int)blockIdx.x, 0);
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
@@ -100,11 +94,7 @@ int launch_den_tied(const DenParams &p, int accumulate, hipStream_t stream) {
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   const int JV = p.L.JV, PV = p.L.PV;
 #define TC_CALL(J, V) launch_jp<J, V>(p, accumulate, lds, stream)
-#ifdef TC_ONLY_C3
-  if (JV == kJvSmall && PV == kPvSmall) return TC_CALL(kJvSmall, kPvSmall);
-#else
   TC_TIED_DISPATCH(TC_CALL)
-#endif
 #undef TC_CALL
   return TC_ERR_UNSUPPORTED;
 }

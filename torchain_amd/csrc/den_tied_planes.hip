@@ -245,11 +245,7 @@ struct PlaneSeq {
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.z, ws.z, F.z, al.z, bt.z, gs, dpart),
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.w, ws.w, F.w, al.w, bt.w, gs, dpart)};
       part += hsum(a);
-#ifdef TC_PW_NT_STORE
-      bst4_aux<2>(hist_t, own16 + pj, a);
-#else
       bst4_aux<0>(hist_t, own16 + pj, a);  // alpha_t: its history row, and where the frame's tail finds it again
-#endif
       {  // the next plane's tables (index clamped: every request of the frame is unconditional)
         const int jn = j + 1 < planes ? j + 1 : j;
         fs_n = bld4u(r_fs, own16, (uint32_t)jn * kPlane);
@@ -365,13 +361,8 @@ struct PlaneSeq {
     ws_n = bld4(r_ws, own16, pj);
     cp_n = bld4(r_pi, own16, pj);
     if (!PURE) {
-#ifdef TC_PW_NT_HIST
-      al_n = bld4_aux<2>(hist_t, own16 + pj);
-      aup_n = bld4_aux<2>(hist_up, own16 + pj);
-#else
       al_n = bld4(hist_t, own16, pj);
       aup_n = bld4(hist_up, own16, pj);
-#endif
     }
     bp_n = bld4(brow, own16, pj);
     request_fix(j);
