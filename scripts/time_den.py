@@ -24,6 +24,10 @@ S, T, P = cfg["S"], cfg["T"], cfg["P"]
 if len(sys.argv) > 2:
     S = int(sys.argv[2])
 fst = synth.config_den_fst(cfgname)
+if os.environ.get("TC_PDF_PERM"):  # the same graph with its pdf ids renumbered at random (this script only)
+    import numpy as np
+    perm = np.random.default_rng(5).permutation(fst.num_pdfs)
+    fst = synth.DenFst(fst.num_states, fst.src, fst.dst, (perm[fst.ilabel - 1] + 1).astype(fst.ilabel.dtype), fst.weight, fst.final, fst.start, fst.num_pdfs)
 dev = torch.device("cuda", 0)
 graph = io.DenominatorGraph(fst, P).prepare(dev)
 print("graph stats", graph.stats())
