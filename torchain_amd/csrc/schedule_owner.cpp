@@ -331,7 +331,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   // half-slots trade places when neither has longer rows than the other's group already walks (so no walk gains a step) and
   // 64 * (sum over half-slots of max f-bank load + max s-bank load) + (sum of squared loads) does not rise; plateau moves are
   // taken, the squares pull the loads flat so that the maxima can fall later.
-  if (!debug_flag(kDbgNoPdfBanks) && !debug_flag(kDbgNoPdfSearch) && !general && H > 64) {
+  if (!debug_flag(kDbgNoPdfBanks) && !debug_flag(kDbgNoPdfSearch) && !general && !count_only && H > 64) {  // (the trades keep every group's longest rows: nothing a count-only pass counts changes)
     const int nhalf = (H + 31) / 32, ngr = (H + 63) / 64;
     std::vector<int> mi(ngr, 1), mo(ngr, 1);
     for (int i = 0; i < H; ++i) {
