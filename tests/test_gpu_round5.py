@@ -394,6 +394,21 @@ def test_unused_positions_add_nothing(oracle, kernel_family, H, deg, P, S, T):
 
 
 # ---- the derivative element-wise against the float64 formulation ---------------------------------
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _float64_truth(cfg, S, T, leaky):
+    """(graph, outputs, float64 log-prob and occupation matrix) of a workload: shared by the kernel forms that are compared with it"""
+    from oracle import independent_f64 as ind
+    from oracle import pyoracle
+    fst = synth.config_den_fst(cfg)
+    pi = pyoracle.DenGraph(fst).initial_probs()
+    y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=11)
+    lp, gam = ind.den_logprob_and_deriv(fst, pi, np.clip(y, -30, 30), S, leaky)
+    return fst, y, lp, np.asarray(gam, np.float64)
+
+
 @pytest.mark.parametrize("form", ["default", "force_mitm", "no_phase_split"])
 @pytest.mark.parametrize("cfg,S,T", [("C2", 2, 150), ("R1", 2, 100), ("R3", 2, 60)])
 def test_derivative_elementwise_against_float64(kernel_family, cfg, S, T, form):
@@ -403,18 +418,13 @@ def test_derivative_elementwise_against_float64(kernel_family, cfg, S, T, form):
     2e-5 (measured, all three forms, both leaky coefficients: at most 5.9e-5 / 1.02e-5, profiles/r05_gamma_accuracy.txt) -- on the
     metric's graph, on a phone-LM-structured graph and on one that reaches the tied kernels through state splitting; two CUs per
     sequence (the default at this batch, in both of its forms) and the fused kernel."""
-    from oracle import independent_f64 as ind
-    from oracle import pyoracle
-    fst = synth.config_den_fst(cfg)
-    pi = pyoracle.DenGraph(fst).initial_probs()
     if form != "default":
         kernel_family(form)
     for leaky in (0.1, 1e-5):
-        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=11)
-        lp, gam = ind.den_logprob_and_deriv(fst, pi, np.clip(y, -30, 30), S, leaky)
+        fst, y, lp, ref = _float64_truth(cfg, S, T, leaky)
         out = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0)
         assert out["status"] == 0 and abs(out["logprob"] - lp) <= 1e-6 * abs(lp)
-        got, ref = np.asarray(out["deriv"], np.float64), np.asarray(gam, np.float64)
+        got = np.asarray(out["deriv"], np.float64)
         for floor, tol in ((1e-4, 1e-4), (1e-3, 2e-5)):
             m = ref > floor
             assert m.sum() > 1000
@@ -429,18 +439,13 @@ def test_derivative_elementwise_against_float64_other_kernels(kernel_family, cfg
     """The same reading for the other kernel families: the plane-wise kernel in both forms and the streamed path on the 24000-state
     graph, the two general on-chip kernels and the streamed path on the metric's graph, three planes of pdfs (C5).  Measured: at most
     5.9e-5 on entries above 1e-4 and 2.7e-5 on entries above 1e-3 (profiles/r05_gamma_accuracy.txt, last block)."""
-    from oracle import independent_f64 as ind
-    from oracle import pyoracle
-    fst = synth.config_den_fst(cfg)
-    pi = pyoracle.DenGraph(fst).initial_probs()
     for f in flags:
         kernel_family(f)
     for leaky in (0.1, 1e-5):
-        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=11)
-        lp, gam = ind.den_logprob_and_deriv(fst, pi, np.clip(y, -30, 30), S, leaky)
+        fst, y, lp, ref = _float64_truth(cfg, S, T, leaky)
         out = hip_den(fst, y, S, leaky=leaky, deriv_weight=1.0)
         assert out["status"] == 0 and abs(out["logprob"] - lp) <= 1e-6 * abs(lp)
-        got, ref = np.asarray(out["deriv"], np.float64), np.asarray(gam, np.float64)
+        got = np.asarray(out["deriv"], np.float64)
         for floor, tol in ((1e-4, 1e-4), (1e-3, 5e-5)):
             m = ref > floor
             assert m.sum() > 1000
