@@ -321,3 +321,39 @@ def test_tuning_cache_is_the_librarys_and_reads_the_python_format(tmp_path, monk
     assert lib.tc_tuning_cache_put(0x1, b"d", 1, 0.1, 0.05) == 0 and json.load(open(path)) == {
         "0000000000000001:d": {"fused_ms": pytest.approx(0.1), "two_sequence_kernel": 1, "two_sequence_ms": pytest.approx(0.05)}}
     assert lib.tc_tuning_cache_put(0x1, None, 1, 0.1, 0.05) < 0 and lib.tc_tuning_cache_put(0x1, b"d", 2, 0.1, 0.05) < 0
+
+
+def test_tuning_cache_survives_odd_device_names_and_damaged_files(tmp_path, monkeypatch):
+    """A device name with quotes, a backslash or a control character still gives a JSON file (those characters are replaced in
+    the key, for reader and writer alike); 1500 randomly damaged files mean "not cached" or the entry, never anything else."""
+    import ctypes as C
+    import json
+    import random
+    path = tmp_path / "tuning.json"
+    monkeypatch.setenv("TORCHAIN_TUNING_CACHE", str(path))
+    got = C.c_int32(0)
+    odd = b'dev "B"\\\n'
+    assert lib.tc_tuning_cache_put(0x1234, b"devA", 1, 0.5, 0.25) == 0 and lib.tc_tuning_cache_put(0x9999, odd, 0, 0.5, 0.75) == 0
+    assert set(json.load(open(path))) == {"0000000000001234:devA", "0000000000009999:dev _B___"}
+    assert lib.tc_tuning_cache_get(0x9999, odd, C.byref(got)) == 1 and got.value == 0
+    good = open(path, "rb").read()
+    rng = random.Random(3)
+    for _ in range(1500):
+        b = bytearray(good)
+        for _ in range(rng.randint(1, 6)):
+            op = rng.random()
+            if op < 0.6:
+                b[rng.randrange(len(b))] = rng.randrange(256)
+            elif op < 0.8:
+                del b[rng.randrange(len(b)):]
+            else:
+                b.insert(rng.randrange(len(b) + 1), rng.randrange(256))
+            if not b:
+                b = bytearray(b"{")
+        open(path, "wb").write(bytes(b))
+        got.value = 7
+        rc = lib.tc_tuning_cache_get(0x1234, b"devA", C.byref(got))
+        assert (rc == 1 and got.value in (0, 1)) or (rc == 0 and got.value == 7)
+    assert lib.tc_tuning_cache_put(0x1234, b"devA", 1, 0.5, 0.25) == 0  # on top of whatever the last damage left
+    assert lib.tc_tuning_cache_get(0x1234, b"devA", C.byref(got)) == 1 and got.value == 1
+    json.load(open(path))

@@ -83,7 +83,11 @@ void make_dirs(const std::string &path) {
 std::string tuning_cache_key(uint64_t graph_hash, const char *device_name) {
   char hex[24];
   snprintf(hex, sizeof hex, "%016llx", (unsigned long long)graph_hash);
-  return std::string(hex) + ":" + (device_name ? device_name : "");
+  std::string key = std::string(hex) + ":" + (device_name ? device_name : "");
+  // (the key is written between quotes as it is: nothing in it may need escaping, for this reader or for a JSON parser)
+  for (char &c : key)
+    if (c == '"' || c == '\\' || (unsigned char)c < 0x20) c = '_';
+  return key;
 }
 
 bool tuning_cache_get(const std::string &key, int *two_sequence_kernel) {
