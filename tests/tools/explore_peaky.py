@@ -1,7 +1,7 @@
 """Development aid (runs on the GPU box): HIP kernels and the fp32 oracle against the float64 formulation on peaky
 outputs; the committed output is profiles/r02_peaky.txt."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import hip_den

@@ -1,9 +1,9 @@
 """One-off extension of tests/test_gpu_fuzz.py: the same case generator with other seeds (development aid; the log
-of a run is kept under profiles/).   python scripts/fuzz_more.py <first seed> <number of seeds> [big]"""
+of a run is kept under profiles/).   python tests/tools/fuzz_more.py <first seed> <number of seeds> [big]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

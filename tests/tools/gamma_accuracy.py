@@ -1,7 +1,7 @@
 """Development aid (runs on the GPU box): element-wise distance of the denominator derivative from the float64 formulation
 (oracle/independent_f64.py), by kernel form and by the role that wrote the frames.  Output kept in profiles/r05_gamma_accuracy.txt."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import hip_den
