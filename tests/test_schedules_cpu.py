@@ -125,3 +125,30 @@ def test_split_graph_that_does_not_fit_goes_back_to_the_general_kernel():
     check_graph(fst, 0)
     stats = io.DenominatorGraph(fst, fst.num_pdfs).stats()
     assert 0 < stats["lds_bytes"] <= 160 * 1024 and stats["fwd_rows"] >= fst.num_states
+
+
+def test_schedules_are_the_same_in_every_process():
+    """Every rank builds its own schedules, and the order of the kernels' float sums -- the last bits of the results -- follows them:
+    the builder's searches run on fixed seeds and ordered containers, so two processes replay a graph bit for bit alike."""
+    import subprocess
+    import sys
+    code = r'''
+import hashlib
+import numpy as np
+from torchain_amd import io, synth
+h = hashlib.sha1()
+for fst in (synth.phone_lm_den_fst(num_pdfs=600, seed=3, num_histories=300, branching=8, unigram_fraction=0.05), synth.random_den_fst(5000, 4, 700, seed=9)):
+    g = io.DenominatorGraph(fst, fst.num_pdfs)
+    rng = np.random.default_rng(1)
+    gather = rng.uniform(0.1, 1.0, fst.num_states).astype(np.float32)
+    pf = rng.uniform(0.5, 2.0, fst.num_pdfs).astype(np.float32)
+    for d in (0, 1):
+        h.update(g.debug_walk(d, gather, pf).tobytes())
+    h.update(repr(sorted(g.stats().items())).encode())
+print(h.hexdigest())
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600) for _ in range(2)]
+    assert all(o.returncode == 0 for o in outs), outs[0].stderr[-2000:]
+    assert len(outs[0].stdout.strip()) == 40 and outs[0].stdout == outs[1].stdout
