@@ -149,8 +149,15 @@ int tc_example_output(const tc_example *example, int32_t j, const char **name, i
  * src/my_lib_example_rand.cpp:35-177).  `scp_path` holds "key path:offset" lines; `len_file` ("" or NULL: scp_path +
  * ".len"; absent: the lengths are read from the examples) holds "key frames_per_sequence" pairs.  Examples of equal
  * length are grouped into minibatches of `batchsize` (the last of a length may be smaller), shuffled inside and across
- * the lengths by a std::mt19937 seeded with `seed` (Fisher-Yates with the draw (engine() * n) >> 32; std::shuffle's
- * own order is unspecified, so no statement of it reproduces the reference's).  New here:
+ * the lengths by a std::mt19937 seeded with `seed`.  tc_rand_reader_new_ordered's `order`:
+ *   TC_RAND_ORDER_SORTED (tc_rand_reader_new): lengths ascending, Fisher-Yates with the draw (engine() * n) >> 32 -- the same on
+ *                  every platform;
+ *   TC_RAND_ORDER_REFERENCE: the reference's statement on its own library calls (src/my_lib_example_rand.cpp:119-141):
+ *                  lengths in the iteration order of a std::unordered_map<size_t, ...> filled in file order, every
+ *                  length's keys copied out and passed to std::shuffle, the batches passed to std::shuffle -- the batch
+ *                  lists of the reference built against the same standard library (libstdc++), seed for seed and epoch
+ *                  for epoch; rank / world sharding applies on top.
+ * New here:
  *   rank / world : every rank forms the same shuffled list and takes batches rank, rank + world, ...; all ranks get
  *                  floor(batches / world) of them per epoch (reference antecedent: example/chime5/parallel_train.py:26-75)
  *   lookahead    : that many worker threads read, parse, merge ([K] MergeChainExamples) and build the supervision
@@ -164,8 +171,12 @@ int tc_example_output(const tc_example *example, int32_t j, const char **name, i
  * tc_rand_reader_batch_keys: the keys of this rank's batch `batch` of the current epoch, space-separated, into buf;
  * returns their number.  Host only. */
 typedef struct tc_rand_reader tc_rand_reader;
+#define TC_RAND_ORDER_SORTED 0
+#define TC_RAND_ORDER_REFERENCE 1
 int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char *len_file, int rank, int world,
                        int lookahead, tc_rand_reader **out);
+int tc_rand_reader_new_ordered(const char *scp_path, int seed, int batchsize, const char *len_file, int rank, int world,
+                               int lookahead, int order, tc_rand_reader **out);
 /* device >= 0: the look-ahead threads also stage every supervision they build for that GPU (tc_supervision_stage). */
 int tc_rand_reader_set_device(tc_rand_reader *reader, int device);
 int tc_rand_reader_reset(tc_rand_reader *reader);
@@ -259,6 +270,12 @@ int tc_chain_objf_and_grad(tc_den_graph *graph, tc_supervision *supervision, con
  *                   in place -- no frame-major copies of the two.  kaldi_way == 0: the reference's second call overwrites
  *                   all the first wrote, so only it is made (on xent_input); the objective here is still that of the
  *                   first call's xent_deriv (the numerator alone on `input`)
+ *   grad == NULL  : an EVALUATION step (xent_grad must be NULL too): [K] ComputeChainObjfAndDeriv with
+ *                   nnet_output_deriv == NULL -- the two forward recursions, results, loss and (when asked for) the
+ *                   cross-entropy objective; no backward recursion of the denominator, hence no alpha-beta check (the
+ *                   NaN / inf guard on objf stays), nothing written but the scalars.  The reference's validation loop
+ *                   (example/chime5/train.py:150-171, under torch.no_grad()) pays for a training step because
+ *                   torchain/functions.py:74,82 fill mmi_grad whatever autograd needs.
  * Workspace: tc_chain_step_workspace_bytes(graph, B, T, three_d, xent branch).  No host synchronisation. */
 int64_t tc_chain_step_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence,
                                       int three_d, int with_xent);
@@ -385,7 +402,10 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
 int tc_debug_set(const char *key, int value);
 /* Diagnostic counters: "pool_device_allocs" = device allocations made so far by the per-device supervision pool
  * (stops growing once the pool is warm: a training step then allocates and frees nothing), "pool_reuses" = slots
- * handed out again.  -1 for an unknown key. */
+ * handed out again; "den_launches" / "den_backward_launches" / "num_launches" / "num_backward_launches" /
+ * "layout_launches" = denominator computations enqueued / those with a backward recursion / numerator computations /
+ * those with a backward recursion / (B, C, T) <-> (T*B, C) copies, process-wide since the library was loaded.
+ * -1 for an unknown key. */
 int64_t tc_debug_counter(const char *key);
 
 int tc_den_graph_debug_walk(const tc_den_graph *graph, int direction, const float *gather,

@@ -281,6 +281,48 @@ def test_native_rand_reader_handle_shards_by_rank_and_looks_ahead(tmp_path):
         io.RandExample(scp, seed=9, batchsize=2, rank=2, world=2)
 
 
+def test_reference_batch_order(tmp_path):
+    """``io.RandExample(order="reference")``: the batch key lists of three seeds, two epochs each, equal those of a standalone
+    restatement of ``/root/reference/src/my_lib_example_rand.cpp:119-141`` on the standard library (tests/tools/
+    reference_batch_order.cpp, compiled here with g++): ``std::unordered_map<size_t, ...>`` iteration over lengths,
+    ``std::shuffle`` with ``std::mt19937`` inside and across them.  Index work: exact.  Rank / world sharding applies on top."""
+    import subprocess
+    exe = str(tmp_path / "reference_batch_order")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(HERE, "tools", "reference_batch_order.cpp")])
+    fst = synth.random_den_fst(40, 4, 24, seed=1)
+    # (16 distinct lengths: the reference's hash table grows past its first bucket counts while it is filled)
+    lengths = [5] * 9 + [8] * 6 + [11] * 2 + [37] * 5 + [3] * 4 + [29] * 3 + [64] + [20] * 7 + [4, 6, 7, 9, 10, 12, 13, 14, 15]
+    keyed, ark, scp = _write_set(tmp_path, fst, lengths)
+    # a length file in an order of its own (the reference fills its map in FILE order; io.print_key_length writes scp order)
+    rng = np.random.default_rng(0)
+    pairs = [(k, L) for (k, _), L in zip(keyed, lengths)]
+    pairs = [pairs[i] for i in rng.permutation(len(pairs))]
+    with open(scp + ".len", "w") as f:
+        f.write("".join("%s %d\n" % kv for kv in pairs))
+    for seed, batchsize in ((1, 3), (12345, 2), (-7, 4)):
+        want = {}
+        for line in subprocess.check_output([exe, scp + ".len", str(seed), str(batchsize), "2"], text=True).splitlines():
+            epoch, _, keys = line.partition(":")
+            want.setdefault(int(epoch), []).append(keys.split())
+        rd = io.RandExample(scp, seed=seed, batchsize=batchsize, prefetch=False, order="reference")
+        parts = [io.RandExample(scp, seed=seed, batchsize=batchsize, prefetch=False, order="reference", rank=r, world=2) for r in range(2)]
+        for epoch in range(2):
+            got = [rd.batch_keys(i) for i in range(rd.n_batch)]
+            assert got == want[epoch], (seed, epoch)
+            for r, p in enumerate(parts):
+                assert [p.batch_keys(i) for i in range(p.n_batch)] == want[epoch][r:2 * (len(want[epoch]) // 2):2]
+                p.reset()
+            rd.reset()
+        assert sorted(k for b in got for k in b) == sorted(k for k, _ in keyed)
+    # the default order is another one: lengths ascending
+    first, ref = io.RandExample(scp, seed=1, batchsize=3, prefetch=False), io.RandExample(scp, seed=1, batchsize=3, prefetch=False, order="reference")
+    assert first.n_batch == ref.n_batch and [first.batch_keys(i) for i in range(first.n_batch)] != [ref.batch_keys(i) for i in range(ref.n_batch)]
+    with pytest.raises(ValueError):
+        io.RandExample(scp, seed=1, batchsize=3, order="kaldi")
+    with pytest.raises(ValueError):
+        io.RandExample(scp, seed=1, batchsize=3, native=False, order="reference")
+
+
 def test_native_merge_equals_the_numpy_statement_and_meets_its_time_bound():
     """``tc_supervision_append`` (the library's host-side AppendSupervision; the reference merges natively,
     src/my_lib_example_rand.cpp:160) against the numpy statement of the same algorithm: identical arrays on random

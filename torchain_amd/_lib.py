@@ -104,6 +104,8 @@ def _load():
     L.tc_supervision_create.argtypes = [C.POINTER(vp), f32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.tc_rand_reader_new.restype = C.c_int
     L.tc_rand_reader_new.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, vp]
+    L.tc_rand_reader_new_ordered.restype = C.c_int
+    L.tc_rand_reader_new_ordered.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     for name in ("tc_rand_reader_reset", "tc_rand_reader_num_batch", "tc_rand_reader_num_data", "tc_rand_reader_next"):
         getattr(L, name).restype = C.c_int
         getattr(L, name).argtypes = [vp]

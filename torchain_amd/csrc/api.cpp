@@ -28,7 +28,7 @@ struct Workspace {
   float *pair_norm = nullptr;                      // two-sequence form (den_tied_pair.hip)
   uint32_t *pair_sync = nullptr;
   long long *pair_stamps = nullptr;                // ... its diagnostic builds (-DTC_PAIR_STAMPS): raw cycle stamps
-  float *alpha_hist;
+  float *alpha_hist, *asum_g;
   double *den_lp, *num_lp, *y2, *xent_lp;
   float *ab, *gs;
   int32_t *fail;
@@ -67,6 +67,7 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   };
   // (pair form: row T + 1 holds the backward role's B_M; plane-wise form: beta'_t of the running backward frame)
   w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair || planes ? 2 : 1)) * S * Hs * sizeof(float));
+  w.asum_g = (float *)take((size_t)S * asum_stride(T) * sizeof(float));  // frame sums of utterances too long for LDS
   w.den_lp = (double *)take((size_t)S * 8);
   w.num_lp = (double *)take((size_t)S * 8);
   w.xent_lp = (double *)take((size_t)S * 8);
@@ -139,7 +140,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
     p->L.Ps = (g->P + 3) & ~3;
     tied = false;  // the on-chip tied kernel's tables are not used; p->big.tied selects the streamed variant
   } else if (g->layout.planewise ? !compute_layout_planes(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), &p->L)
-                                 : !compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L)) {
+                                 : !compute_layout(nstates, g->P, T, std::max(g->fwd.extra_slots, g->bwd.extra_slots), tied, &p->L, g->gen_owner)) {
     return TC_ERR_UNSUPPORTED;  // decided at graph build with T = 256; a much longer T may not fit LDS
   }
   p->big = d.big;
@@ -171,6 +172,7 @@ int fill_den_params(tc_den_graph *g, int device, int32_t S, const float *y, int6
   p->deriv = deriv;
   p->deriv_stride = deriv_stride;
   p->alpha_hist = w.alpha_hist;
+  p->asum_g = w.asum_g;
   p->seq_logprob = w.den_lp;
   p->seq_y2 = w.y2;
   p->seq_ab = w.ab;
@@ -458,7 +460,7 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   if (rc != TC_OK) return rc;
   np.deriv_scale = deriv_scale;
   np.xent_scale = xent_scale;
-  if (xent && xent_out && xent_objf_dev) {
+  if (xent_out && xent_objf_dev) {  // (also without the dense xent matrix: an evaluation step's cross-entropy objective)
     np.xent_out = xent_out;
     np.xent_out_stride = xent_out_stride;
     np.xent_out_bct = xent_out_bct;
@@ -494,7 +496,8 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
   // adds its sparse posteriors.  [K] runs the numerator first; the sum is the same.
   // When the denominator leaves CUs idle (small batches) the numerator's recursion runs beside it on a side
   // stream, leaving its posteriors in the supervision's staging area; the scatter follows the denominator.
-  if ((deriv || xent) && (bct_input || den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus) && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
+  // (a forward-only call overlaps the two forward recursions the same way; its numerator writes nothing but its sums)
+  if ((bct_input || den_cus_used(dp, ss->num_cus) + 16 <= ss->num_cus) && np.t.stage && !debug_flag(kDbgNoNumOverlap)) {
     std::lock_guard<std::recursive_mutex> lock(ss->enqueue);
     np.staged = 1;
     TC_HIP_CHECK(hipEventRecord(ss->num_fork, stream));
@@ -592,9 +595,15 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
                   int64_t row_stride, float l2_regularize, float leaky, float xent_regularize, int kaldi_way,
                   float *grad, float *xent_grad, float *results_dev3, float *loss_dev1, double *xent_objf_dev,
                   void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
-  if (!g || !sup || !input || !grad || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
+  if (!g || !sup || !input || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
   const bool use_xent = xent_input != nullptr && xent_regularize != 0.0f;
-  if (use_xent && !xent_grad) return TC_ERR_INVALID_ARGUMENT;
+  // grad == NULL: an evaluation step ([K] ComputeChainObjfAndDeriv with nnet_output_deriv == NULL, as Kaldi's own
+  // diagnostics call it): the two forward recursions, the results and the loss; no Backward(), so no alpha-beta
+  // check, no gradient written, no copy back.  (The reference's validation loop pays for a whole training step under
+  // torch.no_grad(): example/chime5/train.py:150-171 -> torchain/functions.py:74,82 allocate and fill mmi_grad anyway.)
+  const bool eval_only = grad == nullptr;
+  if (eval_only && xent_grad) return TC_ERR_INVALID_ARGUMENT;
+  if (!eval_only && use_xent && !xent_grad) return TC_ERR_INVALID_ARGUMENT;
   const int S = sup->S, T = sup->T, P = sup->P;
   if (P != g->P) return TC_ERR_INVALID_ARGUMENT;
   const int64_t rows = (int64_t)S * T;
@@ -618,10 +627,10 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
   const int bct = three_d && use_xent ? 1 : 0;
   if (three_d) {
     y = second_only ? w.x2d : w.y2d;  // (filled inside chain_objf, beside the numerator: bct_input)
-    gr = w.g2d;
-    xg = use_xent ? xent_grad : nullptr;
+    gr = eval_only ? nullptr : w.g2d;
+    xg = use_xent && !eval_only ? xent_grad : nullptr;
     stride = P;
-    if (use_xent) {
+    if (use_xent && !eval_only) {
       DeviceGuard guard(device);
       if (!guard.ok) return TC_ERR_HIP;
       TC_HIP_CHECK(hipMemsetAsync(xent_grad, 0, (size_t)rows * P * sizeof(float), stream));
@@ -658,7 +667,7 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
                   use_xent ? xent_objf_dev : nullptr, bct, bct, three_d ? (second_only ? xent_input : input) : nullptr,
                   second_only && xent_objf_dev != nullptr, loss_dev1);
   if (rc != TC_OK) return rc;
-  if (three_d) {
+  if (three_d && !eval_only) {
     rc = tc_from2d(gr, P, S, P, T, -1.0f, grad, device, stream_v);
     if (rc != TC_OK) return rc;
   }

@@ -172,6 +172,9 @@ struct DenLayout {
   int JV, PV;           // template instantiation: float4s of states / pdfs owned per thread
   int acc_floats;       // size of the accumulator region: Hs + 4 + extra slots, rounded to 4
   bool planewise = false;  // den_tied_planes.hip: [P | A | 4 rows per wave + 4 + extra slots | GAMMA | red | asum]
+  // the frame sums asum_0..T live in the workspace (DenParams::asum_g), not behind off_asum: utterances too long for the
+  // LDS the graph leaves (plane-wise kernel, general owner-computes kernel: the kernels they replaced ran any T)
+  bool asum_global = false;
 };
 
 struct DenParams {
@@ -182,6 +185,7 @@ struct DenParams {
   float *deriv;
   int64_t deriv_stride;
   float *alpha_hist;    // [(T+1)][S][Hs]
+  float *asum_g = nullptr;  // [S][asum_stride(T)]: the frame sums when the layout says asum_global
   double *seq_logprob;  // [S]
   double *seq_y2;       // [S] sum of y^2 (for the l2 term)
   float *seq_ab;        // [S] sum_h alpha'_0 beta'_0
@@ -363,7 +367,10 @@ int arrange_half_matching(const std::vector<std::vector<int64_t>> &lane_arcs, in
                           std::vector<std::vector<int>> *pos_out, std::vector<std::vector<int>> *pad_bank,
                           int *lower_bound);                                           // den_layout.cpp
 inline int round4(int x) { return (x + 3) & ~3; }
-bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L);
+// need_alpha (the general owner-computes kernel): only layouts with alpha' in LDS; when the frame sums of T_hint frames
+// do not fit behind one, they go to the workspace (asum_global) instead of alpha' going to the history
+bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L, bool need_alpha = false);
+constexpr int asum_stride(int T) { return (T + 2 + 3) & ~3; }
 bool compute_layout_planes(int Npos, int P, int T_hint, int extra_slots, DenLayout *L);
 int64_t layout_lds_bytes(const DenLayout &L, int T);
 
@@ -443,6 +450,10 @@ bool debug_flag(DebugFlag f);
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp
 void pool_release(int device, PoolSlot *slot);
 int64_t pool_counter(int which);  // 0: device allocations made by the pool, 1: slots reused
+// launches enqueued so far, by kind (tc_debug_counter): the evaluation-step tests read them to see that a forward-only
+// call enqueued no backward recursion
+enum LaunchCounter { kCntDen = 0, kCntDenBackward, kCntNum, kCntNumBackward, kCntLayout, kCntCount };
+void count_launch(LaunchCounter c);
 int supervision_mark_use(tc_supervision *sup, int device, hipStream_t stream);
 #define TC_HIP_CHECK(expr)                        \
   do {                                            \

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(kThreads) void den_general_owner_kernel(const DenPa
   const int planes = Hs / (4 * kThreads), K = Hs / kThreads;
   const uint32_t own16 = 16u * tid, lane16 = 16u * lane;
   const uint32_t aACC = 4u * (uint32_t)p.L.off_acc, aGM = 4u * (uint32_t)p.L.off_g, aOCC = 4u * (uint32_t)p.L.off_al;
-  const uint32_t aRed = 4u * (uint32_t)p.L.off_red, aAsum = 4u * (uint32_t)p.L.off_asum;
+  const uint32_t aRed = 4u * (uint32_t)p.L.off_red;
+  const AsumRow asums(p, s);
   const uint32_t vrow = aACC + 256u * (uint32_t)(K * wave) + 4u * lane, vocc = aOCC + 256u * (uint32_t)(K * wave) + 4u * lane;
   const uint32_t row_bytes = 4u * (uint32_t)p.P;
   const rsrc_t r_pi = make_rsrc(p.pi, 4u * (uint32_t)(Hs + 4));
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void den_general_owner_kernel(const DenPa
         lds4_st(kA0 + own16 + j * kPlane, a);
         bst4(h0, own16 + j * kPlane, a);
       }
-    if (tid == 0) ldsf_st(aAsum, asum0);
+    if (tid == 0) asums.st(0, asum0);
     part = asum0;
   }
   float asum = part, inv_prev = __builtin_amdgcn_rcpf(asum), y2 = 0.f, part_tot = 0.f;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void den_general_owner_kernel(const DenPa
           }
         }
       }
-      if (tid == 0) ldsf_st(aAsum + 4u * t, asum);
+      if (tid == 0) asums.st(t, asum);
       inv_prev = __builtin_amdgcn_rcpf(asum);
     }
   }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void den_general_owner_kernel(const DenPa
     const double y2d = (double)block_sum_a(y2, aRed + 8u * kWaves, wave, lane);
     if (tid == 0) {
       double logsum = 0.0;
-      for (int t = 0; t < T; ++t) logsum += (double)__logf(ldsf(aAsum + 4u * t));
+      for (int t = 0; t < T; ++t) logsum += (double)__logf(asums.ld(t));
       p.seq_logprob[s] = logsum + (double)__logf(tot) + (y2d - y2d);  // (+ 0, or NaN for a NaN / inf input)
       p.seq_y2[s] = y2d;
     }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void den_general_owner_kernel(const DenPa
     Chunk8 q0;
     load_chunk8(q0, bbase, lane16, RES);
     __syncthreads();  // beta_{t+1}, exp(y_t), alpha'_t rows ready; gamma zero
-    const float inv_as = __builtin_amdgcn_rcpf(ldsf(aAsum + 4u * t));
+    const float inv_as = __builtin_amdgcn_rcpf(asums.ld(t));
     f4 ynext[PV], areg[JV];
     {
       // frame t-1's y row and alpha' of the owned states under the arc walk; at t == 0 frame 0 again

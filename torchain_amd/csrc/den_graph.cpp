@@ -95,6 +95,8 @@ int side_streams(hipStream_t stream, SideStreams **out) {
 
 static std::atomic<int> g_debug[kDbgCount];
 bool debug_flag(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed) != 0; }
+static std::atomic<int64_t> g_launches[kCntCount];
+void count_launch(LaunchCounter c) { g_launches[c].fetch_add(1, std::memory_order_relaxed); }
 
 // ---- lists of the streamed path (chain_internal.h: SlabListHost) -------------------------------------------
 struct SlabEntry {
@@ -459,6 +461,9 @@ const bool g_env_applied = [] {
 int64_t tc_debug_counter(const char *key) {
   if (key && !strcmp(key, "pool_device_allocs")) return pool_counter(0);
   if (key && !strcmp(key, "pool_reuses")) return pool_counter(1);
+  static const char *const names[kCntCount] = {"den_launches", "den_backward_launches", "num_launches", "num_backward_launches", "layout_launches"};
+  for (int i = 0; key && i < kCntCount; ++i)
+    if (!strcmp(key, names[i])) return g_launches[i].load(std::memory_order_relaxed);
   return -1;
 }
 

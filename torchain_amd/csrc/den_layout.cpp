@@ -16,7 +16,7 @@ namespace tc {
 
 
 // Lays the per-frame working set of one sequence out in LDS.  Returns false if it cannot fit.
-bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L) {
+bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLayout *L, bool need_alpha) {
   L->Hs = round4(H);
   L->Ps = round4(P);
   const int jv = (L->Hs / 4 + kThreads - 1) / kThreads, pv = (L->Ps / 4 + kThreads - 1) / kThreads;
@@ -48,7 +48,9 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
   } else {
     return false;
   }
-  for (int with_alpha = 1; with_alpha >= 0; --with_alpha) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int with_alpha = need_alpha ? 1 : 1 - attempt;
+    const bool asum_global = need_alpha && attempt == 1;
     int off = L->PV * 4 * kThreads;  // P region, compile-time size
     L->off_a = off;
     off += L->Hs;  // A / B
@@ -67,10 +69,11 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
     L->off_red = off;
     off += 4 * kWaves;
     L->off_asum = off;
-    off += round4(T_hint + 1);
+    off += asum_global ? 4 : round4(T_hint + 1);
     L->total_floats = off;
     L->alpha_in_lds = with_alpha != 0;
     L->planewise = false;
+    L->asum_global = asum_global;
     if ((int64_t)off * 4 <= kLdsLimitBytes) return true;
   }
   return false;
@@ -99,14 +102,15 @@ bool compute_layout_planes(int Npos, int P, int T_hint, int extra_slots, DenLayo
   L->off_al = L->off_p2 = L->off_red = off;
   off += 4 * kWaves;
   L->off_asum = off;
-  off += round4(T_hint + 1);
+  L->asum_global = (int64_t)(off + round4(T_hint + 1)) * 4 > kLdsLimitBytes;  // (a long utterance: the sums go to the workspace)
+  off += L->asum_global ? 4 : round4(T_hint + 1);
   L->total_floats = off;
   L->alpha_in_lds = false;
   return (int64_t)off * 4 <= kLdsLimitBytes;
 }
 
 int64_t layout_lds_bytes(const DenLayout &L, int T) {
-  return 4 * (int64_t)(L.off_asum + round4(T + 1));
+  return 4 * (int64_t)(L.off_asum + (L.asum_global ? 4 : round4(T + 1)));
 }
 
 // Bank-conflict-aware placement for one 32-lane half of a slot.  ds_read_b32 / ds_add_u32 service a

@@ -357,6 +357,26 @@ __device__ __forceinline__ void fold_row_pw(int2 f, uint32_t vrow, uint32_t aACC
 
 constexpr uint32_t kPlane = 16u * kThreads;  // bytes between a thread's float4s of consecutive planes
 
+// The frame sums asum_0..T of one sequence: behind the layout's off_asum in LDS, or -- an utterance too long for the LDS the
+// graph leaves (DenLayout::asum_global) -- in the workspace.  Written by thread 0 in the forward phase, read by every
+// thread of the SAME workgroup in the backward phase (a vector load: one address, one request).
+struct AsumRow {
+  uint32_t lds;
+  float *g;  // null: LDS
+  __device__ __forceinline__ AsumRow(const DenParams &p, int s)
+      : lds(4u * (uint32_t)p.L.off_asum), g(p.L.asum_global ? p.asum_g + (int64_t)s * asum_stride(p.T) : nullptr) {}
+  __device__ __forceinline__ void st(int t, float v) const {
+    if (g)
+      g[t] = v;
+    else
+      ldsf_st(lds + 4u * (uint32_t)t, v);
+  }
+  __device__ __forceinline__ float ld(int t) const {
+    if (g) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(g + t, 4u), 0, 0, 0));
+    return ldsf(lds + 4u * (uint32_t)t);
+  }
+};
+
 }  // namespace
 
 // every <JV, PV> instantiation of the tied kernels: CALL(JV, PV) for the layout's pair (den_layout.cpp)

@@ -35,11 +35,11 @@ namespace tc {
 
 namespace {
 
-template <bool ACCUM>
+template <bool ACCUM, int MAXP>
 struct PlaneSeq {
   static constexpr uint32_t kPB = 0u;             // exp(y_t)
   static constexpr uint32_t kA0 = 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
-  static constexpr int kMaxPlanes = kJvPlanes;
+  static constexpr int kMaxPlanes = MAXP;          // instantiated for graphs of up to 6 and of 7 planes
 
   const DenParams &p;
   const uint32_t tid, lane;
@@ -47,11 +47,12 @@ struct PlaneSeq {
   const int H, S, T, Hs, Ps, planes;
   const uint32_t own16, lane16;
   const uint32_t aACC, vrow, aGM, aRed, aAsum;
+  const AsumRow asums;
   const uint32_t row_bytes;
   const rsrc_t r_pi, r_fs, r_ws;
   const float leaky;
   const int64_t hist_step;
-  float *const hist;     // alpha history (un-dashed): frame t at hist + t * hist_step; row T + 1: beta'_t of the running frame
+  float *const hist;     // alpha history (un-dashed): frame t at hist + t * hist_step
   // two-workgroup form only (null in the fused kernel)
   float *const fn;       // [T + 2] asum_0..T (role F writes, role B reads)
   float *const bn;       // [T + 1] role B's normalisers
@@ -67,9 +68,16 @@ struct PlaneSeq {
   float asum, inv_prev, bsum, part, part_tot, y2;
   float chat;  // c^_t: the scale the fixed-point adds of the running GAMMA frame use
   f4 bt_n;     // GAMMA frames: B_t of the next plane's owned states
+  // The frame's own per-state values of ALL planes, in registers across the walks (round 6): alpha_t as the passes form it
+  // (forward: the frame's tail adds the leaky term without reading its history row back), beta_{t+1} on entry to a backward
+  // frame / beta'_t behind a plane's pass / beta_t behind the tail.  The plane index is a wave-uniform run-time value: a
+  // plane's float4 goes in and out through selects (rget / rset: ~50 v_cndmask per pass) -- no indexed register file
+  // access, nothing for the compiler to put in scratch.  Round 5 kept beta'_t in one more row of the history buffer:
+  // a written and two read rows per frame and CU, and 32 such rows per XCD took 3 of its L2's 4 MB from the cell stream.
+  f4 R[MAXP];
   // the next plane's tables and history values, requested a plane ahead
   u4 fs_n;
-  f4 ws_n, cp_n, al_n, aup_n, bp_n;
+  f4 ws_n, cp_n, al_n, aup_n;
   int fx0_n, fx1_n;
 #ifdef TC_PHASE_STAMPS
   long long st_prev, st_acc[8];
@@ -80,7 +88,7 @@ struct PlaneSeq {
         T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), own16(16u * threadIdx.x), lane16(16u * (threadIdx.x & 63u)),
         aACC(4u * (uint32_t)pp.L.off_acc),
         vrow(4u * (uint32_t)pp.L.off_acc + 1024u * (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4u * (threadIdx.x & 63u)),
-        aGM(4u * (uint32_t)pp.L.off_g), aRed(4u * (uint32_t)pp.L.off_red), aAsum(4u * (uint32_t)pp.L.off_asum), row_bytes(4u * (uint32_t)pp.P),
+        aGM(4u * (uint32_t)pp.L.off_g), aRed(4u * (uint32_t)pp.L.off_red), aAsum(4u * (uint32_t)pp.L.off_asum), asums(pp, seq), row_bytes(4u * (uint32_t)pp.P),
         r_pi(make_rsrc(pp.pi, 4u * (uint32_t)(pp.L.Hs + 4))), r_fs(make_rsrc(pp.tied_fs, 4u * (uint32_t)(pp.L.Hs + 4))),
         r_ws(make_rsrc(pp.tied_w, 4u * (uint32_t)(pp.L.Hs + 4))), leaky(pp.leaky), hist_step((int64_t)pp.S * pp.L.Hs),
         hist(pp.alpha_hist + (int64_t)seq * pp.L.Hs), fn(pp.fwd_norm ? pp.fwd_norm + (int64_t)seq * (pp.T + 2) : nullptr),
@@ -90,6 +98,31 @@ struct PlaneSeq {
   __device__ __forceinline__ rsrc_t hist_row(int t) const { return make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs); }
   __device__ __forceinline__ rsrc_t bhist_row(int t) const { return make_rsrc(bhist + (int64_t)t * hist_step, 4u * Hs); }
   __device__ __forceinline__ bool own_pdfs() const { return 4 * (int)tid < Ps; }
+  // (opaque to the optimiser: written as C selects, the chains become a switch on the plane index whose cases each carry a
+  // copy of the pass, and the walk's scalar loop control ends up in vector registers)
+  // dst = j == k ? a : dst, j wave-uniform
+  static __device__ __forceinline__ void cmov4(int j, int k, f4 &dst, f4 a) {
+    float x = dst.x, y = dst.y, z = dst.z, w = dst.w;
+    asm volatile("s_cmp_eq_u32 %8, %9\n\ts_cselect_b64 vcc, -1, 0\n\t"
+                 "v_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %5, vcc\n\t"
+                 "v_cndmask_b32_e32 %2, %2, %6, vcc\n\tv_cndmask_b32_e32 %3, %3, %7, vcc"
+                 : "+v"(x), "+v"(y), "+v"(z), "+v"(w)
+                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "s"(j), "n"(k)
+                 : "vcc", "scc");
+    dst = f4{x, y, z, w};
+  }
+  __device__ __forceinline__ f4 rget(int j) const {
+    const int ju = __builtin_amdgcn_readfirstlane(j);
+    f4 v = R[0];
+#pragma unroll
+    for (int k = 1; k < MAXP; ++k) cmov4(ju, k, v, R[k]);
+    return v;
+  }
+  __device__ __forceinline__ void rset(int j, f4 v) {
+    const int ju = __builtin_amdgcn_readfirstlane(j);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) cmov4(ju, k, R[k], v);
+  }
 
   __device__ __forceinline__ void stamps_reset() {
 #ifdef TC_PHASE_STAMPS
@@ -134,6 +167,9 @@ struct PlaneSeq {
   // boundaries, by construction) `pass(plane)` runs.  q0 / q1 arrive requested (chunks 0 and 1: ahead of the frame's barrier).
 #ifndef TC_PW_BUFFERS
 #define TC_PW_BUFFERS 3
+#endif
+#ifndef TC_PW_HIST_AUX
+#define TC_PW_HIST_AUX 0  /* cache policy of the alpha history's stores (0: default, 2: nt) */
 #endif
   static constexpr int kBuffers = TC_PW_BUFFERS;  // chunk buffers: kBuffers - 1 chunks requested ahead
   // (the first requests of a frame, ahead of its barrier)
@@ -198,9 +234,11 @@ struct PlaneSeq {
       lds4_st(kPB + own16, exp4(yv));
     }
     if (tid == 0) {
-      ldsf_st(aAsum, asum);
+      asums.st(0, asum);
       if (fn) fn[0] = asum;
     }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) R[k] = mk4(0.f);
     inv_prev = __builtin_amdgcn_rcpf(asum);
     part_tot = 0.f;
     chat = 0.f;
@@ -245,7 +283,8 @@ struct PlaneSeq {
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.z, ws.z, F.z, al.z, bt.z, gs, dpart),
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.w, ws.w, F.w, al.w, bt.w, gs, dpart)};
       part += hsum(a);
-      bst4_aux<0>(hist_t, own16 + pj, a);  // alpha_t: its history row, and where the frame's tail finds it again
+      bst4_aux<TC_PW_HIST_AUX>(hist_t, own16 + pj, a);  // alpha_t: its history row (the backward pass is its next reader)
+      rset(j, a);                                        // ... and the registers, for the frame's tail
       {  // the next plane's tables (index clamped: every request of the frame is unconditional)
         const int jn = j + 1 < planes ? j + 1 : j;
         fs_n = bld4u(r_fs, own16, (uint32_t)jn * kPlane);
@@ -255,16 +294,13 @@ struct PlaneSeq {
       }
       TC_STAMP(3)
     });
-    // alpha'_t = alpha_t + leaky * pi * asum_t: the values come back from L2 while the block sum forms
+    // alpha'_t = alpha_t + leaky * pi * asum_t: pi comes back from L2 while the block sum forms
     // (requests of planes the graph does not have lie beyond their descriptors and return zeros: every element of the
-    // arrays is assigned unconditionally -- assigned under a condition, the compiler carries such an array through the
+    // array is assigned unconditionally -- assigned under a condition, the compiler carries such an array through the
     // frame as one 28-register value and spills it)
-    f4 av[kMaxPlanes], cp[kMaxPlanes];
+    f4 cp[kMaxPlanes];
 #pragma unroll
-    for (int j = 0; j < kMaxPlanes; ++j) {
-      av[j] = bld4(hist_t, own16, j * kPlane);
-      cp[j] = bld4(r_pi, own16, j * kPlane);
-    }
+    for (int j = 0; j < kMaxPlanes; ++j) cp[j] = bld4(r_pi, own16, j * kPlane);
     f4 yp = mk4(0.f);
     if (GAMMA) {  // y_{t-1} for the derivative row's l2 term (this CU read the row a frame ago: L2)
       yp = row_ld(make_rsrc(p.y + ((int64_t)(t - 1) * S + s) * p.y_stride, row_bytes), own16, p.y_vec);
@@ -277,7 +313,7 @@ struct PlaneSeq {
 #pragma unroll
     for (int j = 0; j < kMaxPlanes; ++j)
       if (j < planes) {
-        const f4 a = av[j] + (leaky * cp[j]) * asum;
+        const f4 a = R[j] + (leaky * cp[j]) * asum;
         lds4_st(kA0 + own16 + j * kPlane, a);
         part_tot += hsum(a);
       }
@@ -301,7 +337,7 @@ struct PlaneSeq {
       lds4_st(kPB + own16, exp4(yreg));
     }
     if (tid == 0) {
-      ldsf_st(aAsum + 4u * t, asum);
+      asums.st(t, asum);
       if (fn) fn[t] = asum;
     }
     inv_prev = __builtin_amdgcn_rcpf(asum);
@@ -315,7 +351,7 @@ struct PlaneSeq {
     if (tid == 0) {
       // [K] log-prob = log(tot) + sum over t < T of log(alpha-sum_t): the scales divided out of frames 1..T
       double logsum = 0.0;
-      for (int t = 0; t < T; ++t) logsum += (double)__logf(ldsf(aAsum + 4u * t));
+      for (int t = 0; t < T; ++t) logsum += (double)__logf(asums.ld(t));
       p.seq_logprob[s] = logsum + (double)__logf(tot) + (y2d - y2d) + bad;  // (+ 0, or NaN for a NaN / inf input)
       p.seq_y2[s] = y2d;
     }
@@ -331,31 +367,30 @@ struct PlaneSeq {
     for (int j = 0; j < planes; ++j) part += hsum(leaky * bld4(r_pi, own16, j * kPlane)) * b_T;
     bsum = block_sum_a(part, aRed + 12u * kWaves, wave, lane);  // also orders the reuse of the gather buffer
     stream_begin(p.bwd);
-    const rsrc_t brow = hist_row(T + 1);
     if (own_pdfs()) {
       lds4_st(kPB + own16, exp4(row_ld(make_rsrc(p.y + ((int64_t)(T - 1) * S + s) * p.y_stride, row_bytes), own16, p.y_vec)));
       lds4_st(aGM + own16, mk4(0.f));
     }
     __syncthreads();  // exp(y_{T-1}) complete: Y_{T-1}(g) = beta_T(g) * p_{T-1}(f(g))
-    for (int j = 0; j < planes; ++j) {
+#pragma unroll
+    for (int j = 0; j < kMaxPlanes; ++j) {
       const int h0 = 4 * ((int)tid + kThreads * j);
-      const f4 bd = f4{h0 < H ? b_T : 0.f, h0 + 1 < H ? b_T : 0.f, h0 + 2 < H ? b_T : 0.f, h0 + 3 < H ? b_T : 0.f};
       const u4 fs = bld4u(r_fs, own16, j * kPlane);
+      // beta_T = beta'_T + its leaky sum on the graph's states, zero on phantom positions and planes the graph does not have
       const f4 b = f4{h0 < H ? b_T + bsum : 0.f, h0 + 1 < H ? b_T + bsum : 0.f, h0 + 2 < H ? b_T + bsum : 0.f, h0 + 3 < H ? b_T + bsum : 0.f};
-      if (PURE)
-        bst4_aux<0>(bhist_row(T), own16 + j * kPlane, b);  // B_T
-      else
-        bst4_aux<0>(brow, own16 + j * kPlane, bd);  // beta'_T
-      lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
-                                           b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
+      R[j] = b;
+      if (j < planes) {
+        if (PURE) bst4_aux<0>(bhist_row(T), own16 + j * kPlane, b);  // B_T
+        lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
+                                             b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
+      }
     }
     stamps_reset();
   }
 
-  // the values of plane j a backward pass needs: tables, alpha_t, alpha_{t+1}, beta'_{t+1}
-  // (PURE: no alpha; `brow` is then the B history's row t + 1)
+  // the values of plane j a backward pass needs from memory: tables, alpha_t, alpha_{t+1}  (PURE: no alpha)
   template <bool PURE>
-  __device__ __forceinline__ void request_bwd(int j, const rsrc_t &hist_t, const rsrc_t &hist_up, const rsrc_t &brow) {
+  __device__ __forceinline__ void request_bwd(int j, const rsrc_t &hist_t, const rsrc_t &hist_up) {
     const uint32_t pj = (uint32_t)j * kPlane;
     fs_n = bld4u(r_fs, own16, pj);
     ws_n = bld4(r_ws, own16, pj);
@@ -364,7 +399,6 @@ struct PlaneSeq {
       al_n = bld4(hist_t, own16, pj);
       aup_n = bld4(hist_up, own16, pj);
     }
-    bp_n = bld4(brow, own16, pj);
     request_fix(j);
   }
 
@@ -374,23 +408,22 @@ struct PlaneSeq {
   __device__ __forceinline__ bool backward_frame(int t) {
     Chunk6 q[kBuffers];
     request_first(q);
-    const rsrc_t hist_t = hist_row(t), hist_up = hist_row(t + 1), brow = hist_row(T + 1);
-    const rsrc_t bsrc = PURE ? bhist_row(t + 1) : brow;  // beta_{t+1}: B_{t+1} itself, or beta'_{t+1} (+ its leaky sum)
-    request_bwd<PURE>(0, hist_t, hist_up, bsrc);
+    const rsrc_t hist_t = hist_row(t), hist_up = hist_row(t + 1);
+    request_bwd<PURE>(0, hist_t, hist_up);
+    float asum_t = 1.f;
+    if (!PURE && asums.g) asum_t = asums.ld(t);  // (from the workspace: requested ahead of the barrier)
     __syncthreads();  // Y, exp(y_t) ready; gamma zero
     TC_STAMP(0)
-    const float asum_t = PURE ? 1.f : ldsf(aAsum + 4u * t);
+    if (!PURE && !asums.g) asum_t = asums.ld(t);
     const float inv_as = __builtin_amdgcn_rcpf(asum_t);
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f, part_u = 0.f;
-    const float bsum_up = PURE ? 0.f : bsum;
     run_stream(q, [&](int j) __attribute__((always_inline)) {
       TC_STAMP(2)
-      const uint32_t pj = (uint32_t)j * kPlane;
       const u4 fs = fs_n;
       const f4 ws = ws_n, cp = leaky * cp_n, aup = PURE ? mk4(0.f) : aup_n;
       const f4 al = PURE ? mk4(0.f) : al_n + cp * asum_t;  // alpha'_t of the owned states (the history keeps alpha_t)
-      const f4 bo = bp_n + bsum_up;                        // beta_{t+1}
+      const f4 bo = rget(j);                               // beta_{t+1} (PURE: B_{t+1})
       const int fx0 = fx0_n, fx1 = fx1_n;
       for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
       f4 a = own_rows(vrow, 0);
@@ -402,10 +435,10 @@ struct PlaneSeq {
       part += hsum(cp * b);
       if (PURE) part_u += hsum(a);
       if (!PURE && t == 0) part_ab += hsum(al * b);
-      bst4_aux<0>(brow, own16 + pj, b);  // (row T + 1: this thread's own entries; beta'_{t+1} of the plane has just been used)
+      rset(j, b);  // (beta_{t+1} of the plane has just been used)
       // the next plane's values, requested behind this plane's arithmetic (both sets at once do not fit the registers) and
       // a whole sub-stream ahead of their use; index clamped: every request of the frame is unconditional
-      request_bwd<PURE>(j + 1 < planes ? j + 1 : j, hist_t, hist_up, bsrc);
+      request_bwd<PURE>(j + 1 < planes ? j + 1 : j, hist_t, hist_up);
       TC_STAMP(3)
     });
     // beta'_t and the forward pdfs again, for the Y update behind the two barriers
@@ -413,13 +446,9 @@ struct PlaneSeq {
     // read it a frame ago: L2) -- requested here rather than held in registers through the walks
     const f4 ynext = row_ld(make_rsrc(p.y + ((int64_t)(t > 0 ? t - 1 : 0) * S + s) * p.y_stride, row_bytes), own16, p.y_vec);
     const f4 ynow = row_ld(make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes), own16, p.y_vec);
-    f4 bv[kMaxPlanes];
     u4 fsT[kMaxPlanes];
 #pragma unroll
-    for (int j = 0; j < kMaxPlanes; ++j) {  // (unconditional: see the forward tail)
-      bv[j] = bld4(brow, own16, j * kPlane);
-      fsT[j] = bld4u(r_fs, own16, j * kPlane);
-    }
+    for (int j = 0; j < kMaxPlanes; ++j) fsT[j] = bld4u(r_fs, own16, j * kPlane);  // (unconditional: see the forward tail)
     float inv_n = 1.f;
     if (PURE) {
       // n_t = sum_h U_t(h) / H; B'_t = U_t / n_t; leaky sum of B'_t
@@ -458,21 +487,23 @@ struct PlaneSeq {
     __syncthreads();
     // beta_t = beta'_t + leaky-sum; next frame's gather source Y_{t-1} = beta_t * p_{t-1}(f)
 #pragma unroll
-    for (int j = 0; j < kMaxPlanes; ++j)
+    for (int j = 0; j < kMaxPlanes; ++j) {
+      const f4 b = PURE ? R[j] * inv_n + bsum : R[j] + bsum;
+      R[j] = b;  // beta_t (B_t) for the next frame's passes
       if (j < planes) {
-        const f4 b = PURE ? bv[j] * inv_n + bsum : bv[j] + bsum;
-        if (PURE) bst4_aux<0>(bhist_row(t), own16 + j * kPlane, b);  // B_t for the partner (and this role's next frame)
+        if (PURE) bst4_aux<0>(bhist_row(t), own16 + j * kPlane, b);  // B_t for the partner
         lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
                                              b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
       }
+    }
     TC_STAMP(4)
     return false;
   }
 };
 
-template <bool ACCUM, bool WANT_DERIV>
+template <bool ACCUM, bool WANT_DERIV, int MAXP>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenParams p) {
-  PlaneSeq<ACCUM> q(p, (int)blockIdx.x);
+  PlaneSeq<ACCUM, MAXP> q(p, (int)blockIdx.x);
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
   q.forward_begin();
@@ -491,9 +522,9 @@ __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenPara
 // Two workgroups per sequence that meet in the middle (batches of at most half the CUs): den_tied_mitm.hip's scheme
 // =========================================================================================================
 // ROLE F: alpha forward over frames 1..M exactly as the fused kernel, the hand-over, then frames M+1..T with gamma_{t-1}
-template <bool ACCUM>
+template <bool ACCUM, int MAXP>
 __device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const MitmParams &mq, int s) {
-  PlaneSeq<ACCUM> q(p, s);
+  PlaneSeq<ACCUM, MAXP> q(p, s);
   const int T = q.T, M = mq.M;
   q.forward_begin();
   for (int t = 1; t <= M; ++t) q.template forward_frame<false>(t);
@@ -513,9 +544,9 @@ __device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const Mi
 }
 
 // ROLE B: frames T-1..M with normalisers of its own and no gamma, the hand-over, then the fused kernel's backward frame
-template <bool ACCUM>
+template <bool ACCUM, int MAXP>
 __device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const MitmParams &mq, int s) {
-  PlaneSeq<ACCUM> q(p, s);
+  PlaneSeq<ACCUM, MAXP> q(p, s);
   const int T = q.T, M = mq.M;
   q.template backward_begin<true>(1.0f);  // B'_T = 1
   for (int t = T - 1; t >= M; --t) q.template backward_frame<true>(t);
@@ -524,37 +555,37 @@ __device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const M
   {
     // asum_0..M from role F; c_M = 1 / sum_g alpha_M(g) B_M(g); from here on beta = c_M B: Kaldi's scale
     for (int i = (int)q.tid; i <= M; i += kThreads) ldsf_st(q.aAsum + 4u * (uint32_t)i, vload_f32(q.fn + i));
-    const rsrc_t aM = q.hist_row(M), bM = q.bhist_row(M), brow = q.hist_row(T + 1);
+    const rsrc_t aM = q.hist_row(M), bM = q.bhist_row(M);
     float d = 0.f;
     for (int j = 0; j < q.planes; ++j) d += hsum(bld4(aM, q.own16, j * kPlane) * bld4(bM, q.own16, j * kPlane));
     d = block_sum_a(d, q.aRed + 4u * kWaves, q.wave, q.lane);  // (its barrier also publishes the frame sums)
     const float c = __builtin_amdgcn_rcpf(d);
-    for (int j = 0; j < q.planes; ++j) {
-      bst4_aux<0>(brow, q.own16 + j * kPlane, bld4(bM, q.own16, j * kPlane) * c);  // beta_M where frame M-1 looks for beta'_M ...
-      lds4_st(q.kA0 + q.own16 + j * kPlane, lds4(q.kA0 + q.own16 + j * kPlane) * c);  // Y_{M-1}
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+      q.R[j] = q.R[j] * c;  // beta_M = c_M B_M, where frame M-1 looks for beta_{t+1}
+      if (j < q.planes) lds4_st(q.kA0 + q.own16 + j * kPlane, lds4(q.kA0 + q.own16 + j * kPlane) * c);  // Y_{M-1}
     }
-    q.bsum = 0.f;  // ... with its leaky sum already in
   }
   for (int t = M - 1; t >= 0; --t)
     if (q.template backward_frame<false>(t)) break;
   if (!partner_ok && q.tid == 0) p.seq_ab[s] = __builtin_nanf("");
 }
 
-template <bool ACCUM>
+template <bool ACCUM, int MAXP>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_mitm_kernel(const DenParams p, const MitmParams q) {
   const uint32_t ticket = take_ticket(q);
   const int s = (int)(ticket >> 1);
   if (s >= p.S) return;
   if ((ticket & 1u) == 0u)
-    planes_mitm_forward<ACCUM>(p, q, s);
+    planes_mitm_forward<ACCUM, MAXP>(p, q, s);
   else
-    planes_mitm_backward<ACCUM>(p, q, s);
+    planes_mitm_backward<ACCUM, MAXP>(p, q, s);
 }
 
 }  // namespace
 
 bool planes_mitm_fits(const DenParams &p) {
-  return p.L.planewise && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
+  return p.L.planewise && !p.L.asum_global && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
          (size_t)layout_lds_bytes(p.L, p.T) + 16u <= (size_t)kLdsLimitBytes;
 }
 
@@ -566,7 +597,11 @@ int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t 
   q.M = p.T / 2;
   q.aScr = (uint32_t)layout_lds_bytes(p.L, p.T);
   TC_HIP_CHECK(hipMemsetAsync(p.mitm_sync, 0, mitm_sync_bytes(p.S), stream));
-  void (*k)(const DenParams, const MitmParams) = accumulate ? den_tied_planes_mitm_kernel<true> : den_tied_planes_mitm_kernel<false>;
+  void (*k)(const DenParams, const MitmParams) = nullptr;
+  if (p.L.JV <= 6)
+    k = accumulate ? den_tied_planes_mitm_kernel<true, 6> : den_tied_planes_mitm_kernel<false, 6>;
+  else
+    k = accumulate ? den_tied_planes_mitm_kernel<true, kJvPlanes> : den_tied_planes_mitm_kernel<false, kJvPlanes>;
   TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds));
   hipLaunchKernelGGL(k, dim3(2 * p.S), dim3(kThreads), lds, stream, p, q);
   TC_HIP_CHECK(hipGetLastError());
@@ -577,10 +612,17 @@ int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t strea
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (!p.L.planewise || lds > (size_t)kLdsLimitBytes || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanes) return TC_ERR_UNSUPPORTED;
   void (*k)(const DenParams) = nullptr;
-  if (!p.deriv)
-    k = den_tied_planes_kernel<false, false>;
-  else
-    k = accumulate ? den_tied_planes_kernel<true, true> : den_tied_planes_kernel<false, true>;
+  if (p.L.JV <= 6) {
+    if (!p.deriv)
+      k = den_tied_planes_kernel<false, false, 6>;
+    else
+      k = accumulate ? den_tied_planes_kernel<true, true, 6> : den_tied_planes_kernel<false, true, 6>;
+  } else {
+    if (!p.deriv)
+      k = den_tied_planes_kernel<false, false, kJvPlanes>;
+    else
+      k = accumulate ? den_tied_planes_kernel<true, true, kJvPlanes> : den_tied_planes_kernel<false, true, kJvPlanes>;
+  }
   TC_HIP_CHECK(allow_dynamic_lds((const void *)k, lds));
   hipLaunchKernelGGL(k, dim3(p.S), dim3(kThreads), lds, stream, p);
   TC_HIP_CHECK(hipGetLastError());

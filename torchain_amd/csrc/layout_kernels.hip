@@ -125,6 +125,7 @@ int launch_trace_mat_mat(const float *a, int64_t a_stride, const float *b, int64
 
 int launch_layout(bool to2d, const float *in, float *out, int B, int Cn, int T, int64_t stride2d, float scale,
                   hipStream_t stream) {
+  count_launch(kCntLayout);
   const dim3 grid((Cn + kTileC - 1) / kTileC, B, (T + kTileTMax - 1) / kTileTMax);
   const size_t lds = sizeof(float) * kTileC * ((size_t)(T < kTileTMax ? T : kTileTMax) | 1);
   // 16-byte path of the 2-D side: rows and base 16-byte aligned, whole float4s of channels in every tile

@@ -212,6 +212,8 @@ int launch_num_scatter(const NumParams &p, hipStream_t stream) {
 }
 
 int launch_num(const NumParams &p, hipStream_t stream) {
+  count_launch(kCntNum);
+  if (p.deriv || p.xent || p.seq_xent) count_launch(kCntNumBackward);
   const size_t lds = (size_t)p.lds_states * 16 + (size_t)p.lds_uniq * 4 + (size_t)p.lds_arcs * 4;
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;
   // with the sequence's tables staged in LDS when that keeps a workgroup within a quarter of a CU's LDS

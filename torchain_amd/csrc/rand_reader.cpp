@@ -26,6 +26,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "torchain_hip.h"
@@ -57,6 +58,10 @@ thread_local std::string g_error;
 struct tc_rand_reader {
   std::vector<Entry> entries;
   std::map<int32_t, std::vector<int32_t>> by_length;  // frames_per_sequence -> entries (ascending lengths, scp order)
+  // order == TC_RAND_ORDER_REFERENCE: the reference's own container, filled in the order it fills its own
+  // (src/my_lib_example_rand.cpp:41,69-110): the lengths come out in libstdc++'s hash-table iteration order
+  std::unordered_map<size_t, std::vector<int32_t>> by_length_ref;
+  int order = TC_RAND_ORDER_SORTED;
   std::mt19937 engine;
   int batchsize = 1, rank = 0, world = 1, lookahead = 0;
   int device = -1;  // >= 0: look-ahead threads stage the supervisions they build for this GPU
@@ -84,13 +89,37 @@ struct tc_rand_reader {
 
   void shuffle_keys() {  // reference: RandReader::shuffle_keys
     std::vector<std::vector<int32_t>> all;
-    for (auto &kv : by_length) {
-      std::vector<int32_t> keys = kv.second;
-      shuffle(keys);
-      for (size_t i = 0; i < keys.size(); i += (size_t)batchsize)
-        all.emplace_back(keys.begin() + (long)i, keys.begin() + (long)std::min(keys.size(), i + (size_t)batchsize));
+    if (order == TC_RAND_ORDER_REFERENCE) {
+      // The reference's statement on the reference's library calls (src/my_lib_example_rand.cpp:119-141): the lengths in the
+      // iteration order of the std::unordered_map, each length's keys COPIED out of the map (`for (auto kv : ...)`: every
+      // epoch starts from the file order again) and passed to std::shuffle, cut into batches, the batches passed to
+      // std::shuffle.  What comes out is the order of the standard library this file is compiled with -- libstdc++ here
+      // and in the reference's build.
+      std::vector<int32_t> batch;
+      batch.reserve((size_t)batchsize);
+      for (auto kv : by_length_ref) {
+        auto &keys = kv.second;
+        std::shuffle(keys.begin(), keys.end(), engine);
+        for (const auto &k : keys) {
+          batch.push_back(k);
+          if (batch.size() == (size_t)batchsize) {
+            all.push_back(batch);
+            batch.clear();
+          }
+        }
+        if (batch.size() > 0) all.push_back(batch);
+        batch.clear();
+      }
+      std::shuffle(all.begin(), all.end(), engine);
+    } else {
+      for (auto &kv : by_length) {
+        std::vector<int32_t> keys = kv.second;
+        shuffle(keys);
+        for (size_t i = 0; i < keys.size(); i += (size_t)batchsize)
+          all.emplace_back(keys.begin() + (long)i, keys.begin() + (long)std::min(keys.size(), i + (size_t)batchsize));
+      }
+      shuffle(all);
     }
-    shuffle(all);
     // this rank's share: the same number of batches on every rank (the last all.size() % world batches of the epoch's
     // list are left out; the list is shuffled anew every epoch)
     batches.clear();
@@ -191,7 +220,13 @@ const char *tc_rand_reader_last_error(void) { return g_error.c_str(); }
 
 int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char *len_file, int rank, int world,
                        int lookahead, tc_rand_reader **out) {
-  if (!scp_path || !out || batchsize <= 0 || world <= 0 || rank < 0 || rank >= world || lookahead < 0 || lookahead > 64)
+  return tc_rand_reader_new_ordered(scp_path, seed, batchsize, len_file, rank, world, lookahead, TC_RAND_ORDER_SORTED, out);
+}
+
+int tc_rand_reader_new_ordered(const char *scp_path, int seed, int batchsize, const char *len_file, int rank, int world,
+                               int lookahead, int order, tc_rand_reader **out) {
+  if (!scp_path || !out || batchsize <= 0 || world <= 0 || rank < 0 || rank >= world || lookahead < 0 || lookahead > 64 ||
+      (order != TC_RAND_ORDER_SORTED && order != TC_RAND_ORDER_REFERENCE))
     return TC_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   g_error.clear();
@@ -202,6 +237,7 @@ int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char
     r->rank = rank;
     r->world = world;
     r->lookahead = lookahead;
+    r->order = order;
     std::ifstream scp(scp_path);
     if (!scp.is_open()) {
       g_error = std::string("cannot open ") + scp_path;
@@ -243,6 +279,7 @@ int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char
         auto it = index.find(key);
         if (it == index.end()) continue;  // (a key the scp does not hold cannot be read)
         r->by_length[(int32_t)length].push_back(it->second);
+        r->by_length_ref[(size_t)length].push_back(it->second);
         ++r->n_data;
       }
     } else {
@@ -258,6 +295,7 @@ int tc_rand_reader_new(const char *scp_path, int seed, int batchsize, const char
           return rc;
         }
         r->by_length[dims[1]].push_back((int32_t)i);
+        r->by_length_ref[(size_t)dims[1]].push_back((int32_t)i);
         ++r->n_data;
       }
     }

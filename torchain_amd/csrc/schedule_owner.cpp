@@ -769,7 +769,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
     if (planewise && out->mask_stride > 64) return false;  // (a wave's mask words live in one register: at most 256 chunks)
   }
   if (planewise ? !compute_layout_planes(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), &g->layout)
-                : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), !general, &g->layout))
+                : !compute_layout(Npos, g->P, 256, std::max(extra_total[0], extra_total[1]), !general, &g->layout, general))
     return false;
   if (general) {
     // the walk takes a row's alpha'_t from LDS (one value per row and lane), rows of other lanes would need their owner's

@@ -298,52 +298,8 @@ class _ChainStep(Function):
     @staticmethod
     def forward(ctx, input, xent_input, results, den_graph, supervision,
                 l2_regularize, leaky_hmm_coefficient, xent_regularize=0.0, kaldi_way=False):
-        device = input.device
-        three_d = input.dim() == 3
-        use_xent = xent_input is not None and xent_regularize != 0.0
-        if isinstance(den_graph, io.DenominatorGraph):
-            den_graph.prepare(device)
-        den_ptr = den_graph.ptr if isinstance(den_graph, io.DenominatorGraph) else den_graph
-        if isinstance(supervision, io.Supervision):
-            sup_ptr, S, T, P = supervision.ptr, supervision.n_batch, supervision.n_frame, supervision.n_pdf
-        else:
-            sup_ptr = supervision
-            S, T, P = (lib.tc_supervision_num_sequence(sup_ptr), lib.tc_supervision_num_frame(sup_ptr),
-                       lib.tc_supervision_num_pdf(sup_ptr))
-        want = (S, P, T) if three_d else (S * T, P)
-        if tuple(input.shape) != want or (use_xent and tuple(xent_input.shape) != want):
-            raise ValueError("nnet output of shape %s does not match the supervision (%s expected)" % (tuple(input.shape), want))
-        x = input.detach()
-        xe = xent_input.detach() if use_xent else None
-        grad = torch.empty_like(x, memory_format=torch.contiguous_format)
-        xgrad = torch.empty_like(xe, memory_format=torch.contiguous_format) if use_xent else None
-        with torch.cuda.device(device):
-            cur = torch.cuda.current_stream(device)
-            key = (S, T, three_d, use_xent)
-            sizes = den_graph.__dict__.setdefault("_step_bytes", {}) if isinstance(den_graph, io.DenominatorGraph) else {}
-            nbytes = sizes.get(key)
-            if nbytes is None:
-                nbytes = lib.tc_chain_step_workspace_bytes(den_ptr, S, T, int(three_d), int(use_xent))
-                if nbytes < 0:
-                    check(int(nbytes), "tc_chain_step_workspace_bytes")
-                sizes[key] = nbytes
-            ws = _workspace(device, cur.cuda_stream, nbytes)
-            out = torch.empty(6, dtype=torch.float32, device=device)  # objf, l2_term, weight | loss | xent objective (f64)
-            rc = lib.tc_chain_step(den_ptr, sup_ptr, _ptr(x), _ptr(xe), int(three_d), 0 if three_d else x.stride(0),
-                                   float(l2_regularize), float(leaky_hmm_coefficient), float(xent_regularize),
-                                   int(bool(kaldi_way)), _ptr(grad), _ptr(xgrad), C.c_void_p(out.data_ptr()),
-                                   C.c_void_p(out.data_ptr() + 12), C.c_void_p(out.data_ptr() + 16) if use_xent else None,
-                                   _ptr(ws), ws.numel(), device.index, C.c_void_p(cur.cuda_stream))
-            check(rc, "tc_chain_step")
-            results._dev = out[:3]
-            results._stale = True
-            results._ready = torch.cuda.Event()
-            results._ready.record(cur)
-            if use_xent:
-                results._xent_dev = out[4:6].view(torch.float64)
-                results._xent_ready = results._ready
-                results._xent_scale = 1.0 / -float(xent_regularize)  # (the library's sum is of the scaled gradient, both layouts)
-                results._xent_host = None
+        out, grad, xgrad = _run_step(input, xent_input, results, den_graph, supervision, l2_regularize,
+                                     leaky_hmm_coefficient, xent_regularize, kaldi_way, want_grad=True)
         ctx.grads = (grad, xgrad)
         if results._defer_host_copy:
             return input.new_zeros(1)
@@ -354,6 +310,59 @@ class _ChainStep(Function):
         return (ctx.grads[0], ctx.grads[1], None, None, None, None, None, None, None)
 
 
+def _run_step(input, xent_input, results, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
+              xent_regularize, kaldi_way, want_grad):
+    """One ``tc_chain_step``.  ``want_grad=False`` is the evaluation step (``grad == NULL``): forward recursions only,
+    no gradient tensors -- [K] ``ComputeChainObjfAndDeriv`` with ``nnet_output_deriv == NULL``."""
+    device = input.device
+    three_d = input.dim() == 3
+    use_xent = xent_input is not None and xent_regularize != 0.0
+    if isinstance(den_graph, io.DenominatorGraph):
+        den_graph.prepare(device)
+    den_ptr = den_graph.ptr if isinstance(den_graph, io.DenominatorGraph) else den_graph
+    if isinstance(supervision, io.Supervision):
+        sup_ptr, S, T, P = supervision.ptr, supervision.n_batch, supervision.n_frame, supervision.n_pdf
+    else:
+        sup_ptr = supervision
+        S, T, P = (lib.tc_supervision_num_sequence(sup_ptr), lib.tc_supervision_num_frame(sup_ptr),
+                   lib.tc_supervision_num_pdf(sup_ptr))
+    want = (S, P, T) if three_d else (S * T, P)
+    if tuple(input.shape) != want or (use_xent and tuple(xent_input.shape) != want):
+        raise ValueError("nnet output of shape %s does not match the supervision (%s expected)" % (tuple(input.shape), want))
+    x = input.detach()
+    xe = xent_input.detach() if use_xent else None
+    grad = torch.empty_like(x, memory_format=torch.contiguous_format) if want_grad else None
+    xgrad = torch.empty_like(xe, memory_format=torch.contiguous_format) if use_xent and want_grad else None
+    with torch.cuda.device(device):
+        cur = torch.cuda.current_stream(device)
+        key = (S, T, three_d, use_xent)
+        sizes = den_graph.__dict__.setdefault("_step_bytes", {}) if isinstance(den_graph, io.DenominatorGraph) else {}
+        nbytes = sizes.get(key)
+        if nbytes is None:
+            nbytes = lib.tc_chain_step_workspace_bytes(den_ptr, S, T, int(three_d), int(use_xent))
+            if nbytes < 0:
+                check(int(nbytes), "tc_chain_step_workspace_bytes")
+            sizes[key] = nbytes
+        ws = _workspace(device, cur.cuda_stream, nbytes)
+        out = torch.empty(6, dtype=torch.float32, device=device)  # objf, l2_term, weight | loss | xent objective (f64)
+        rc = lib.tc_chain_step(den_ptr, sup_ptr, _ptr(x), _ptr(xe), int(three_d), 0 if three_d else x.stride(0),
+                               float(l2_regularize), float(leaky_hmm_coefficient), float(xent_regularize),
+                               int(bool(kaldi_way)), _ptr(grad), _ptr(xgrad), C.c_void_p(out.data_ptr()),
+                               C.c_void_p(out.data_ptr() + 12), C.c_void_p(out.data_ptr() + 16) if use_xent else None,
+                               _ptr(ws), ws.numel(), device.index, C.c_void_p(cur.cuda_stream))
+        check(rc, "tc_chain_step")
+        results._dev = out[:3]
+        results._stale = True
+        results._ready = torch.cuda.Event()
+        results._ready.record(cur)
+        if use_xent:
+            results._xent_dev = out[4:6].view(torch.float64)
+            results._xent_ready = results._ready
+            results._xent_scale = 1.0 / -float(xent_regularize)  # (the library's sum is of the scaled gradient, both layouts)
+            results._xent_host = None
+    return out, grad, xgrad
+
+
 def _one_call(x):
     """Tensors ``tc_chain_step`` takes as they are: CUDA float32, (B, C, T) contiguous or 2-D with unit column stride."""
     if x is None:
@@ -361,6 +370,21 @@ def _one_call(x):
     if not (x.is_cuda and x.dtype == torch.float32):
         return False
     return (x.dim() == 3 and x.is_contiguous()) or (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1])
+
+
+def _needs_grad(input, xent_input):
+    if not torch.is_grad_enabled():
+        return False
+    return input.requires_grad or (xent_input is not None and xent_input.requires_grad)
+
+
+def _as_step_input(x):
+    """A tensor ``tc_chain_step`` takes as it is (evaluation steps only: nothing flows back, so a copy is harmless)."""
+    assert x.is_cuda, "Only CUDA implementation is available"
+    x = x.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x if _one_call(x) else x.contiguous()
 
 
 def to2d(x):
@@ -386,6 +410,13 @@ def _chain_loss_into(results, input, den_graph, supervision, l2_regularize, leak
                      xent_input, kaldi_way):
     """``chain_loss`` with the ``ChainResults`` given (parallel.chain_loss_data_parallel passes one that defers the
     host copy of the three floats until after its all-reduce)."""
+    if not _needs_grad(input, xent_input):
+        # Evaluation (the recipe's validation loop runs under torch.no_grad(), example/chime5/train.py:150-171): the
+        # forward recursions only.  The reference has no such check (functions.py:74,82) and pays for a training step.
+        x, xe = _as_step_input(input), (_as_step_input(xent_input) if xent_input is not None else None)
+        out, _, _ = _run_step(x, xe, results, den_graph, supervision, l2_regularize, leaky_hmm_coefficient,
+                              xent_regularize, kaldi_way, want_grad=False)
+        return (input.new_zeros(1) if results._defer_host_copy else out[3:4].to(input.dtype)), results
     if (_one_call(input) and _one_call(xent_input) and (xent_input is None or xent_input.dim() == input.dim())
             and (xent_input is None or xent_input.dim() == 3 or xent_input.stride(0) == input.stride(0))):
         loss = _ChainStep.apply(input, xent_input, results, den_graph, supervision,

@@ -294,7 +294,8 @@ class RandExample(Example):
     is not specified -- and not the order round 3's Python reader (``native=False``: NumPy's MT19937 shuffle) gives for
     the same ``seed``: the batch order for a given seed changed when the native reader became the default in round 4."""
 
-    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True, rank=0, world=1, native=True, device=None):
+    def __init__(self, scp_path, seed, batchsize, len_file="", prefetch=True, rank=0, world=1, native=True, device=None,
+                 order="sorted"):
         """``rank`` / ``world``: this process's share of a data-parallel job (every rank forms the same shuffled list of
         minibatches from ``seed`` and takes every ``world``-th; all ranks get the same number).  ``native`` (default): the
         whole reader -- bucketing, shuffle, look-ahead threads, merge, supervision handles -- is the library's
@@ -304,7 +305,12 @@ class RandExample(Example):
         ``None``, building the reader touches no GPU -- a script may still fork or re-launch itself -- and the staging starts
         with the first ``next()`` made after the process has initialised CUDA, for the then current device.
         ``native=False`` keeps the Python statement of it below (NumPy's MT19937 shuffle, a thread pool), which needs
-        ``rank == 0, world == 1``."""
+        ``rank == 0, world == 1``.
+        ``order``: ``"sorted"`` (default; lengths ascending, a Fisher-Yates pass that is the same on every platform) or
+        ``"reference"``: the reference's ``shuffle_keys`` restated on the same standard-library calls
+        (``src/my_lib_example_rand.cpp:119-141``: ``std::unordered_map`` iteration, ``std::shuffle`` over ``std::mt19937``) --
+        the batch lists a reference built against libstdc++ forms for the same ``seed``, epoch for epoch (native reader
+        only; ``rank`` / ``world`` sharding applies on top)."""
         assert os.path.exists(scp_path)
         self.scp_path = scp_path
         self.rspec = scp_path
@@ -316,8 +322,10 @@ class RandExample(Example):
             # the training thread's own enqueue slows down -- 0.11 ms beside two readers, 0.39 beside four, 0.47 beside
             # eight on the test box -- and the step with it: profiles/r04_egs_steps.txt)
             depth = (3 if prefetch is True else int(prefetch)) if prefetch else 0
-            rc = lib.tc_rand_reader_new(os.fsencode(scp_path), int(seed), int(batchsize), os.fsencode(len_file or ""),
-                                        int(rank), int(world), depth, C.byref(handle))
+            if order not in ("sorted", "reference"):
+                raise ValueError("order must be 'sorted' or 'reference'")
+            rc = lib.tc_rand_reader_new_ordered(os.fsencode(scp_path), int(seed), int(batchsize), os.fsencode(len_file or ""),
+                                                int(rank), int(world), depth, 1 if order == "reference" else 0, C.byref(handle))
             if rc != 0:
                 raise _egs.EgsFormatError((lib.tc_rand_reader_last_error() or b"").decode() or "tc_rand_reader_new: %d" % rc)
             self._native = handle
@@ -330,8 +338,8 @@ class RandExample(Example):
             if device is not None:
                 self._set_staging_device(int(torch.device("cuda", device).index if not isinstance(device, int) else device))
             return
-        if rank != 0 or world != 1:
-            raise ValueError("the Python reader does not shard: use native=True")
+        if rank != 0 or world != 1 or order != "sorted":
+            raise ValueError("the Python reader does not shard and has one order: use native=True")
         # The next minibatches are prepared on background threads while the current one is in use (reading, parsing,
         # merging and building the supervision handle are library calls that release the interpreter lock): the
         # training thread finds its batch ready instead of re-opening and re-parsing every scp entry synchronously.
