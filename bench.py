@@ -86,6 +86,20 @@ def cpu_baseline(fst, cfg, y_np, nseq):
     return out, ref
 
 
+def load_secondary(config, kern_ms):
+    path = os.path.join(ROOT, "profiles", "secondary_%s.json" % config)
+    if not os.path.exists(path):
+        return None
+    try:
+        sec = json.load(open(path))
+        return {"lds_active_frac": sec["lds_active_ms"] / kern_ms, "valu_issue_frac": sec["valu_issue_ms"] / kern_ms,
+                "lds_conflict_ratio": sec["lds_conflict_ratio"], "lds_active_ms": sec["lds_active_ms"],
+                "valu_issue_ms": sec["valu_issue_ms"], "clock_mhz": sec["clock_mhz"], "kernel": sec.get("kernel"),
+                "source": "profiles/secondary_%s.json: %s" % (config, sec.get("source", ""))}
+    except Exception:
+        return None
+
+
 def extras(graph, fst, cfg, S, T, P, dev):
     """Not part of the metric: the rest of the path around the benchmarked unit, timed after the timed
     region with HIP events -- the full objective (tc_chain_objf_and_deriv: denominator + numerator +
@@ -146,8 +160,19 @@ def extras(graph, fst, cfg, S, T, P, dev):
             torch.autograd.grad(loss, [a, b] if xent else a)
         return timeit(step, n=20, warm=8)
 
+    # the evaluation step: the same call under torch.no_grad() (the recipe's validation loop, example/chime5/train.py:150-171):
+    # forward recursions only, no gradient tensors (tc_chain_step with grad == NULL)
+    def eval_step(xent):
+        b = torch.randn_like(x) if xent else None
+
+        def step():
+            with torch.no_grad():
+                chain_loss(x, graph, hsup, cfg.get("l2", 0.0), cfg["leaky"], 0.1 if xent else 0.0, b, True)
+        return timeit(step, n=20, warm=8)
+
     steps = {"train_step_bct_ms": train_step(False, True), "train_step_bct_xent_kaldi_way_ms": train_step(True, True),
-             "train_step_bct_xent_reference_way_ms": train_step(True, False)}
+             "train_step_bct_xent_reference_way_ms": train_step(True, False),
+             "eval_step_bct_ms": eval_step(False), "eval_step_bct_xent_ms": eval_step(True)}
 
     # A graph of the size a chain recipe's own den.fst has (synth R4: 24000 states, 312000 arcs, in-degrees to 200;
     # example/chime5/train_faster.py:91 hands the recipe's den.fst to src/my_lib_example.cpp:129-134): the plane-wise on-chip
@@ -169,6 +194,10 @@ def extras(graph, fst, cfg, S, T, P, dev):
                 g4.ptr, S4, C.c_void_p(y4.data_ptr()), S4 * T, c4["P"], y4.stride(0), c4["leaky"], -1.0, 0.0, 0,
                 C.c_void_p(d4.data_ptr()), d4.stride(0), None, None, C.c_void_p(ws.data_ptr()), nb, dev.index or 0,
                 C.c_void_p(st)), "den"), n=5, warm=5)
+            if S4 == S:
+                res4["r4_secondary"] = load_secondary("R4", res4["r4_den_batch%d_ms" % S4])
+                bytes4 = 8.0 * S4 * T * c4["P"] + 8.0 * S4 * (T + 1) * (f4.num_states + 1)
+                res4["r4_roofline_frac"] = bytes4 / (res4["r4_den_batch%d_ms" % S4] * 1e-3) / 8.0e12
             del ws
         return res4
 
@@ -261,7 +290,7 @@ def main():
     lp = torch.zeros(1, dtype=torch.float64, device=dev)
     st = torch.zeros(1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
-    # Upload of the graph's tables; tc_den_graph_prepare also times the graph's two kernels once (DESIGN.md 4.1c).  Done
+    # Upload of the graph's tables; tc_den_graph_prepare also times the graph's two kernels once (DESIGN.md 4.3).  Done
     # here, behind the seconds of host-side input generation above, the device goes into the warm-up from the clocks of
     # a running job instead of from idle (the first ~10 launches after idle run 10 - 30 % slow while the clocks ramp).
     # Every rank runs the kernel rank 0 chose (cached from an earlier run, or timed once): the two kernels differ in the last bits.
@@ -381,6 +410,10 @@ def main():
                                % args.config)
             except Exception:
                 traffic = None
+        # secondary ceilings: the LDS and VALU pipes' busy time per launch from the committed SQ counters at
+        # the measured clock, as fractions of THIS run's kernel time -- the context of "x % of the HBM roofline" for a
+        # kernel whose phases use these pipes one after the other
+        secondary = load_secondary(args.config, kern_ms)
         tied = gstats["tied"]
         out = {
             "metric": "sequence-frames/sec through denominator fwd-bwd", "value": value,
@@ -400,7 +433,7 @@ def main():
                          # the per-graph choice between the fused and the two-sequence kernel and the two times it was
                          # made on (zeros: taken from the cache of an earlier run, or the graph has one kernel only)
                          "kernel_choice": tuning,
-                         "kernel_ms": kern_ms, "algorithmic_bytes": bytes_alg},
+                         "kernel_ms": kern_ms, "algorithmic_bytes": bytes_alg, "secondary": secondary},
             "check": {"den_logprob_per_frame": logprob / (S * T), "status": status},
         }
         if exchange is not None:

@@ -381,7 +381,7 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *     "sched_trace" (1: builder statistics on stderr)
  *   "slab_wide" / "slab_narrow" (1: the streamed path cuts the batch into slabs of 32 / 16 sequences whatever the graph's size)
  *   "old_arrange"    (1: the greedy placement of a half-slot's cells that rounds 1-4 used, instead of round 5's matching:
- *                     DESIGN.md 4.1e)
+ *                     HISTORY.md 4.1e)
  *   "no_planes"      (1: tied graphs of 16385..28672 positions take the streamed path, not the plane-wise on-chip kernel)
  *   "old_general"    (1: general graphs take round 1's on-chip kernel, not the one on owner-computes schedules)
  * Read at launch (one relaxed atomic load):
@@ -404,7 +404,10 @@ int tc_debug_set(const char *key, int value);
  * (stops growing once the pool is warm: a training step then allocates and frees nothing), "pool_reuses" = slots
  * handed out again; "den_launches" / "den_backward_launches" / "num_launches" / "num_backward_launches" /
  * "layout_launches" = denominator computations enqueued / those with a backward recursion / numerator computations /
- * those with a backward recursion / (B, C, T) <-> (T*B, C) copies, process-wide since the library was loaded.
+ * those with a backward recursion / (B, C, T) <-> (T*B, C) copies, process-wide since the library was loaded;
+ * (tc_den_graph_prepare's one-off timing launches of a graph's two kernels are counted like any other);
+ * "den_long_utterance_launches" = on-chip denominator launches whose frame sums did not fit LDS and went through the
+ * workspace (utterances of many hundred frames on the largest on-chip graphs).
  * -1 for an unknown key. */
 int64_t tc_debug_counter(const char *key);
 

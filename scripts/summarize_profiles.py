@@ -76,5 +76,36 @@ if sq:
         g.write("counter,mean_per_launch\n")
         for k in sorted(sq):
             g.write("%s,%.6g\n" % (k, sq[k]))
+# ---- secondary ceilings: what the kernel's LDS and VALU pipes were busy for, as time at the measured clock
+config = sys.argv[4] if len(sys.argv) > 4 else "C3"
+clock_mhz = None
+cf = os.path.join(out, "clock.txt")
+if os.path.exists(cf):
+    import re
+    m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", open(cf).read())
+    if m:
+        clock_mhz = float(m.group(1))
+if sq and clock_mhz and "SQ_INSTS_VALU" in sq and "SQ_LDS_IDX_ACTIVE" in sq:
+    CUS, SIMDS = 256, 1024
+    sec = {
+        "config": config, "kernel": summary.get("kernel", KERNEL), "clock_mhz": clock_mhz,
+        # a wave's VALU instruction occupies its SIMD's issue for 4 cycles (64 lanes on 16); summed over all waves / 1024 SIMDs
+        "valu_issue_ms": sq["SQ_INSTS_VALU"] * 4.0 / SIMDS / (clock_mhz * 1e3),
+        # cycles a CU's LDS was serving indexed operations, summed over CUs / 256 CUs
+        "lds_active_ms": sq["SQ_LDS_IDX_ACTIVE"] / CUS / (clock_mhz * 1e3),
+        "lds_conflict_ratio": sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"],
+        "counters": {k: sq[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_LDS_IDX_ACTIVE",
+                                        "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_BUSY_CYCLES") if k in sq},
+        "kernel_ms_under_rocprofv3": summary.get("avg_ns", 0.0) * 1e-6,
+        "source": "rocprofv3 --pmc SQ_* passes of scripts/collect_profiles.sh %s %s (per launch, summed over XCDs), shader clock from "
+                  "rocm-smi while the same workload ran un-profiled; not measured by the bench run that quotes it" % (tag, config),
+    }
+    json.dump(sec, open(os.path.join(out, "secondary_%s.json" % config), "w"), indent=1)
+    if "hbm_bytes_per_launch" in summary:
+        json.dump({k: summary[k] for k in ("fetch_size_kb_per_launch", "write_size_kb_per_launch", "hbm_bytes_per_launch")} |
+                  {"kernel": summary.get("kernel", KERNEL), "note": "scripts/collect_profiles.sh %s %s: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in "
+                   "separate passes; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 16-byte-per-lane reads at 1/2, "
+                   "MI355X_MICROARCH.md HBM section)" % (tag, config)},
+                  open(os.path.join(out, "traffic_%s.json" % config), "w"), indent=1)
 json.dump(summary, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary))

@@ -293,7 +293,8 @@ def test_graph_hash_and_fixed_kernel_choice_need_no_gpu():
 
 def test_tuning_cache_is_the_librarys_and_reads_the_python_format(tmp_path, monkeypatch):
     """Round 5: the cache of measured kernel choices lives below the Python layer (csrc/tuning_cache.cpp,
-    consulted by tc_den_graph_prepare).  Host-only part: entries written through the C ABI are valid JSON in the format
+    consulted by tc_den_graph_prepare).  Round 6: the key ends with the generation of the kernels the choice was timed on
+    (":k6"), so that a cache written against another round's kernels is not applied to this one's.  Host-only part: entries written through the C ABI are valid JSON in the format
     round 4's io.py wrote, entries written by that Python code are found by the library, a damaged file means "not cached"."""
     import ctypes as C
     import json
@@ -304,13 +305,13 @@ def test_tuning_cache_is_the_librarys_and_reads_the_python_format(tmp_path, monk
     assert lib.tc_tuning_cache_put(0x1234, b"AMD Instinct MI355X", 1, 0.5, 0.25) == 0
     assert lib.tc_tuning_cache_put(0xABCDEF0123456789, b"AMD Instinct MI355X", 0, 0.75, 0.875) == 0
     table = json.load(open(path))
-    assert table["0000000000001234:AMD Instinct MI355X"] == {"fused_ms": 0.5, "two_sequence_kernel": 1, "two_sequence_ms": 0.25}
-    assert table["abcdef0123456789:AMD Instinct MI355X"]["two_sequence_kernel"] == 0
+    assert table["0000000000001234:AMD Instinct MI355X:k6"] == {"fused_ms": 0.5, "two_sequence_kernel": 1, "two_sequence_ms": 0.25}
+    assert table["abcdef0123456789:AMD Instinct MI355X:k6"]["two_sequence_kernel"] == 0
     assert lib.tc_tuning_cache_get(0x1234, b"AMD Instinct MI355X", C.byref(got)) == 1 and got.value == 1
     assert lib.tc_tuning_cache_get(0xABCDEF0123456789, b"AMD Instinct MI355X", C.byref(got)) == 1 and got.value == 0
     assert lib.tc_tuning_cache_get(0x1234, b"another device", C.byref(got)) == 0
     # the round-4 Python writer's format (json.dump(indent=1, sort_keys=True))
-    table["00000000000000ff:dev"] = {"fused_ms": 1.0, "two_sequence_kernel": 1, "two_sequence_ms": 0.5}
+    table["00000000000000ff:dev:k6"] = {"fused_ms": 1.0, "two_sequence_kernel": 1, "two_sequence_ms": 0.5}
     with open(path, "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     assert lib.tc_tuning_cache_get(0xFF, b"dev", C.byref(got)) == 1 and got.value == 1
@@ -319,7 +320,7 @@ def test_tuning_cache_is_the_librarys_and_reads_the_python_format(tmp_path, monk
         f.write("{ not json")
     assert lib.tc_tuning_cache_get(0x1234, b"AMD Instinct MI355X", C.byref(got)) == 0
     assert lib.tc_tuning_cache_put(0x1, b"d", 1, 0.1, 0.05) == 0 and json.load(open(path)) == {
-        "0000000000000001:d": {"fused_ms": pytest.approx(0.1), "two_sequence_kernel": 1, "two_sequence_ms": pytest.approx(0.05)}}
+        "0000000000000001:d:k6": {"fused_ms": pytest.approx(0.1), "two_sequence_kernel": 1, "two_sequence_ms": pytest.approx(0.05)}}
     assert lib.tc_tuning_cache_put(0x1, None, 1, 0.1, 0.05) < 0 and lib.tc_tuning_cache_put(0x1, b"d", 2, 0.1, 0.05) < 0
 
 
@@ -334,7 +335,7 @@ def test_tuning_cache_survives_odd_device_names_and_damaged_files(tmp_path, monk
     got = C.c_int32(0)
     odd = b'dev "B"\\\n'
     assert lib.tc_tuning_cache_put(0x1234, b"devA", 1, 0.5, 0.25) == 0 and lib.tc_tuning_cache_put(0x9999, odd, 0, 0.5, 0.75) == 0
-    assert set(json.load(open(path))) == {"0000000000001234:devA", "0000000000009999:dev _B___"}
+    assert set(json.load(open(path))) == {"0000000000001234:devA:k6", "0000000000009999:dev _B___:k6"}
     assert lib.tc_tuning_cache_get(0x9999, odd, C.byref(got)) == 1 and got.value == 0
     good = open(path, "rb").read()
     rng = random.Random(3)

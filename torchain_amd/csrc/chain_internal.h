@@ -444,6 +444,8 @@ extern thread_local int g_last_hip_error;
 
 // Diagnostic switches (tc_debug_set in the public header): process-wide, read when a graph is built.  They
 // replace what used to be environment variables of the shipping library.
+// bumped whenever a round changes a kernel the per-graph choice is timed on (tuning_cache.cpp: part of the cache key)
+constexpr int kKernelGeneration = 6;
 enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgCount };
 bool debug_flag(DebugFlag f);
 
@@ -452,7 +454,7 @@ void pool_release(int device, PoolSlot *slot);
 int64_t pool_counter(int which);  // 0: device allocations made by the pool, 1: slots reused
 // launches enqueued so far, by kind (tc_debug_counter): the evaluation-step tests read them to see that a forward-only
 // call enqueued no backward recursion
-enum LaunchCounter { kCntDen = 0, kCntDenBackward, kCntNum, kCntNumBackward, kCntLayout, kCntCount };
+enum LaunchCounter { kCntDen = 0, kCntDenBackward, kCntNum, kCntNumBackward, kCntLayout, kCntDenAsumGlobal, kCntCount };
 void count_launch(LaunchCounter c);
 int supervision_mark_use(tc_supervision *sup, int device, hipStream_t stream);
 #define TC_HIP_CHECK(expr)                        \

@@ -274,6 +274,9 @@ int build_schedules(tc_den_graph *g) {
       split_made = tied;
     }
     g->tied = tied;
+    // a general graph of more than kMaxIndex states fits no on-chip layout: straight to the streamed tables (the general
+    // schedule builders pack state indices into 16 + 2 bits and would run for seconds before compute_layout refused)
+    if (!tied && g->H > kMaxIndex) want_big = true;
   }
   auto restore_unsplit = [&]() {
     g->work_H = g->H;
@@ -352,7 +355,7 @@ int build_schedules(tc_den_graph *g) {
       g->layout_ok = true;
       return TC_OK;
     }
-    if (split_made) {
+    if (split_made && g->H <= kMaxIndex) {
       // The graph became tied only through state splitting, and the enlarged work graph does not fit the owner-computes
       // layouts.  Before it is given up to the streamed kernels (~8x slower per arc), the ORIGINAL graph gets its
       // chance on the general on-chip kernel, which it may well fit.
@@ -461,7 +464,8 @@ const bool g_env_applied = [] {
 int64_t tc_debug_counter(const char *key) {
   if (key && !strcmp(key, "pool_device_allocs")) return pool_counter(0);
   if (key && !strcmp(key, "pool_reuses")) return pool_counter(1);
-  static const char *const names[kCntCount] = {"den_launches", "den_backward_launches", "num_launches", "num_backward_launches", "layout_launches"};
+  static const char *const names[kCntCount] = {"den_launches", "den_backward_launches", "num_launches", "num_backward_launches", "layout_launches",
+                                              "den_long_utterance_launches"};
   for (int i = 0; key && i < kCntCount; ++i)
     if (!strcmp(key, names[i])) return g_launches[i].load(std::memory_order_relaxed);
   return -1;

@@ -506,6 +506,7 @@ bool den_zeroes_xent(const DenParams &p, int num_cus) {
 int launch_den_mode(const DenParams &p, int accumulate, hipStream_t stream) {
   count_launch(kCntDen);
   if (p.deriv) count_launch(kCntDenBackward);
+  if (!p.big.in.rows && p.L.asum_global) count_launch(kCntDenAsumGlobal);
   if (p.big.in.rows) return launch_den_big(p, accumulate, stream);  // graph beyond the on-chip layout
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
   if (lds > (size_t)kLdsLimitBytes) return TC_ERR_UNSUPPORTED;

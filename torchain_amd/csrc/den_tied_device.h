@@ -48,6 +48,12 @@ __device__ __forceinline__ f4 bld4(rsrc_t r, uint32_t voff, uint32_t soff) {
   const u4 v = bld4u(r, voff, soff);
   return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
+// ... with the cache policy chosen by the caller (0: default, 2: nt -- a row nobody reads again soon)
+template <int AUX>
+__device__ __forceinline__ f4 bld4_aux(rsrc_t r, uint32_t voff, uint32_t soff) {
+  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX);
+  return f4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
 // Stores never put their offset into the SGPR soffset field.  Measured on gfx950 (this kernel's history rows, 2nd
 // plane): `buffer_store_dwordx4 v[76:79], v106, s[40:43], s0 offen` followed directly by a VALU write of v76
 // stored corrupted data -- the >64-bit store-data hazard.  The compiler pads that hazard with s_nop only when

@@ -14,13 +14,15 @@
 //     (schedule_owner.cpp, `planewise`) cuts every wave's stream at chunk boundaries into its secondary rows and one
 //     sub-stream per plane; when a plane's sub-stream ends, the wave runs that plane's per-state pass and walks on.  The
 //     row sums of all planes share four accumulator rows per wave.
-//   * NOTHING per-state waits in registers.  What a frame must keep per owned state goes through L2: the forward pass
-//     writes alpha_t (un-dashed) straight into its history row and the frame's tail reads it back to form the gather
-//     source alpha'_t = alpha_t + leaky * pi * asum_t; the backward pass keeps beta'_t in one more row of the history
-//     buffer.  That is 0.1-0.3 MB per frame and CU next to the 1.7-1.9 MB of cells every walk streams.
-//   * the registers go to the stream instead: three chunk buffers, two chunks requested ahead -- the waves of a frame are at
-//     different planes, some in their passes, so the stream path is only busy while enough requests are in flight
-//     (two buffers: 11.2 ms per 256 x 150 batch of the 24000-state R4 graph, profiles/r05).
+//   * per-state values cross the walks in as FEW registers as a frame can do with: one float4 per plane (24-28 registers) --
+//     alpha_t as the passes form it, until the frame's tail adds the leaky term; beta_{t+1} / beta'_t / beta_t through a
+//     backward frame -- indexed by the wave-uniform run-time plane number through opaque selects (rget / rset).  Everything
+//     else a plane's pass needs (tables, alpha_t and alpha_{t+1} of the backward pass) is requested from L2 a sub-stream
+//     ahead.  Round 5 kept NOTHING per-state in registers: alpha_t was read back from the history row it had just been
+//     written to, and beta'_t lived in one more row of the history buffer -- a written and two read rows per frame and CU
+//     whose 32 copies per XCD took 3 of its L2's 4 MB from the cell stream (R4: 9.5 ms per 256 x 150 batch; now 7.55).
+//   * the rest of the registers go to the stream: two chunk buffers in the fused kernel, three in the two-workgroup form.
+//     The history rows are stored `nt`: their next reader is the backward pass.
 //   * cells carry 16-bit POSITIONS (byte offset = one SDWA shift), one row-end byte per chunk.
 // One instantiation serves 5, 6 and 7 planes (the plane index is a wave-uniform run-time value).
 //
@@ -35,7 +37,7 @@ namespace tc {
 
 namespace {
 
-template <bool ACCUM, int MAXP>
+template <bool ACCUM, int MAXP, int BUF>
 struct PlaneSeq {
   static constexpr uint32_t kPB = 0u;             // exp(y_t)
   static constexpr uint32_t kA0 = 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
@@ -165,13 +167,25 @@ struct PlaneSeq {
 
   // The frame's walk: chunks through kBuffers buffers, kBuffers - 1 requested ahead; whenever the sub-stream of a plane ends (at chunk
   // boundaries, by construction) `pass(plane)` runs.  q0 / q1 arrive requested (chunks 0 and 1: ahead of the frame's barrier).
-#ifndef TC_PW_BUFFERS
-#define TC_PW_BUFFERS 3
+#ifndef TC_PW_BUFFERS_FUSED
+#define TC_PW_BUFFERS_FUSED 2
+#endif
+#ifndef TC_PW_BUFFERS_PAIR
+#define TC_PW_BUFFERS_PAIR 3
 #endif
 #ifndef TC_PW_HIST_AUX
-#define TC_PW_HIST_AUX 0  /* cache policy of the alpha history's stores (0: default, 2: nt) */
+#define TC_PW_HIST_AUX 2  /* cache policy of the alpha history's stores (0: default, 2: nt: the backward pass is their next reader -- R4 8.04 -> 7.80 ms) */
 #endif
-  static constexpr int kBuffers = TC_PW_BUFFERS;  // chunk buffers: kBuffers - 1 chunks requested ahead
+#ifndef TC_PW_AL_AUX
+#define TC_PW_AL_AUX 0  /* ... of the backward pass's first read of a history row (alpha_t in frame t) */
+#endif
+#ifndef TC_PW_AUP_AUX
+#define TC_PW_AUP_AUX 0  /* ... of its second and last read (alpha_{t+1} in frame t) */
+#endif
+  // chunk buffers: kBuffers - 1 chunks requested ahead.  Two in the fused kernel, three in the two-workgroup form (measured in
+  // round 6, with 24-28 registers of per-state rows across the walks: R4 at 256 sequences 7.76 -> 7.55 ms with two, but at 128
+  // -- two workgroups per sequence, half the CUs' L1s on one stream each -- 4.24 -> 4.89)
+  static constexpr int kBuffers = BUF;
   // (the first requests of a frame, ahead of its barrier)
   __device__ __forceinline__ void request_first(Chunk6 (&q)[kBuffers]) {
 #pragma unroll
@@ -396,8 +410,8 @@ struct PlaneSeq {
     ws_n = bld4(r_ws, own16, pj);
     cp_n = bld4(r_pi, own16, pj);
     if (!PURE) {
-      al_n = bld4(hist_t, own16, pj);
-      aup_n = bld4(hist_up, own16, pj);
+      al_n = bld4_aux<TC_PW_AL_AUX>(hist_t, own16, pj);
+      aup_n = bld4_aux<TC_PW_AUP_AUX>(hist_up, own16, pj);
     }
     request_fix(j);
   }
@@ -503,7 +517,7 @@ struct PlaneSeq {
 
 template <bool ACCUM, bool WANT_DERIV, int MAXP>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenParams p) {
-  PlaneSeq<ACCUM, MAXP> q(p, (int)blockIdx.x);
+  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_FUSED> q(p, (int)blockIdx.x);
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
   q.forward_begin();
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenPara
 // ROLE F: alpha forward over frames 1..M exactly as the fused kernel, the hand-over, then frames M+1..T with gamma_{t-1}
 template <bool ACCUM, int MAXP>
 __device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const MitmParams &mq, int s) {
-  PlaneSeq<ACCUM, MAXP> q(p, s);
+  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_PAIR> q(p, s);
   const int T = q.T, M = mq.M;
   q.forward_begin();
   for (int t = 1; t <= M; ++t) q.template forward_frame<false>(t);
@@ -546,7 +560,7 @@ __device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const Mi
 // ROLE B: frames T-1..M with normalisers of its own and no gamma, the hand-over, then the fused kernel's backward frame
 template <bool ACCUM, int MAXP>
 __device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const MitmParams &mq, int s) {
-  PlaneSeq<ACCUM, MAXP> q(p, s);
+  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_PAIR> q(p, s);
   const int T = q.T, M = mq.M;
   q.template backward_begin<true>(1.0f);  // B'_T = 1
   for (int t = T - 1; t >= M; --t) q.template backward_frame<true>(t);

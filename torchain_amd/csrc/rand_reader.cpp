@@ -129,9 +129,9 @@ struct tc_rand_reader {
 
   // (`dev`: the staging device as the caller read it under `mu`)
   Ready load(const std::vector<int32_t> &batch, int dev) const {
-    Ready r;
+    Ready r;  // (filled in place: what an exception leaves half-built is released here, not lost with a local of the callee)
     try {
-      r = load_unguarded(batch, dev);
+      load_into(r, batch, dev);
     } catch (const std::exception &e) {  // (bad_alloc and whatever else: a failed batch, not std::terminate on a worker)
       release(r);
       r.rc = TC_ERR_IO;
@@ -144,8 +144,7 @@ struct tc_rand_reader {
     return r;
   }
 
-  Ready load_unguarded(const std::vector<int32_t> &batch, int dev) const {
-    Ready r;
+  void load_into(Ready &r, const std::vector<int32_t> &batch, int dev) const {
     std::vector<const char *> paths;
     std::vector<int64_t> offs;
     for (int32_t e : batch) {
@@ -155,7 +154,7 @@ struct tc_rand_reader {
     r.rc = tc_example_read(paths.data(), offs.data(), (int32_t)paths.size(), 1, &r.example);
     if (r.rc != TC_OK) {
       r.error = tc_example_last_error();
-      return r;
+      return;
     }
     const char *name = nullptr;
     int32_t nidx = 0, dims[5] = {0, 0, 0, 0, 0};
@@ -166,7 +165,6 @@ struct tc_rand_reader {
     if (r.rc == TC_OK) r.rc = tc_supervision_create(&r.sup, weight, dims[0], dims[1], dims[2], dims[3], ab, il, aw, nx, fin);
     if (r.rc != TC_OK) r.error = "the minibatch's supervision does not build (tc_supervision_create)";
     if (r.rc == TC_OK && dev >= 0) (void)tc_supervision_stage(r.sup, dev);  // (a failure shows at the first use)
-    return r;
   }
 
   void worker() {

@@ -2,12 +2,13 @@
 // reference's denominator-graph handle (src/my_lib.h:29) that calls tc_den_graph_prepare directly gets the same kernel --
 // and with it the same last bits -- from run to run without knowing about tc_den_graph_set_variant.  One JSON file,
 // $TORCHAIN_TUNING_CACHE or ~/.cache/torchain_amd/tuning.json (read at every call: tests point it elsewhere), an object of
-//   "<tc_den_graph_hash as 16 hex digits>:<device name>": {"fused_ms": f, "two_sequence_kernel": 0 | 1, "two_sequence_ms": f}
+//   "<tc_den_graph_hash as 16 hex digits>:<device name>:k<kernel generation>": {"fused_ms": f, "two_sequence_kernel": 0 | 1, "two_sequence_ms": f}
 // entries -- the format torchain_amd/io.py wrote in round 4, so both sides read each other's files.  Any failure (no
 // home, read-only directory, damaged file) means "not cached": the choice is timed again.  Host code only.
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,7 +55,13 @@ std::map<std::string, std::string> read_table(const std::string &path) {
     if (b0 == std::string::npos) break;
     const size_t b1 = text.find('}', b0);
     if (b1 == std::string::npos) break;
-    table[text.substr(k0 + 1, k1 - k0 - 1)] = text.substr(b0 + 1, b1 - b0 - 1);
+    // (entries are plain ASCII as this library and the Python writer form them; anything else is damage, and carried into
+    // the next file it would make that one unreadable to a JSON parser)
+    const std::string key = text.substr(k0 + 1, k1 - k0 - 1), body = text.substr(b0 + 1, b1 - b0 - 1);
+    bool plain = true;
+    for (unsigned char c : key) plain = plain && c >= 0x20 && c < 0x7f && c != '\\';
+    for (unsigned char c : body) plain = plain && ((c >= 0x20 && c < 0x7f && c != '\\' && c != '"') || c == '\n' || c == '\r' || c == '\t' || c == '"');
+    if (plain) table[key] = body;
     i = b1 + 1;
   }
   return table;
@@ -83,10 +90,11 @@ void make_dirs(const std::string &path) {
 std::string tuning_cache_key(uint64_t graph_hash, const char *device_name) {
   char hex[24];
   snprintf(hex, sizeof hex, "%016llx", (unsigned long long)graph_hash);
-  std::string key = std::string(hex) + ":" + (device_name ? device_name : "");
+  // (the kernels a choice was timed against: a choice measured with another round's kernels is not this library's)
+  std::string key = std::string(hex) + ":" + (device_name ? device_name : "") + ":k" + std::to_string(kKernelGeneration);
   // (the key is written between quotes as it is: nothing in it may need escaping, for this reader or for a JSON parser)
   for (char &c : key)
-    if (c == '"' || c == '\\' || (unsigned char)c < 0x20) c = '_';
+    if (c == '"' || c == '\\' || (unsigned char)c < 0x20 || (unsigned char)c >= 0x7f) c = '_';
   return key;
 }
 
@@ -105,12 +113,23 @@ void tuning_cache_put(const std::string &key, int two_sequence_kernel, float fus
   const std::string path = cache_path();
   if (path.empty()) return;
   make_dirs(path);
-  auto table = read_table(path);
-  char body[160];
-  snprintf(body, sizeof body, "\n  \"fused_ms\": %.9g,\n  \"two_sequence_kernel\": %d,\n  \"two_sequence_ms\": %.9g\n ", (double)fused_ms,
-           two_sequence_kernel ? 1 : 0, (double)two_sequence_ms);
-  table[key] = body;
-  const std::string tmp = path + "." + std::to_string((long long)getpid()) + ".tmp";
+  auto body_of = [](double fused, int choice, double two) {
+    char body[160];
+    snprintf(body, sizeof body, "\n  \"fused_ms\": %.9g,\n  \"two_sequence_kernel\": %d,\n  \"two_sequence_ms\": %.9g\n ", fused, choice ? 1 : 0, two);
+    return std::string(body);
+  };
+  // entries of the old file are carried over as their three numbers, written anew: whatever else a damaged file held
+  // stays behind, and what is written is JSON again
+  std::map<std::string, std::string> table;
+  for (const auto &kv : read_table(path)) {
+    double fused = 0.0, choice = 0.0, two = 0.0;
+    if (field(kv.second, "fused_ms", &fused) && field(kv.second, "two_sequence_kernel", &choice) && field(kv.second, "two_sequence_ms", &two) &&
+        fused == fused && two == two && fused - fused == 0.0 && two - two == 0.0)
+      table[kv.first] = body_of(fused, choice > 0.5, two);
+  }
+  table[key] = body_of((double)fused_ms, two_sequence_kernel, (double)two_sequence_ms);
+  static std::atomic<unsigned> serial{0};  // (two threads of one process preparing graphs at once write two files)
+  const std::string tmp = path + "." + std::to_string((long long)getpid()) + "." + std::to_string(serial.fetch_add(1)) + ".tmp";
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return;
   bool ok = fputs("{", f) >= 0;

@@ -452,7 +452,9 @@ class RandExample(Example):
 
     def next(self):
         if self._native is not None:
-            if self._staging_device is None and torch.cuda.is_available() and torch.cuda.is_initialized():
+            # (is_initialized() first: on ROCm is_available() itself initialises the runtime, and a reader built with
+            # device=None promises to touch no GPU until the process has)
+            if self._staging_device is None and torch.cuda.is_initialized():
                 self._set_staging_device(torch.cuda.current_device())  # (the process uses the GPU by now: no new context)
             rc = lib.tc_rand_reader_next(self._native)
             self._cur = None
