@@ -16,6 +16,7 @@ export TMPDIR=/tmp
 export TORCHAIN_HIP_DEBUG=no_tune
 cmd="python3 $root/bench.py --config $config --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
 cd /tmp
+if [ -z "${CLOCK_ONLY:-}" ]; then
 # the kernel-trace pass runs the default bench (30 steps + 5 warm-up + 20 event-timed launches), so its
 # average is taken over the same mix of launches as bench.py's HIP-event figure
 rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt" -o kt -- python3 $root/bench.py --config $config --no-cpu-baseline --no-extras > "$out/kt.log" 2>&1
@@ -24,12 +25,13 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$out/write" -o pmc -- $cmd > 
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM -d "$out/sq1" -o pmc -- $cmd > "$out/sq1.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$out/sq2" -o pmc -- $cmd > "$out/sq2.log" 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES -d "$out/sq3" -o pmc -- $cmd > "$out/sq3.log" 2>&1
+fi
 cd "$root"
 # the shader clock the kernel really runs at (the chip is power-capped: 2.1 - 2.4 GHz by batch): sampled while the same
 # workload runs un-profiled, for the secondary ceilings (LDS-active and VALU-issue time need a clock)
-(python3 bench.py --config $config --steps 3000 --warmup 2 --no-cpu-baseline --no-extras > "$out/clock_run.log" 2>&1) &
+(python3 bench.py --config $config --steps 30000 --warmup 2 --no-cpu-baseline --no-extras > "$out/clock_run.log" 2>&1) &
 pid=$!
-sleep 12
+sleep 20   # (imports, the graph's schedules, the upload: the timed loop is running by now and for tens of seconds more)
 rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|mclk\|power" | head -6 > "$out/clock.txt"
 kill $pid 2>/dev/null; wait $pid 2>/dev/null
 cat "$out/clock.txt"

@@ -71,7 +71,13 @@ if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
 sq = {}
 for sub in ("sq1", "sq2", "sq3"):
     sq.update(counter_means(sub))
-if sq:
+if not sq and os.environ.get("SQ_CSV"):
+    # the counters of an earlier collection (a clock-only re-run: CLOCK_ONLY=1 scripts/collect_profiles.sh)
+    for row in csv.DictReader(open(os.environ["SQ_CSV"])):
+        sq[row["counter"]] = float(row["mean_per_launch"])
+    if os.environ.get("KERNEL_MS"):
+        summary["avg_ns"] = float(os.environ["KERNEL_MS"]) * 1e6
+elif sq:
     with open(os.path.join(out, "%s_sq_counters.csv" % tag), "w") as g:
         g.write("counter,mean_per_launch\n")
         for k in sorted(sq):

@@ -367,3 +367,32 @@ def test_one_call_step_numerical_failure_is_soft(three_d, kaldi_way):
     assert torch.allclose(a.grad[finite], want[finite], rtol=1e-6, atol=0)
     assert torch.count_nonzero(b.grad) == 0
     assert res.xent_objf == 0.0
+
+
+@pytest.mark.parametrize("three_d", [False, True])
+@pytest.mark.parametrize("xent", [False, True])
+def test_registered_operator_equals_chain_loss(three_d, xent):
+    """``torch.ops.torchain_amd.chain_step`` (torchain_amd/ops.py: the step as a ``torch.library`` operator with an autograd formula)
+    against ``chain_loss``: loss, results, both gradients bit for bit; the evaluation step under ``no_grad``; ``grad_output`` ignored
+    as in the reference's backward (``torchain/functions.py:106-115``)."""
+    from torchain_amd.ops import chain_loss_op
+    S, T = 8, 20
+    cfg, graph, sup, y2d = _workload("C2", S, T, seed=21)
+    xe2d = torch.from_numpy(synth.random_nnet_output(S, T, cfg["P"], seed=22)).to(DEV)
+    x, xe = (_as_bct(y2d, S, T), _as_bct(xe2d, S, T)) if three_d else (y2d, xe2d)
+    kw = dict(l2_regularize=5e-5, leaky_hmm_coefficient=0.1, xent_regularize=0.1 if xent else 0.0, kaldi_way=True)
+    outs = []
+    for fn in (chain_loss, chain_loss_op):
+        a = x.clone().requires_grad_(True)
+        b = xe.clone().requires_grad_(True) if xent else None
+        loss, res = fn(a, graph, sup, xent_input=b, **kw)
+        (3.0 * loss).sum().backward()  # (the factor changes nothing)
+        outs.append((loss.detach().clone(), res.data.clone(), a.grad.clone(), None if b is None else b.grad.clone(), res.xent_objf))
+    (l0, r0, g0, x0, o0), (l1, r1, g1, x1, o1) = outs
+    assert torch.equal(l0, l1) and torch.equal(r0, r1) and torch.equal(g0, g1) and o0 == o1
+    assert (x0 is None and x1 is None) or torch.equal(x0, x1)
+    before = _counters()
+    with torch.no_grad():
+        le, re_ = chain_loss_op(x, graph, sup, xent_input=xe if xent else None, **kw)
+    assert _delta(before)["den_backward_launches"] == 0
+    np.testing.assert_allclose(re_.data.numpy(), r0.numpy(), rtol=1e-6)

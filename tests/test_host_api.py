@@ -70,3 +70,20 @@ def test_shard_range_partitions_exactly():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_torch_library_registration_and_fake_implementation():
+    """``torchain_amd::chain_step`` (SURVEY.md section 7 step 5) is a registered operator with a schema and a fake implementation:
+    shapes of its three outputs without a GPU, for a training and an evaluation step."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from torchain_amd import ops  # noqa: F401  (registers the operator)
+    op = torch.ops.torchain_amd.chain_step
+    assert "Tensor input, Tensor xent_input" in str(op.default._schema)
+    with FakeTensorMode():
+        x, xe = torch.empty(4, 7, 5), torch.empty(4, 7, 5)
+        out, g, xg = op(x, xe, 1, 2, 0.0, 0.1, 0.1, True, True)
+        assert out.shape == (6,) and g.shape == x.shape and xg.shape == xe.shape
+        out, g, xg = op(x, torch.empty(0), 1, 2, 0.0, 0.1, 0.0, True, False)
+        assert out.shape == (6,) and g.numel() == 0 and xg.numel() == 0

@@ -228,6 +228,7 @@ namespace tc {
 // sequence per CU and kTuneFrames frames (their time does not depend on the values) in scratch memory that is freed
 // again; the two-sequence kernel is kept when it is at least 3% faster.  Any failure here leaves the fused kernel.
 constexpr int kTuneFrames = 48, kTuneWarmup = 60, kTuneRounds = 4;
+constexpr double kPairMinArcsPerState = 11.0;
 
 int tune_den_variant(tc_den_graph *g, int device) {
   DenGraphDev d;
@@ -256,6 +257,11 @@ int tune_den_variant(tc_den_graph *g, int device) {
   };
   if (!pair_room(g) || !d.fwd.cells_pair || debug_flag(kDbgNoPair) || debug_flag(kDbgNoTune) || debug_flag(kDbgForcePair))
     return finish();
+  // The two-sequence kernel shares one walk between two sequences and pays for it in its gamma frames: measured, it never
+  // wins below about 11-12 arcs per state (C3's 8: 8 % slower) -- such graphs keep the fused kernel without being timed
+  // (no timing launches, no scratch).  Its frame bodies are its own statement of the tied frame (clamp, gamma scale and
+  // fixed-point adds are den_tied_device.h's shared helpers); tests/test_gpu_tied.py holds it to the fused kernel's values.
+  if ((double)g->work_src.size() < kPairMinArcsPerState * (double)std::max(1, g->work_H) && preset < 0) return finish();
   if (preset >= 0) {  // the caller's choice (a cache of an earlier run, or rank 0's): no timing launches
     choice = preset;
     return finish();
