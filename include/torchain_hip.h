@@ -382,9 +382,12 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "slab_wide" / "slab_narrow" (1: the streamed path cuts the batch into slabs of 32 / 16 sequences whatever the graph's size)
  *   "old_arrange"    (1: the greedy placement of a half-slot's cells that rounds 1-4 used, instead of round 5's matching:
  *                     HISTORY.md 4.1e)
- *   "no_planes"      (1: tied graphs of 16385..28672 positions take the streamed path, not the plane-wise on-chip kernel)
+ *   "no_planes"      (1: tied graphs of 16385..40960 positions take the streamed path, not the plane-wise on-chip kernel)
+ *   "no_split_source" (1: tied graphs of 28673..40960 positions take the streamed path at every batch, as before round 6)
  *   "old_general"    (1: general graphs take round 1's on-chip kernel, not the one on owner-computes schedules)
  * Read at launch (one relaxed atomic load):
+ *   "split_source_any_batch" (1: tied graphs of 28673..40960 positions run their on-chip kernel also below 129 sequences,
+ *                     where the library routes them to the streamed path: it is the faster one there)
  *   "no_phase_split" (1: batches of at most 128 sequences of tied on-chip graphs take the fused kernel instead of
  *                     running forward and backward recursion on two CUs at once; the plane-wise kernel likewise)
  *   "no_num_overlap" (1: the numerator always follows the denominator on the caller's stream; by default it runs

@@ -52,6 +52,23 @@ def test_plane_wise_schedules_replay(H, deg, P):
     check_graph(fst, 1)
 
 
+@pytest.mark.parametrize("H,deg,P", [(29000, 3, 900), (33000, 4, 2928), (40000, 3, 4096)])
+def test_split_source_schedules_replay(H, deg, P):
+    """28673..40960 positions (round 6): the gather source is in LDS a half at a time, so every row is cut into the cells whose
+    source lies in the first ceil(planes / 2) planes and the others; a wave's stream is [sub-streams of the first half | of the
+    second], a cell's field is its position inside its half, fix-up lists per half, thread and plane."""
+    fst = synth.random_den_fst(H, deg, P, seed=H + deg)
+    assert io.DenominatorGraph(fst, P).stats()["lds_bytes"] <= 160 * 1024
+    check_graph(fst, 1)
+
+
+def test_split_source_schedules_with_hub_states_replay():
+    """... with in-degrees of hundreds: secondary rows of both halves share their private slots."""
+    fst = synth.phone_lm_den_fst(num_histories=3200, branching=10, seed=11)
+    assert fst.num_states > 28672
+    check_graph(fst, 1)
+
+
 def test_plane_wise_schedules_of_phone_lm_graphs_replay():
     """R4 (24000 states, 312000 arcs, in-degrees to 200: secondary rows folded per plane) stays on chip."""
     check_graph(synth.config_den_fst("R4"), 1)

@@ -70,6 +70,13 @@ constexpr int kMaxIndex = 1 << 14;
 // rows per wave.  Cells carry positions (16 bits), not byte offsets.
 constexpr int kJvPlanes = 7;
 constexpr int kMaxPlanePositions = 4096 * kJvPlanes;
+// ... and of 28673..40960 positions (round 6): the gather source no longer fits LDS as a whole, so a frame is walked in TWO
+// sub-passes -- the cells whose source lies in the first half of the positions (planes 0 .. ceil(planes / 2) - 1), then,
+// with the second half of the source brought in from the workspace, the others; a plane's row sums of the first sub-pass
+// wait in the workspace (DenParams::part_scratch) for the second, which runs the per-state pass.  ScheduleHost::halves.
+constexpr int kJvPlanesSplit = 10;
+constexpr int kMaxSplitPositions = 4096 * kJvPlanesSplit;
+constexpr int kSplitSourceMinSeq = 129;  // batches below take the streamed path (tc_den_graph::small_batch)
 
 struct ScheduleHost {
   std::vector<ArcRec> cells;       // all waves' streams, [cell][lane] (final layout [pair][lane][2])
@@ -90,6 +97,10 @@ struct ScheduleHost {
   // rows, then one per plane -- each padded to whole chunks, with mask words of its own: wave_range[wave * subs + sub],
   // masks[(wave * subs + sub) * mask_stride ...]; fix_begin is [thread][plane] (+ 1)
   int32_t subs = 0;
+  // 2: split gather source (kMaxPlanePositions < positions <= kMaxSplitPositions): the wave's stream is `subs` sub-streams
+  // per half (wave_range[wave * halves * subs + half * subs + sub]), a cell's field is its position inside its half,
+  // fix_begin is [half][thread][plane] (+ 1)
+  int32_t halves = 1;
 };
 
 struct ScheduleDev {
@@ -101,7 +112,8 @@ struct ScheduleDev {
   const int32_t *extra_first = nullptr;
   int32_t mask_stride = 0, nfix = 0;
   const void *cells_pair = nullptr;     // tied graphs of at most 8192 positions: the stream with offsets = position * 8
-  int32_t subs = 0;                     // plane-wise form: sub-streams per wave (ScheduleHost::subs), else 0
+  int32_t subs = 0;                     // plane-wise form: sub-streams per wave and half (ScheduleHost::subs), else 0
+  int32_t halves = 1;                   // ... and the number of halves of the gather source (ScheduleHost::halves)
 };
 
 // ---- graphs too large for the on-chip layout ("streamed" path, den_slab_kernel.hip) ------------------
@@ -175,6 +187,9 @@ struct DenLayout {
   // the frame sums asum_0..T live in the workspace (DenParams::asum_g), not behind off_asum: utterances too long for the
   // LDS the graph leaves (plane-wise kernel, general owner-computes kernel: the kernels they replaced ran any T)
   bool asum_global = false;
+  // plane-wise form: planes of the gather source that are in LDS at a time -- JV, or ceil(JV / 2) for graphs beyond
+  // kMaxPlanePositions (the gather region is 4096 * src_planes floats)
+  int src_planes = 0;
 };
 
 struct DenParams {
@@ -186,6 +201,9 @@ struct DenParams {
   int64_t deriv_stride;
   float *alpha_hist;    // [(T+1)][S][Hs]
   float *asum_g = nullptr;  // [S][asum_stride(T)]: the frame sums when the layout says asum_global
+  // split gather source (DenLayout::src_planes < JV): the second half of the running frame's gather source
+  // [S][4096 * (JV - src_planes)] and the first sub-pass's row sums [S][Hs]
+  float *src_scratch = nullptr, *part_scratch = nullptr;
   double *seq_logprob;  // [S]
   double *seq_y2;       // [S] sum of y^2 (for the l2 term)
   float *seq_ab;        // [S] sum_h alpha'_0 beta'_0
@@ -269,6 +287,13 @@ struct tc_den_graph {
   std::vector<int32_t> big_f_off;
   std::vector<int32_t> tied_f, tied_s;  // per work state: forward / special self-loop pdf, -1 if none
   float big_sum_pi = 0.f;
+  // Graphs of kMaxPlanePositions + 1 .. kMaxSplitPositions positions (split gather source, den_tied_planes.hip) have only
+  // the one-workgroup-per-sequence form on chip, which costs the same whatever the batch; below kSplitSourceMinSeq sequences
+  // the streamed path is faster (X2: 11.0 vs 18.5 ms at 64 sequences, 17.2 vs 18.6 at 128; 27.3 vs 20.4 at 256).  Such a graph
+  // therefore carries a second handle of the same FST built for the streamed path, and every entry point that knows the
+  // batch routes to it (api.cpp: route()).  Owned: freed and uploaded with this one.
+  tc_den_graph *small_batch = nullptr;
+  bool build_streamed = false;  // (this handle IS such a second one)
   std::mutex mu;
   std::map<int, tc::DenGraphDev> dev;
   std::map<int, int> preset_variant;  // device -> kernel choice fixed by the caller (tc_den_graph_set_variant)
@@ -446,7 +471,7 @@ extern thread_local int g_last_hip_error;
 // replace what used to be environment variables of the shipping library.
 // bumped whenever a round changes a kernel the per-graph choice is timed on (tuning_cache.cpp: part of the cache key)
 constexpr int kKernelGeneration = 6;
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgNoSplitSrc, kDbgSplitSrcAnyBatch, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

@@ -255,7 +255,7 @@ static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
 }
 
 int build_schedules(tc_den_graph *g) {
-  bool want_big = debug_flag(kDbgForceStreamed) || g->H > kMaxPlanePositions || g->P > kMaxIndex;
+  bool want_big = debug_flag(kDbgForceStreamed) || g->build_streamed || g->H > kMaxSplitPositions || g->P > kMaxIndex;
   bool split_made = false;  // tied only thanks to make_work_graph
   // ---- the tied path: on the FST as it is, or on its tied-ified work graph
   std::vector<char> special;
@@ -425,7 +425,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search", "no_split_source", "split_source_any_batch"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -532,6 +532,21 @@ int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs
     for (int s = 0; s < H; ++s) g->initial_probs[s] = (float)avg[s];
   }
   build_schedules(g);
+  if (!g->big && g->tied && g->layout_ok && g->layout.planewise && g->layout.src_planes < g->layout.JV) {
+    // split gather source: small batches take the streamed path (chain_internal.h: tc_den_graph::small_batch)
+    tc_den_graph *alt = new tc_den_graph();
+    alt->H = g->H;
+    alt->P = g->P;
+    alt->A = g->A;
+    alt->arc_src = g->arc_src;
+    alt->arc_dst = g->arc_dst;
+    alt->arc_pdf = g->arc_pdf;
+    alt->arc_prob = g->arc_prob;
+    alt->initial_probs = g->initial_probs;
+    alt->build_streamed = true;
+    build_schedules(alt);
+    g->small_batch = alt;
+  }
   *out = g;
   return TC_OK;
 }
@@ -645,6 +660,7 @@ int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pd
 
 void tc_den_graph_free(tc_den_graph *g) {
   if (!g) return;
+  if (g->small_batch) tc_den_graph_free(g->small_batch);
   for (auto &kv : g->dev) {
     if (kv.second.blob) {
       int cur = 0;
@@ -790,7 +806,12 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
   if (g->tied) {
     const int K = Hs / kThreads;
     const bool pw = g->layout.planewise;
-    const int subs = pw ? sc.subs : 1;
+    const int subs = pw ? sc.subs : 1, halves = pw ? sc.halves : 1, subs_all = subs * halves;
+    // split gather source (ScheduleHost::halves == 2): the walk is replayed a half at a time, as the kernel makes it -- the
+    // half's cells address positions inside the half, its secondary rows are folded from slots the next half reuses, and the
+    // halves' row sums add up
+    const int half_pos = halves == 2 ? 4096 * ((Hs / 4096 + 1) / 2) : 0;
+    std::vector<float> total(acc.size(), 0.f);
     std::vector<float> src_pos((size_t)Hs + 4, 0.f);
     // a split state's alpha is the sum of its copies' (forward: the first copy carries the value), its
     // beta is shared by all copies (backward: every copy presents it)
@@ -800,12 +821,15 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
         src_pos[g->pos[c]] = direction == 0 ? (c == g->copy_first[h] ? gather[h] : 0.f)
                                             : gather[h] * pdf_factor[(fs & 0xffffu) >> 2];
       }
+    for (int hv = 0; hv < halves; ++hv) {
+    std::fill(acc.begin(), acc.end(), 0.f);
+    const int pos_base = hv ? half_pos : 0;
     for (int w = 0; w < kWaves; ++w)
      for (int sub = 0; sub < subs; ++sub) {
       // (plane-wise form: .y is the sub-stream's END counted from the wave's first cell, and the mask bytes are the wave's)
-      const int first = sc.wave_range[(size_t)w * subs + sub].x;
-      const int rel = pw ? first - sc.wave_range[(size_t)w * subs].x : 0;
-      const int n = sc.wave_range[(size_t)w * subs + sub].y - rel;
+      const int first = sc.wave_range[(size_t)w * subs_all + hv * subs + sub].x;
+      const int rel = pw ? first - sc.wave_range[(size_t)w * subs_all].x : 0;
+      const int n = sc.wave_range[(size_t)w * subs_all + hv * subs + sub].y - rel;
       for (int l = 0; l < 64; ++l) {
         const int tid = 64 * w + l;
         int k = !pw ? 0 : sub == 0 ? K : 4 * (sub - 1);  // (sub-stream 0: the wave's secondary rows)
@@ -819,14 +843,14 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
           uint32_t x = base[((q / 4) * 64 + l) * 4 + (q % 4)];
           memcpy(wgt, &x, 4);
           const uint32_t o = base[(2 * 64 + l) * 4 + q / 2];
-          *position = (int)(((q & 1) ? o >> 16 : o & 0xffffu) >> (pw ? 0 : 2));
+          *position = pos_base + (int)(((q & 1) ? o >> 16 : o & 0xffffu) >> (pw ? 0 : 2));
         };
         for (int i = 0; i < n; i += 2) {
           float w0, w1;
           int p0, p1;
           cell(i, &w0, &p0);
           cell(i + 1, &w1, &p1);
-          uint32_t m = sc.masks[((size_t)w * subs + sub) * sc.mask_stride + (i / 2) / 8];
+          uint32_t m = pw ? 0u : sc.masks[((size_t)w * subs + sub) * sc.mask_stride + (i / 2) / 8];
           int bit = (i / 2) % 8;
           if (pw) {  // one byte per chunk of the wave's stream; re-stated in the pair form the loop below tests
             const int cell = rel + i, chunk = cell / 8;
@@ -851,12 +875,17 @@ int tc_den_graph_debug_walk(const tc_den_graph *g, int direction, const float *g
         }
       }
     }
-    for (size_t t = 0; t + 1 < sc.fix_begin.size(); ++t)
+    const size_t lists = (sc.fix_begin.size() - 1) / (size_t)halves;  // (fix_begin: [half][thread][plane] in the plane-wise form)
+    for (size_t t = hv * lists; t < (hv + 1) * lists; ++t)
       for (int e = sc.fix_begin[t]; e < sc.fix_begin[t + 1]; ++e) {
-        if (pw && ((sc.fix[e].x >> 2) % kThreads != (int)(t / (K / 4)) || sc.fix[e].x / (4 * kThreads) != (int)(t % (K / 4))))
+        const size_t tl = t - hv * lists;
+        if (pw && ((sc.fix[e].x >> 2) % kThreads != (int)(tl / (K / 4)) || sc.fix[e].x / (4 * kThreads) != (int)(tl % (K / 4))))
           return TC_ERR_UNSUPPORTED;  // (an entry must sit in the list of the thread and plane that own its state)
         acc[sc.fix[e].x] += acc[sc.fix[e].y];
       }
+    for (int p = 0; p < Hs; ++p) total[p] += acc[p];
+    }  // halves
+    acc.swap(total);
     for (int h = 0; h < H; ++h) {
       float sum = 0.f;
       for (int c = g->copy_first[h]; c < g->copy_first[h + 1]; ++c) {
@@ -907,7 +936,8 @@ static int upload_den_graph(tc_den_graph *g, int device);
 // two-sequence kernel on that device and keeps the faster (tune_den_variant).
 int tc_den_graph_prepare(tc_den_graph *g, int device) {
   if (!g) return TC_ERR_INVALID_ARGUMENT;
-  const int rc = upload_den_graph(g, device);
+  int rc = upload_den_graph(g, device);
+  if (rc == TC_OK && g->small_batch) rc = tc_den_graph_prepare(g->small_batch, device);
   if (rc != TC_OK) return rc;
   return tune_den_variant(g, device);
 }
@@ -1048,6 +1078,8 @@ static int upload_den_graph(tc_den_graph *g, int device) {
                       g->bwd.mask_stride, g->bwd.nfix};
   d.fwd.subs = g->fwd.subs;
   d.bwd.subs = g->bwd.subs;
+  d.fwd.halves = g->fwd.halves;
+  d.bwd.halves = g->bwd.halves;
   d.pi = (const float *)(blob + parts[4].off);
   if (g->tied) {
     d.tied_fs = (const uint32_t *)(blob + parts[9].off);

@@ -86,14 +86,16 @@ bool compute_layout(int H, int P, int T_hint, int extra_slots, bool tied, DenLay
 bool compute_layout_planes(int Npos, int P, int T_hint, int extra_slots, DenLayout *L) {
   L->Hs = Npos;
   L->Ps = round4(P);
-  if (Npos % (4 * kThreads) != 0 || Npos > kMaxPlanePositions || L->Ps > 4 * kThreads * kPvSmall) return false;
+  if (Npos % (4 * kThreads) != 0 || Npos > kMaxSplitPositions || L->Ps > 4 * kThreads * kPvSmall) return false;
   L->JV = Npos / (4 * kThreads);  // the kernel is instantiated per plane count (den_tied_planes.hip)
   if (L->JV < 5) return false;
   L->PV = kPvSmall;
   L->planewise = true;
+  // beyond kMaxPlanePositions the gather source is in LDS a half at a time (chain_internal.h: kJvPlanesSplit)
+  L->src_planes = Npos > kMaxPlanePositions ? (L->JV + 1) / 2 : L->JV;
   int off = L->PV * 4 * kThreads;
   L->off_a = off;
-  off += Npos;
+  off += 4 * kThreads * L->src_planes;
   L->off_acc = off;
   L->acc_floats = round4(4 * kThreads + 4 + extra_slots);
   off += L->acc_floats;

@@ -37,7 +37,12 @@ namespace tc {
 
 namespace {
 
-template <bool ACCUM, int MAXP, int BUF>
+// SPLIT: graphs of 28673..40960 positions -- the gather source is in LDS a HALF at a time (the first ceil(planes / 2) planes of
+// positions, then the others); a frame is two walks: the first over the cells whose source lies in the first half, whose
+// per-plane "pass" only parks the plane's row sums in the workspace, then -- the second half of the source brought in from
+// the workspace, where the previous frame's tail left it -- the second, whose per-plane pass adds the parked sums and is
+// the frame's real per-state pass.  Two more barriers and ~0.5 MB of L2 traffic per frame pair and CU beside 4.8 MB of cells.
+template <bool ACCUM, int MAXP, int BUF, bool SPLIT = false>
 struct PlaneSeq {
   static constexpr uint32_t kPB = 0u;             // exp(y_t)
   static constexpr uint32_t kA0 = 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
@@ -81,6 +86,17 @@ struct PlaneSeq {
   u4 fs_n;
   f4 ws_n, cp_n, al_n, aup_n;
   int fx0_n, fx1_n;
+  // split gather source only (an empty struct otherwise: members the other instantiations must not carry -- new members next
+  // to the old ones changed how the compiler packs them and cost every instantiation 5 registers)
+  struct SplitOn {
+    int planes_a;    // planes of the gather source in LDS at a time: the first half's
+    float *src_b;    // the second half of the running frame's gather source (workspace)
+    float *parked;   // the first walk's row sums, [position] (workspace)
+    f4 part_n;       // the next plane's parked row sums
+    f4 al_n;         // forward: the next plane's parked alpha'_{t-1} (planes of the first half)
+  };
+  struct SplitOff {};
+  std::conditional_t<SPLIT, SplitOn, SplitOff> sp;
 #ifdef TC_PHASE_STAMPS
   long long st_prev, st_acc[8];
 #endif
@@ -95,7 +111,13 @@ struct PlaneSeq {
         r_ws(make_rsrc(pp.tied_w, 4u * (uint32_t)(pp.L.Hs + 4))), leaky(pp.leaky), hist_step((int64_t)pp.S * pp.L.Hs),
         hist(pp.alpha_hist + (int64_t)seq * pp.L.Hs), fn(pp.fwd_norm ? pp.fwd_norm + (int64_t)seq * (pp.T + 2) : nullptr),
         bn(pp.bwd_norm ? pp.bwd_norm + (int64_t)seq * (pp.T + 1) : nullptr),
-        bhist(pp.beta_hist ? pp.beta_hist + (int64_t)seq * pp.L.Hs : nullptr) {}
+        bhist(pp.beta_hist ? pp.beta_hist + (int64_t)seq * pp.L.Hs : nullptr) {
+    if constexpr (SPLIT) {
+      sp.planes_a = pp.L.src_planes;
+      sp.src_b = pp.src_scratch + (int64_t)seq * (4 * kThreads) * (pp.L.JV - pp.L.src_planes);
+      sp.parked = pp.part_scratch + (int64_t)seq * (pp.L.Hs + 4 * kThreads * pp.L.src_planes);
+    }
+  }
 
   __device__ __forceinline__ rsrc_t hist_row(int t) const { return make_rsrc(hist + (int64_t)t * hist_step, 4u * Hs); }
   __device__ __forceinline__ rsrc_t bhist_row(int t) const { return make_rsrc(bhist + (int64_t)t * hist_step, 4u * Hs); }
@@ -148,7 +170,7 @@ struct PlaneSeq {
   // ---- one direction's stream: descriptor, row-end bytes (four chunks to a word, word i in lane i), the chunk at which each
   // sub-stream ends (sub-stream i in lane i), the wave's first secondary row
   __device__ __forceinline__ void stream_begin(const ScheduleDev &sc) {
-    const int subs = planes + 1;
+    const int subs = (SPLIT ? 2 : 1) * (planes + 1);
     const int2 r0 = sc.wave_range[wave * subs], r1 = sc.wave_range[wave * subs + subs - 1];
     total = __builtin_amdgcn_readfirstlane(r1.y) / kChunk;
     // (the descriptor covers the look-ahead past the wave's last chunk: the array ends with readable padding)
@@ -187,46 +209,128 @@ struct PlaneSeq {
   // -- two workgroups per sequence, half the CUs' L1s on one stream each -- 4.24 -> 4.89)
   static constexpr int kBuffers = BUF;
   // (the first requests of a frame, ahead of its barrier)
-  __device__ __forceinline__ void request_first(Chunk6 (&q)[kBuffers]) {
+  // (half: which of a split source's two walks; its first chunk is where the first walk's last sub-stream ends)
+  __device__ __forceinline__ int first_chunk(int half) const {
+    return SPLIT && half ? __builtin_amdgcn_readlane((int)ends, planes) : 0;
+  }
+  __device__ __forceinline__ void request_first(Chunk6 (&q)[kBuffers], int half = 0) {
+    const int c0 = first_chunk(half);
 #pragma unroll
-    for (int k = 0; k + 1 < kBuffers; ++k) load_chunk(q[k], base, lane16, k);
+    for (int k = 0; k + 1 < kBuffers; ++k) load_chunk(q[k], base, lane16, c0 + k);
   }
   template <class Pass>
-  __device__ __forceinline__ void run_stream(Chunk6 (&q)[kBuffers], Pass pass) {
-    int c = 0, sub = 0;
-    int next_end = __builtin_amdgcn_readlane((int)ends, 0);
-    float acc = 0.f;
-    const RowCommit plane_rows{aACC + 1024u * (uint32_t)wave, sec, 4};
-    RowCommit rc{sec, sec, 1 << 30};  // sub-stream 0: the wave's secondary rows, private slots one after the other
-    if (next_end == 0) {              // (none)
-      sub = 1;
-      rc = plane_rows;
-      next_end = __builtin_amdgcn_readlane((int)ends, 1);
-    }
-    while (c < total) {
+  __device__ __forceinline__ void run_stream(Chunk6 (&q)[kBuffers], Pass pass, int half = 0) {
+    if constexpr (!SPLIT) {
+      // (kept apart from the general form below, word for word as it was: stated through first_chunk() / c_end the same loop
+      // costs the one-walk instantiations five registers)
+      int c = 0, sub = 0;
+      int next_end = __builtin_amdgcn_readlane((int)ends, 0);
+      float acc = 0.f;
+      const RowCommit plane_rows{aACC + 1024u * (uint32_t)wave, sec, 4};
+      RowCommit rc{sec, sec, 1 << 30};  // sub-stream 0: the wave's secondary rows, private slots one after the other
+      if (next_end == 0) {              // (none)
+        sub = 1;
+        rc = plane_rows;
+        next_end = __builtin_amdgcn_readlane((int)ends, 1);
+      }
+      while (c < total) {
 #pragma unroll
-      for (int k = 0; k < kBuffers; ++k) {
-        load_chunk(q[(k + kBuffers - 1) % kBuffers], base, lane16, c + kBuffers - 1);
-        chunk_pw<kA0>(q[k], mask_of(c), acc, rc);
-        ++c;
-        if (c == next_end) {  // the sub-stream of a plane (or the secondary rows) ends here
-          if (sub > 0) pass(sub - 1);
-          ++sub;
-          rc = plane_rows;
-          next_end = sub > planes ? -1 : __builtin_amdgcn_readlane((int)ends, sub <= planes ? sub : 0);
+        for (int k = 0; k < kBuffers; ++k) {
+          load_chunk(q[(k + kBuffers - 1) % kBuffers], base, lane16, c + kBuffers - 1);
+          chunk_pw<kA0>(q[k], mask_of(c), acc, rc);
+          ++c;
+          if (c == next_end) {  // the sub-stream of a plane (or the secondary rows) ends here
+            if (sub > 0) pass(sub - 1);
+            ++sub;
+            rc = plane_rows;
+            next_end = sub > planes ? -1 : __builtin_amdgcn_readlane((int)ends, sub <= planes ? sub : 0);
+          }
+          if (c >= total) break;
         }
-        if (c >= total) break;
+      }
+    } else {
+      const int s0 = half ? planes + 1 : 0;  // the walk's first sub-stream
+      int c = first_chunk(half), sub = 0;
+      const int c_end = __builtin_amdgcn_readlane((int)ends, s0 + planes);
+      int next_end = __builtin_amdgcn_readlane((int)ends, s0);
+      float acc = 0.f;
+      const RowCommit plane_rows{aACC + 1024u * (uint32_t)wave, sec, 4};
+      RowCommit rc{sec, sec, 1 << 30};
+      if (next_end == c) {  // (no secondary rows)
+        sub = 1;
+        rc = plane_rows;
+        next_end = __builtin_amdgcn_readlane((int)ends, s0 + 1);
+      }
+      while (c < c_end) {
+#pragma unroll
+        for (int k = 0; k < kBuffers; ++k) {
+          load_chunk(q[(k + kBuffers - 1) % kBuffers], base, lane16, c + kBuffers - 1);
+          chunk_pw<kA0>(q[k], mask_of(c), acc, rc);
+          ++c;
+          if (c == next_end) {
+            if (sub > 0) pass(sub - 1);
+            ++sub;
+            rc = plane_rows;
+            next_end = sub > planes ? -1 : __builtin_amdgcn_readlane((int)ends, s0 + (sub <= planes ? sub : 0));
+          }
+          if (c >= c_end) break;
+        }
       }
     }
   }
 
-  // the fix-up list of (this thread, plane): secondary rows of its hub states, folded into the plane's row sums
-  __device__ __forceinline__ void request_fix(int j) {
+  // the fix-up list of (this thread, plane[, half]): secondary rows of its hub states, folded into the plane's row sums
+  __device__ __forceinline__ void request_fix(int j, int half = 0) {
     fx0_n = fx1_n = 0;
     if (nfix) {
-      fx0_n = fix_begin[(int)tid * planes + j];
-      fx1_n = fix_begin[(int)tid * planes + j + 1];
+      const int at = ((SPLIT && half ? kThreads : 0) + (int)tid) * planes + j;
+      fx0_n = fix_begin[at];
+      fx1_n = fix_begin[at + 1];
     }
+  }
+
+  // ---- split gather source: the first walk of a frame (both directions).  Its per-plane pass parks the plane's row sums;
+  // behind it the second half of the source replaces the first in LDS (two barriers: every wave has left the first half,
+  // the second is complete).  q leaves requested for the second walk.
+  // FORWARD: the forward per-state pass also needs alpha'_{t-1} of the OWNED states (the self-loop term); for the planes of
+  // the first half that is in LDS only now, so it is parked too.
+  template <bool FORWARD>
+  __device__ __forceinline__ void first_walk(Chunk6 (&q)[kBuffers]) {
+    const rsrc_t r_part = part_rsrc();
+    run_stream(q, [&](int j) __attribute__((always_inline)) {
+      const int fx0 = fx0_n, fx1 = fx1_n;
+      for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
+      bst4_aux<0>(r_part, own16 + (uint32_t)j * kPlane, own_rows(vrow, 0));
+      if (FORWARD && j < sp.planes_a) bst4_aux<0>(r_part, own16 + (uint32_t)j * kPlane + 4u * (uint32_t)Hs, lds4(kA0 + own16 + (uint32_t)j * kPlane));
+      request_fix(j + 1 < planes ? j + 1 : j, 0);
+    }, 0);
+    request_first(q, 1);
+    const rsrc_t r_src = make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a));
+    f4 sb[(MAXP + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < (MAXP + 1) / 2; ++j) sb[j] = bld4(r_src, own16, j * kPlane);  // (beyond the half's planes: zeros)
+    __syncthreads();  // every wave has gathered its last value of the first half
+#pragma unroll
+    for (int j = 0; j < (MAXP + 1) / 2; ++j)
+      if (j < planes - sp.planes_a) lds4_st(kA0 + own16 + j * kPlane, sb[j]);
+    __syncthreads();  // the second half is in place
+  }
+  // a plane's value of the next frame's gather source: the first half's planes to LDS, the others to the workspace
+  __device__ __forceinline__ void source_st(int j, f4 v) {
+    if constexpr (SPLIT) {
+      if (j < sp.planes_a)
+        lds4_st(kA0 + own16 + j * kPlane, v);
+      else
+        bst4_aux<0>(make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a)), own16 + (uint32_t)(j - sp.planes_a) * kPlane, v);
+    } else {
+      lds4_st(kA0 + own16 + j * kPlane, v);
+    }
+  }
+  __device__ __forceinline__ rsrc_t part_rsrc() const {
+    if constexpr (SPLIT)  // [row sums of every plane | alpha'_{t-1} of the first half's planes]
+      return make_rsrc(sp.parked, 4u * (uint32_t)Hs + 16u * kThreads * (uint32_t)sp.planes_a);
+    else
+      return make_rsrc(hist, 0u);
   }
 
   // ================================================================================================== forward
@@ -239,7 +343,7 @@ struct PlaneSeq {
     for (int j = 0; j < planes; ++j) {
       const f4 pi4 = bld4(r_pi, own16, j * kPlane);
       bst4_aux<0>(h0, own16 + j * kPlane, pi4);  // the history keeps alpha UN-dashed
-      lds4_st(kA0 + own16 + j * kPlane, pi4 + (leaky * pi4) * asum);
+      source_st(j, pi4 + (leaky * pi4) * asum);
     }
     y2 = 0.f;
     if (own_pdfs()) {
@@ -267,8 +371,10 @@ struct PlaneSeq {
   __device__ __forceinline__ void forward_frame(int t) {
     Chunk6 q[kBuffers];
     request_first(q);
-    fs_n = bld4u(r_fs, own16, 0);
-    ws_n = bld4(r_ws, own16, 0);
+    if (!SPLIT) {
+      fs_n = bld4u(r_fs, own16, 0);
+      ws_n = bld4(r_ws, own16, 0);
+    }
     request_fix(0);
     const rsrc_t brow = GAMMA ? bhist_row(t) : make_rsrc(hist, 0u);
     if (GAMMA) bt_n = bld4(brow, own16, 0);
@@ -281,6 +387,15 @@ struct PlaneSeq {
     f4 yreg = mk4(0.f);
     if (t < T) yreg = row_ld(make_rsrc(p.y + ((int64_t)t * S + s) * p.y_stride, row_bytes), own16, p.y_vec);  // y_t under the walks
     const rsrc_t hist_t = hist_row(t);
+    const rsrc_t r_part = part_rsrc();
+    if constexpr (SPLIT) {
+      first_walk<true>(q);  // the cells whose source lies in the first half; the second half of alpha'_{t-1} is in LDS behind it
+      fs_n = bld4u(r_fs, own16, 0);
+      ws_n = bld4(r_ws, own16, 0);
+      sp.part_n = bld4(r_part, own16, 0);
+      sp.al_n = bld4(r_part, own16, 4u * (uint32_t)Hs);
+      request_fix(0, 1);
+    }
     part = 0.f;
     run_stream(q, [&](int j) __attribute__((always_inline)) {
       TC_STAMP(2)
@@ -289,8 +404,15 @@ struct PlaneSeq {
       const f4 ws = ws_n;
       const int fx0 = fx0_n, fx1 = fx1_n;
       for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
-      const f4 F = own_rows(vrow, 0);
-      const f4 al = lds4(kA0 + own16 + pj);  // alpha'_{t-1} of the owned states
+      f4 F = own_rows(vrow, 0);
+      f4 al;  // alpha'_{t-1} of the owned states
+      if constexpr (SPLIT) {
+        F += sp.part_n;
+        // (the second half's planes are what LDS holds now; the first half's were parked by the first walk)
+        al = j < sp.planes_a ? sp.al_n : lds4(kA0 + own16 + (uint32_t)(j - sp.planes_a < 0 ? 0 : j - sp.planes_a) * kPlane);
+      } else {
+        al = lds4(kA0 + own16 + pj);
+      }
       const f4 bt = bt_n;
       const f4 a = f4{tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.x, ws.x, F.x, al.x, bt.x, gs, dpart),
                       tied_fwd_state<GAMMA>(kPB, aGM, inv_prev, fs.y, ws.y, F.y, al.y, bt.y, gs, dpart),
@@ -304,10 +426,14 @@ struct PlaneSeq {
         fs_n = bld4u(r_fs, own16, (uint32_t)jn * kPlane);
         ws_n = bld4(r_ws, own16, (uint32_t)jn * kPlane);
         if (GAMMA) bt_n = bld4(brow, own16, (uint32_t)jn * kPlane);
-        request_fix(jn);
+        if constexpr (SPLIT) {
+          sp.part_n = bld4(r_part, own16, (uint32_t)jn * kPlane);
+          sp.al_n = bld4(r_part, own16, (uint32_t)(jn < sp.planes_a ? jn : 0) * kPlane + 4u * (uint32_t)Hs);
+        }
+        request_fix(jn, SPLIT ? 1 : 0);
       }
       TC_STAMP(3)
-    });
+    }, SPLIT ? 1 : 0);
     // alpha'_t = alpha_t + leaky * pi * asum_t: pi comes back from L2 while the block sum forms
     // (requests of planes the graph does not have lie beyond their descriptors and return zeros: every element of the
     // array is assigned unconditionally -- assigned under a condition, the compiler carries such an array through the
@@ -328,7 +454,7 @@ struct PlaneSeq {
     for (int j = 0; j < kMaxPlanes; ++j)
       if (j < planes) {
         const f4 a = R[j] + (leaky * cp[j]) * asum;
-        lds4_st(kA0 + own16 + j * kPlane, a);
+        source_st(j, a);
         part_tot += hsum(a);
       }
     if (GAMMA) {
@@ -395,8 +521,8 @@ struct PlaneSeq {
       R[j] = b;
       if (j < planes) {
         if (PURE) bst4_aux<0>(bhist_row(T), own16 + j * kPlane, b);  // B_T
-        lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
-                                             b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
+        source_st(j, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
+                        b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
       }
     }
     stamps_reset();
@@ -404,7 +530,7 @@ struct PlaneSeq {
 
   // the values of plane j a backward pass needs from memory: tables, alpha_t, alpha_{t+1}  (PURE: no alpha)
   template <bool PURE>
-  __device__ __forceinline__ void request_bwd(int j, const rsrc_t &hist_t, const rsrc_t &hist_up) {
+  __device__ __forceinline__ void request_bwd(int j, const rsrc_t &hist_t, const rsrc_t &hist_up, int half = 0) {
     const uint32_t pj = (uint32_t)j * kPlane;
     fs_n = bld4u(r_fs, own16, pj);
     ws_n = bld4(r_ws, own16, pj);
@@ -413,7 +539,7 @@ struct PlaneSeq {
       al_n = bld4_aux<TC_PW_AL_AUX>(hist_t, own16, pj);
       aup_n = bld4_aux<TC_PW_AUP_AUX>(hist_up, own16, pj);
     }
-    request_fix(j);
+    request_fix(j, half);
   }
 
   // frame t = T-1..0   ([K] BetaDashGeneralFrame(t) + Beta(t)); returns true after frame 0.
@@ -423,13 +549,22 @@ struct PlaneSeq {
     Chunk6 q[kBuffers];
     request_first(q);
     const rsrc_t hist_t = hist_row(t), hist_up = hist_row(t + 1);
-    request_bwd<PURE>(0, hist_t, hist_up);
+    const rsrc_t r_part = part_rsrc();
+    if (!SPLIT)
+      request_bwd<PURE>(0, hist_t, hist_up);
+    else
+      request_fix(0, 0);
     float asum_t = 1.f;
     if (!PURE && asums.g) asum_t = asums.ld(t);  // (from the workspace: requested ahead of the barrier)
     __syncthreads();  // Y, exp(y_t) ready; gamma zero
     TC_STAMP(0)
     if (!PURE && !asums.g) asum_t = asums.ld(t);
     const float inv_as = __builtin_amdgcn_rcpf(asum_t);
+    if constexpr (SPLIT) {
+      first_walk<false>(q);  // the cells whose destination lies in the first half; the second half of Y_t is in LDS behind it
+      request_bwd<PURE>(0, hist_t, hist_up, 1);
+      sp.part_n = bld4(r_part, own16, 0);
+    }
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f, part_u = 0.f;
     run_stream(q, [&](int j) __attribute__((always_inline)) {
@@ -441,6 +576,7 @@ struct PlaneSeq {
       const int fx0 = fx0_n, fx1 = fx1_n;
       for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
       f4 a = own_rows(vrow, 0);
+      if constexpr (SPLIT) a += sp.part_n;
       a.x = tied_bwd_state<PURE>(kPB, aGM, fs.x, ws.x, bo.x, al.x, aup.x, 0.f, a.x, inv_as, 0.f);
       a.y = tied_bwd_state<PURE>(kPB, aGM, fs.y, ws.y, bo.y, al.y, aup.y, 0.f, a.y, inv_as, 0.f);
       a.z = tied_bwd_state<PURE>(kPB, aGM, fs.z, ws.z, bo.z, al.z, aup.z, 0.f, a.z, inv_as, 0.f);
@@ -452,9 +588,10 @@ struct PlaneSeq {
       rset(j, b);  // (beta_{t+1} of the plane has just been used)
       // the next plane's values, requested behind this plane's arithmetic (both sets at once do not fit the registers) and
       // a whole sub-stream ahead of their use; index clamped: every request of the frame is unconditional
-      request_bwd<PURE>(j + 1 < planes ? j + 1 : j, hist_t, hist_up);
+      request_bwd<PURE>(j + 1 < planes ? j + 1 : j, hist_t, hist_up, SPLIT ? 1 : 0);
+      if constexpr (SPLIT) sp.part_n = bld4(r_part, own16, (uint32_t)(j + 1 < planes ? j + 1 : j) * kPlane);
       TC_STAMP(3)
-    });
+    }, SPLIT ? 1 : 0);
     // beta'_t and the forward pdfs again, for the Y update behind the two barriers
     // y_{t-1} (at t == 0 frame 0 again) for the next frame's exp(y), y_t once more for the derivative row's l2 term (this CU
     // read it a frame ago: L2) -- requested here rather than held in registers through the walks
@@ -506,8 +643,8 @@ struct PlaneSeq {
       R[j] = b;  // beta_t (B_t) for the next frame's passes
       if (j < planes) {
         if (PURE) bst4_aux<0>(bhist_row(t), own16 + j * kPlane, b);  // B_t for the partner
-        lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
-                                             b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
+        source_st(j, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
+                        b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
       }
     }
     TC_STAMP(4)
@@ -515,9 +652,9 @@ struct PlaneSeq {
   }
 };
 
-template <bool ACCUM, bool WANT_DERIV, int MAXP>
+template <bool ACCUM, bool WANT_DERIV, int MAXP, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenParams p) {
-  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_FUSED> q(p, (int)blockIdx.x);
+  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_FUSED, SPLIT> q(p, (int)blockIdx.x);
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
   q.forward_begin();
@@ -599,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void den_tied_planes_mitm_kernel(const De
 }  // namespace
 
 bool planes_mitm_fits(const DenParams &p) {
-  return p.L.planewise && !p.L.asum_global && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
+  return p.L.planewise && !p.L.asum_global && p.L.src_planes == p.L.JV && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
          (size_t)layout_lds_bytes(p.L, p.T) + 16u <= (size_t)kLdsLimitBytes;
 }
 
@@ -624,9 +761,15 @@ int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t 
 
 int launch_den_tied_planes(const DenParams &p, int accumulate, hipStream_t stream) {
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T);
-  if (!p.L.planewise || lds > (size_t)kLdsLimitBytes || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanes) return TC_ERR_UNSUPPORTED;
+  if (!p.L.planewise || lds > (size_t)kLdsLimitBytes || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanesSplit) return TC_ERR_UNSUPPORTED;
   void (*k)(const DenParams) = nullptr;
-  if (p.L.JV <= 6) {
+  if (p.L.src_planes < p.L.JV) {  // split gather source (28673..40960 positions)
+    if (!p.src_scratch || !p.part_scratch) return TC_ERR_WORKSPACE;
+    if (!p.deriv)
+      k = den_tied_planes_kernel<false, false, kJvPlanesSplit, true>;
+    else
+      k = accumulate ? den_tied_planes_kernel<true, true, kJvPlanesSplit, true> : den_tied_planes_kernel<false, true, kJvPlanesSplit, true>;
+  } else if (p.L.JV <= 6) {
     if (!p.deriv)
       k = den_tied_planes_kernel<false, false, 6>;
     else

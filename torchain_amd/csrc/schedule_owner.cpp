@@ -35,48 +35,60 @@ struct OwnerTask {
 
 // pdf != nullptr: GENERAL graphs (den_general_owner.hip) -- a cell also carries the LDS offset of its arc's pdf in exp(y)
 // (8-byte cells: {w, position * 4 | pdf * 4 << 16}), and the placement inside a half-slot weighs both gathers' banks.
+// slots_b != nullptr: split gather source (chain_internal.h: kJvPlanesSplit) -- `slots` holds the rows' cells whose source lies
+// below position `half_pos`, `slots_b` the others; a wave's stream is [sub-streams of the first half | of the second].
 static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std::vector<OwnerTask>>> &slots,
                               const std::vector<int64_t> &order, const int32_t *opos, const float *prob,
-                              ScheduleHost *out, bool planewise, bool count_only, const int32_t *pdf = nullptr, int num_pdfs = 1) {
+                              ScheduleHost *out, bool planewise, bool count_only, const int32_t *pdf = nullptr, int num_pdfs = 1,
+                              const std::vector<std::vector<std::vector<OwnerTask>>> *slots_b = nullptr, int half_pos = 0) {
+  const int halves = slots_b ? 2 : 1;
+  auto slots_of = [&](int hv) -> const std::vector<std::vector<std::vector<OwnerTask>>> & { return hv ? *slots_b : slots; };
   // slots[w][k] = 64 tasks (lane order); k >= K are secondary rows.  count_only: the number of cells alone (padded_arcs)
   if (count_only) {
     int64_t cells = 0;
-    for (int w = 0; w < kWaves; ++w) {
-      int64_t in_sub = 0;
-      auto close_sub = [&]() {
-        cells += (in_sub + kStreamUnrollTied - 1) / kStreamUnrollTied * kStreamUnrollTied * 64;
-        in_sub = 0;
-      };
-      for (size_t k = 0; k < slots[w].size(); ++k) {
-        int steps = 1;
-        for (const OwnerTask &t : slots[w][k]) steps = std::max(steps, t.len);
-        in_sub += steps;
-        if (planewise && (k + 1 == slots[w].size() || ((int)k < K && k % 4 == 3))) close_sub();
+    for (int hv = 0; hv < halves; ++hv)
+      for (int w = 0; w < kWaves; ++w) {
+        const auto &sl = slots_of(hv)[w];
+        int64_t in_sub = 0;
+        auto close_sub = [&]() {
+          cells += (in_sub + kStreamUnrollTied - 1) / kStreamUnrollTied * kStreamUnrollTied * 64;
+          in_sub = 0;
+        };
+        for (size_t k = 0; k < sl.size(); ++k) {
+          int steps = 1;
+          for (const OwnerTask &t : sl[k]) steps = std::max(steps, t.len);
+          in_sub += steps;
+          if (planewise && (k + 1 == sl.size() || ((int)k < K && k % 4 == 3))) close_sub();
+        }
+        close_sub();
       }
-      close_sub();
-    }
     out->padded_arcs = cells;
     return;
   }
   out->conflict_cost = out->conflict_free_cost = out->conflict_bound = 0;
   out->cells.clear();
   // plane-wise form: per wave, sub-stream 0 = its secondary rows, sub-stream 1 + j = the four rows of plane j
-  const int subs = planewise ? K / 4 + 1 : 1;
-  const int off_shift = planewise ? 16 : 18;  // the cell's 16-bit offset field: position, or position * 4
-  out->subs = planewise ? subs : 0;
+  const int subs_half = planewise ? K / 4 + 1 : 1;  // sub-streams per half of the gather source
+  const int subs = subs_half * halves;
+  const int off_shift = planewise ? 16 : 18;  // the cell's 16-bit offset field: position (inside its half), or position * 4
+  out->subs = planewise ? subs_half : 0;
+  out->halves = halves;
   out->wave_range.assign((size_t)kWaves * subs, make_int2(0, 0));
   std::vector<std::vector<uint32_t>> wave_masks((size_t)kWaves * subs);
   int64_t arc_cells = 0;
   int nrows = 0;
   for (int w = 0; w < kWaves; ++w)
-    for (int sub = 0; sub < subs; ++sub) {
+    for (int sub_all = 0; sub_all < subs; ++sub_all) {
+      const int hv = sub_all / subs_half, sub = sub_all % subs_half;
+      const auto &wslots = slots_of(hv)[w];
+      const int32_t pos_base = hv ? half_pos : 0;
       const size_t first = out->cells.size() / 64;
       size_t cells_before = 0;
       std::vector<char> row_end;  // per pair of this stream: flags A | B
       const size_t k0 = !planewise ? 0 : sub == 0 ? (size_t)K : (size_t)4 * (sub - 1);
-      const size_t k1 = !planewise ? slots[w].size() : sub == 0 ? slots[w].size() : (size_t)4 * sub;
+      const size_t k1 = !planewise ? wslots.size() : sub == 0 ? wslots.size() : (size_t)4 * sub;
       for (size_t k = k0; k < k1; ++k) {
-        const auto &tasks = slots[w][k];
+        const auto &tasks = wslots[k];
         int steps = 1;  // rows need not be whole pairs: a pair may straddle two rows (flag A below)
         for (const OwnerTask &t : tasks) steps = std::max(steps, t.len);
         const size_t off = out->cells.size();
@@ -107,7 +119,7 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
               ArcRec &cell = out->cells[off + (size_t)i * 64 + lane];
               if (pos[l][i] >= 0) {
                 const int64_t a = lane_arcs[l][pos[l][i]];
-                cell = ArcRec{prob[a], (uint32_t)opos[a] << off_shift};
+                cell = ArcRec{prob[a], (uint32_t)(opos[a] - pos_base) << off_shift};
                 if (pdf) cell.idx = ((uint32_t)opos[a] << 2) | ((uint32_t)pdf[a] << 18);
               } else {
                 // padding: w = 0, gathered from a bank that is idle in this step
@@ -130,14 +142,14 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
         for (int l = 0; l < 64; ++l) out->cells.push_back(ArcRec{0.f, pdf ? ((uint32_t)l << 2) | ((uint32_t)(l % std::max(1, num_pdfs)) << 18) : 0u});
       row_end.resize((out->cells.size() / 64 - first + 1) / 2, 0);  // the padding cells end no row
       if (debug_flag(kDbgSchedTrace))
-        fprintf(stderr, "[sched] wave %d sub %d: %zu cells, %zu rows\n", w, sub, out->cells.size() / 64 - first, k1 - k0);
+        fprintf(stderr, "[sched] wave %d half %d sub %d: %zu cells, %zu rows\n", w, hv, sub, out->cells.size() / 64 - first, k1 - k0);
       if (planewise) {
         // one stream per wave, cut at chunk boundaries: {first cell of the sub-stream, its END counted from the wave's first
         // cell}, and ONE byte of row-end bits per chunk (bit i: a row ends with cell i), four chunks to a word
         const size_t wave_first = (size_t)out->wave_range[(size_t)w * subs].x;
-        const size_t rel = sub == 0 ? 0 : first - wave_first;
-        if (sub == 0) out->wave_range[(size_t)w * subs].x = (int)first;
-        out->wave_range[(size_t)w * subs + sub] = make_int2((int)first, (int)(rel + out->cells.size() / 64 - first));
+        const size_t rel = sub_all == 0 ? 0 : first - wave_first;
+        if (sub_all == 0) out->wave_range[(size_t)w * subs].x = (int)first;
+        out->wave_range[(size_t)w * subs + sub_all] = make_int2((int)first, (int)(rel + out->cells.size() / 64 - first));
         auto &mw = wave_masks[(size_t)w * subs];  // (the wave's words: index 0 of its sub-streams)
         mw.resize((rel + out->cells.size() / 64 - first) / 8 / 4 + 1, 0u);
         for (size_t i = 0; i < row_end.size(); ++i)
@@ -147,8 +159,8 @@ static void emit_owner_stream(int Npos, int K, const std::vector<std::vector<std
               mw[chunk / 4] |= 1u << (8 * (chunk % 4) + cell % 8);
             }
       } else {
-        out->wave_range[(size_t)w * subs + sub] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
-        auto &mw = wave_masks[(size_t)w * subs + sub];
+        out->wave_range[(size_t)w * subs + sub_all] = make_int2((int)first, (int)(out->cells.size() / 64 - first));
+        auto &mw = wave_masks[(size_t)w * subs + sub_all];
         mw.assign((row_end.size() + 7) / 8, 0u);
         for (size_t i = 0; i < row_end.size(); ++i) {
           if (row_end[i] & 1) mw[i / 8] |= 1u << (i % 8);        // B flags: bits 0..7
@@ -229,7 +241,12 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   // (measured on graphs the 12- / 16-states-per-thread kernels hold: the plane-wise form is 40 % slower there -- X1 6.6 vs 4.7 ms,
   // R2 6.3 vs 4.5, R3 4.9 vs 3.4 --, its per-state values go through L2 where theirs sit in registers)
   const bool planewise = Npos > kMaxIndex;
-  if (Npos > kMaxPlanePositions || (planewise && debug_flag(kDbgNoPlanes))) return false;
+  if (Npos > kMaxSplitPositions || (planewise && debug_flag(kDbgNoPlanes))) return false;
+  // beyond kMaxPlanePositions the gather source is in LDS a half at a time: every row is cut into the cells whose source
+  // lies in the first ceil(planes / 2) planes and the others (chain_internal.h: kJvPlanesSplit)
+  const bool split_src = Npos > kMaxPlanePositions && !debug_flag(kDbgNoSplitSrc);
+  if (Npos > kMaxPlanePositions && !split_src) return false;
+  const int half_pos = split_src ? 4096 * ((Npos / 4096 + 1) / 2) : 0;
   // general graphs (den_general_owner.hip): 8 states per thread, alpha'_t of the owned states in LDS
   if (general && Npos > 4 * kThreads * kJvSmall) return false;
   const int K = Npos / kThreads;
@@ -256,14 +273,125 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   sort_by(src, &out_first, &out_order);
   auto deg = [](const std::vector<int64_t> &first, int h) { return (int)(first[h + 1] - first[h]); };
 
+  // ---- split gather source: which states live in the first half of the positions.  A row is walked in two parts -- the cells
+  // whose source lies in the first half, then the others -- and the 64 rows of a slot run in lockstep, so a part costs its
+  // slot the LONGEST of 64.  Halves dealt without regard to the arcs make the parts Binomial(length, 1/2): X2's 360 000 cells
+  // took 625 000 slots.  So the states are first divided such that every row's two parts are as equal as the graph allows: a
+  // local search on the sum over all rows (both directions) of (first part - second part)^2.
+  std::vector<char> in_b(H, 0);  // 1: the state lives in the second half
+  const int planes_all = Npos / 4096, planes_first = (planes_all + 1) / 2;
+  int n_first = H;
+  if (split_src) {
+    n_first = std::min<int64_t>(half_pos, std::max<int64_t>((int64_t)H - (Npos - half_pos), ((int64_t)H * planes_first + planes_all - 1) / planes_all));
+    for (int h = n_first; h < H; ++h) in_b[h] = 1;  // (FST order to start with)
+    std::vector<int32_t> d_in(H, 0), d_out(H, 0);    // per row: cells with the source in the first half minus the others
+    for (int64_t a = 0; a < A2; ++a) {
+      d_in[dst[a]] += in_b[src[a]] ? -1 : 1;
+      d_out[src[a]] += in_b[dst[a]] ? -1 : 1;
+    }
+    // moving state u to the other half changes d by -+2 in every row that gathers u
+    auto move_delta = [&](int u, int sign, bool apply) {  // sign = -1: u leaves the first half
+      int64_t delta = 0;
+      for (int64_t i = out_first[u]; i < out_first[u + 1]; ++i) {  // arcs u -> x: the in-row of x gathers u
+        int32_t &d = d_in[dst[out_order[i]]];
+        delta += (int64_t)(d + 2 * sign) * (d + 2 * sign) - (int64_t)d * d;
+        if (apply) d += 2 * sign;
+      }
+      for (int64_t i = in_first[u]; i < in_first[u + 1]; ++i) {  // arcs x -> u: the out-row of x gathers u
+        int32_t &d = d_out[src[in_order[i]]];
+        delta += (int64_t)(d + 2 * sign) * (d + 2 * sign) - (int64_t)d * d;
+        if (apply) d += 2 * sign;
+      }
+      return delta;
+    };
+    uint64_t rng = 0xA0761D6478BD642Full;
+    auto next = [&]() {
+      rng ^= rng << 13;
+      rng ^= rng >> 7;
+      rng ^= rng << 17;
+      return rng;
+    };
+    // Single moves inside the slack the phantom positions leave (a half may hold any number of states up to its positions),
+    // swept over the states in random order until a sweep finds nothing, then trades of two states of different halves.
+    // How far it gets: a blind deal leaves a mean squared difference of 9 per row on X2 (rows of 9 cells: Binomial), this
+    // search 2.9; trades alone, ten times as many proposals or annealing end between 2.6 and 2.9 as well -- 80 000 rows
+    // constrain 40 000 binary choices, so most rows cannot be even.  X2's 360 000 cells take 510 000 slots (blind: 625 000).
+    int64_t accepted = 0, count[2] = {n_first, H - n_first};
+    const int64_t room[2] = {half_pos, Npos - half_pos};
+    std::vector<int32_t> visit(H);
+    std::iota(visit.begin(), visit.end(), 0);
+    const int sweeps = count_only ? 4 : 40;
+    for (int sweep = 0; sweep < sweeps; ++sweep) {
+      for (int i = H - 1; i > 0; --i) std::swap(visit[i], visit[(size_t)(next() % (uint64_t)(i + 1))]);
+      int64_t moved = 0;
+      for (int u : visit) {
+        const int to = in_b[u] ? 0 : 1;
+        if (count[to] >= room[to]) continue;
+        const int su = in_b[u] ? 1 : -1;
+        const int64_t du = move_delta(u, su, false);
+        if (du < 0 || (du == 0 && (next() & 7) == 0)) {
+          move_delta(u, su, true);
+          in_b[u] = (char)to;
+          count[to]++;
+          count[1 - to]--;
+          ++moved;
+        }
+      }
+      accepted += moved;
+      if (moved == 0) break;
+    }
+    const int64_t proposals = count_only ? 0 : (int64_t)H * 50;
+    for (int64_t it = 0; it < proposals; ++it) {
+      const uint64_t r = next();
+      const int u = (int)(r % (uint64_t)H), v = (int)((r >> 32) % (uint64_t)H);
+      if (in_b[u] == in_b[v]) continue;
+      const int su = in_b[u] ? 1 : -1;  // u moves to the other half, v the opposite way
+      // (apply u's move first: the two may gather each other or share a row)
+      const int64_t du = move_delta(u, su, true), dv = move_delta(v, -su, true);
+      if (du + dv < 0) {
+        std::swap(in_b[u], in_b[v]);
+        ++accepted;
+      } else {
+        move_delta(v, su, true);
+        move_delta(u, -su, true);
+      }
+    }
+    if (debug_flag(kDbgSchedTrace)) {
+      int64_t sq = 0;
+      for (int h = 0; h < H; ++h) sq += (int64_t)d_in[h] * d_in[h] + (int64_t)d_out[h] * d_out[h];
+      fprintf(stderr, "[sched] split source: %lld moves and trades taken, sum of squared part differences %lld over %d rows, %lld + %lld states\n",
+              (long long)accepted, (long long)sq, 2 * H, (long long)count[0], (long long)count[1]);
+    }
+  }
+  // the length a row costs its slot: the whole row, or (split source) its two parts one after the other
+  std::vector<int32_t> len_in(H), len_out(H);
+  for (int h = 0; h < H; ++h) {
+    len_in[h] = std::min(deg(in_first, h), max_row);
+    len_out[h] = std::min(deg(out_first, h), max_row);
+  }
+  std::vector<int32_t> part_in[2], part_out[2];  // split source: cells of the row by the half of their source
+  if (split_src) {
+    for (int hv = 0; hv < 2; ++hv) {
+      part_in[hv].assign(H, 0);
+      part_out[hv].assign(H, 0);
+    }
+    for (int64_t a = 0; a < A2; ++a) {
+      part_in[(int)in_b[src[a]]][dst[a]]++;
+      part_out[(int)in_b[dst[a]]][src[a]]++;
+    }
+    for (int h = 0; h < H; ++h) {
+      len_in[h] = std::min(part_in[0][h], max_row) + std::min(part_in[1][h], max_row);
+      len_out[h] = std::min(part_out[0][h], max_row) + std::min(part_out[1][h], max_row);
+    }
+  }
+  auto lin = [&](int h) { return (int)len_in[h]; };
+  auto lout = [&](int h) { return (int)len_out[h]; };
+  auto sort_states = [&](std::vector<int32_t> &st) {
+    const int H = (int)st.size();  // (the states of this list)
+    if (H == 0) return;
   // ---- the permutation: sort by primary in-length into a few super-buckets, inside by primary out-length
-  std::vector<int32_t> st(H);
-  std::iota(st.begin(), st.end(), 0);
-  auto lin = [&](int h) { return std::min(deg(in_first, h), max_row); };
-  auto lout = [&](int h) { return std::min(deg(out_first, h), max_row); };
   std::stable_sort(st.begin(), st.end(), [&](int x, int y) { return lin(x) > lin(y); });
-  const int ngroups = Npos / 64;
-  // How many super-buckets: few make the out-lengths of a group uniform, many the in-lengths.  Which matters depends on the
+    // How many super-buckets: few make the out-lengths of a group uniform, many the in-lengths.  Which matters depends on the
   // graph (a phone-LM graph has near-constant out-degrees and in-degrees from 1 to hundreds: sqrt(groups) buckets left 7 % of
   // its forward cells as padding), so a handful of counts is tried and the one with the fewest padded steps kept.
   {
@@ -293,10 +421,28 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
     }
     st.swap(best);
   }
+  };
+  const int ngroups = Npos / 64;
+  std::vector<int32_t> st;
+  if (!split_src) {
+    st.resize(H);
+    std::iota(st.begin(), st.end(), 0);
+    sort_states(st);
+  } else {
+    // each half sorted by itself and padded with phantom states to its share of the positions: [first half | second half]
+    std::vector<int32_t> half_list[2];
+    for (int h = 0; h < H; ++h) half_list[(int)in_b[h]].push_back(h);
+    sort_states(half_list[0]);
+    sort_states(half_list[1]);
+    half_list[0].resize(half_pos, -1);
+    half_list[1].resize(Npos - half_pos, -1);
+    st = half_list[0];
+    st.insert(st.end(), half_list[1].begin(), half_list[1].end());
+  }
   // Inside runs of equal (in, out) length the order is free: use it so that every 32 consecutive states --
   // one half-slot, i.e. the 32 lanes that gather exp(y) at f(g) / s(g) and add gamma there in ONE
   // instruction of the per-state passes -- have distinct pdf banks (greedy, first fit).
-  if (!debug_flag(kDbgNoPdfBanks) && !general) {
+  if (!debug_flag(kDbgNoPdfBanks) && !general && !split_src) {  // (split source: the list has phantoms in its middle)
     auto key = [&](int h) { return lin(h) * 64 + lout(h); };
     int used_f[32], used_s[32];
     size_t run_end = 0;
@@ -331,7 +477,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   // half-slots trade places when neither has longer rows than the other's group already walks (so no walk gains a step) and
   // 64 * (sum over half-slots of max f-bank load + max s-bank load) + (sum of squared loads) does not rise; plateau moves are
   // taken, the squares pull the loads flat so that the maxima can fall later.
-  if (!debug_flag(kDbgNoPdfBanks) && !debug_flag(kDbgNoPdfSearch) && !general && !count_only && H > 64) {  // (the trades keep every group's longest rows: nothing a count-only pass counts changes)
+  if (!debug_flag(kDbgNoPdfBanks) && !debug_flag(kDbgNoPdfSearch) && !general && !count_only && H > 64 && !split_src) {  // (the trades keep every group's longest rows: nothing a count-only pass counts changes)
     const int nhalf = (H + 31) / 32, ngr = (H + 63) / 64;
     std::vector<int> mi(ngr, 1), mo(ngr, 1);
     for (int i = 0; i < H; ++i) {
@@ -424,21 +570,33 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   std::vector<Group> groups(ngroups);
   for (int gi = 0; gi < ngroups; ++gi) {
     int mi = 1, mo = 1;
-    for (int l = 0; l < 64; ++l) {
-      const int h = st[(size_t)gi * 64 + l];
-      if (h < 0) continue;
-      mi = std::max(mi, lin(h));
-      mo = std::max(mo, lout(h));
+    int64_t over_in = 0, over_out = 0;  // its states' arcs beyond max_row become secondary rows of the same wave, 64 to a slot
+    if (!split_src) {
+      for (int l = 0; l < 64; ++l) {
+        const int h = st[(size_t)gi * 64 + l];
+        if (h < 0) continue;
+        mi = std::max(mi, lin(h));
+        mo = std::max(mo, lout(h));
+        over_in += std::max(0, deg(in_first, h) - max_row);
+        over_out += std::max(0, deg(out_first, h) - max_row);
+      }
+    } else {  // the slot's steps: the longest first part + the longest second part of its 64 rows
+      mi = mo = 0;
+      for (int hv = 0; hv < 2; ++hv) {
+        int pi_ = 1, po_ = 1;
+        for (int l = 0; l < 64; ++l) {
+          const int h = st[(size_t)gi * 64 + l];
+          if (h < 0) continue;
+          pi_ = std::max(pi_, std::min(part_in[hv][h], max_row));
+          po_ = std::max(po_, std::min(part_out[hv][h], max_row));
+          over_in += std::max(0, part_in[hv][h] - max_row);
+          over_out += std::max(0, part_out[hv][h] - max_row);
+        }
+        mi += pi_;
+        mo += po_;
+      }
     }
     groups[gi] = Group{gi, mi, mo, mi, mo};
-    // its states' arcs beyond max_row become secondary rows of the same wave, 64 to a slot
-    int64_t over_in = 0, over_out = 0;
-    for (int l = 0; l < 64; ++l) {
-      const int h = st[(size_t)gi * 64 + l];
-      if (h < 0) continue;
-      over_in += std::max(0, deg(in_first, h) - max_row);
-      over_out += std::max(0, deg(out_first, h) - max_row);
-    }
     groups[gi].cin += (int)((over_in + 63) / 64);
     groups[gi].cout += (int)((over_out + 63) / 64);
   }
@@ -463,13 +621,16 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
   std::stable_sort(by_cost.begin(), by_cost.end(), [](const Group &x, const Group &y) { return x.cin + x.cout > y.cin + y.cout; });
   std::vector<std::vector<int>> wave_groups(kWaves);
   std::vector<int64_t> load_in(kWaves, 0), load_out(kWaves, 0);
+  std::vector<int> taken[2] = {std::vector<int>(kWaves, 0), std::vector<int>(kWaves, 0)};
   for (const Group &gr : by_cost) {
     // (round 3, before the issue priorities: shares skewed towards the older waves of each SIMD, which the CU serves first, were measured: no
     // gain -- the walk is bound by the shared stream path, not by any one wave)
     int best = -1;
     double best_t = 0;
+    // (split source: a wave's first 4 * planes_first slots are positions of the first half, and a group is of one half)
+    const int gh = split_src && gr.idx >= half_pos / 64 ? 1 : 0;
     for (int w = 0; w < kWaves; ++w) {
-      if ((int)wave_groups[w].size() >= K) continue;
+      if (!split_src ? (int)wave_groups[w].size() >= K : taken[gh][w] >= (gh ? K - 4 * planes_first : 4 * planes_first)) continue;
       const double tw = (double)std::max(load_in[w] + gr.cin, load_out[w] + gr.cout) / wave_speed[w];
       if (best < 0 || tw < best_t) {
         best = w;
@@ -477,9 +638,13 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
       }
     }
     wave_groups[best].push_back(gr.idx);
+    taken[gh][best]++;
     load_in[best] += gr.cin;
     load_out[best] += gr.cout;
   }
+  if (split_src)  // first-half groups to the front: slot k < 4 * planes_first is a position of the first half
+    for (int w = 0; w < kWaves; ++w)
+      std::stable_partition(wave_groups[w].begin(), wave_groups[w].end(), [&](int gi) { return gi < half_pos / 64; });
   // A wave's stream is padded to whole chunks of 8 steps, and a chunk of padding costs a walk as much as a chunk of arcs:
   // dealt by load alone, 10 of C3's 16 forward streams were 57 steps -- 8 chunks -- long.  Groups trade places between
   // waves while that lowers the number of chunks (first the longest stream's, then the sum over waves and directions).
@@ -560,6 +725,7 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
         for (int a = 0; a < K; ++a)
           for (int b = a + 1; b < K; ++b) {
             if (a / 4 == b / 4) continue;
+            if (split_src && (a / 4 < planes_first) != (b / 4 < planes_first)) continue;  // (a group stays in its half)
             const int before = plane_cost(a / 4) + plane_cost(b / 4);
             std::swap(wg[a], wg[b]);
             if (plane_cost(a / 4) + plane_cost(b / 4) < before)
@@ -687,84 +853,106 @@ bool build_owner(tc_den_graph *g, const std::vector<char> &special, int max_row,
     ScheduleHost *out = dir == 0 ? &g->fwd : &g->bwd;
     std::vector<int32_t> opos(A2);
     for (int64_t a = 0; a < A2; ++a) opos[a] = g->pos[other[a]];
-    std::vector<std::vector<std::vector<OwnerTask>>> slots(kWaves, std::vector<std::vector<OwnerTask>>(K, std::vector<OwnerTask>(64)));
-    // Secondary rows stay on the wave that owns their state: its lanes commit them to private slots and the owner
-    // lane reads them back after the WAVE's walk -- LDS operations of one wave execute in order, so the fold needs
-    // no workgroup barrier and a wave that has finished its walk goes on to its per-state pass while others still
-    // walk (dealt to the least-loaded wave instead, every frame of a graph with popular states paid a barrier at
-    // which the fast waves idled for 1-5 k cycles: profiles/r02_phase_stamps_r3.txt).
-    std::vector<std::vector<OwnerTask>> secondary(kWaves);
-    std::vector<int64_t> load(kWaves, 0);
-    for (int w = 0; w < kWaves; ++w)
-      for (int k = 0; k < K; ++k) {
-        int steps = 1;
-        for (int l = 0; l < 64; ++l) {
-          const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
-          const int h = state_at[p];
-          OwnerTask t{h, 0, 0};
-          if (h >= 0) {
-            const int d = deg(first, h);
-            t.begin = first[h];
-            t.len = std::min(d, max_row);
-            for (int done = t.len; done < d; done += max_row)
-              secondary[w].push_back(OwnerTask{h, first[h] + done, std::min(max_row, d - done)});
-          }
-          slots[w][k][l] = t;
-          steps = std::max(steps, t.len);
-        }
-        load[w] += steps;
+    // Split gather source: a state's list is put in the order [cells whose source lies below half_pos | the others] and
+    // becomes TWO rows, one per half; everything below is done per half (halves == 1: the one "half" is the whole list).
+    const int halves = split_src ? 2 : 1;
+    std::vector<int64_t> order_h(order);
+    std::vector<int32_t> len_a(H, 0);  // cells of the state's list in the first half
+    if (split_src)
+      for (int h = 0; h < H; ++h) {
+        auto b0 = order_h.begin() + first[h], b1 = order_h.begin() + first[h + 1];
+        len_a[h] = (int32_t)(std::stable_partition(b0, b1, [&](int64_t a) { return opos[a] < half_pos; }) - b0);
       }
-    std::vector<std::vector<int2>> fix_of_thread(kThreads);
-    std::vector<int> extra_first(kWaves + 1, 0);
-    std::vector<std::vector<std::vector<OwnerTask>>> sec_slots(kWaves);
-    for (int w = 0; w < kWaves; ++w) {
-      std::vector<OwnerTask> &sec = secondary[w];
-      std::stable_sort(sec.begin(), sec.end(), [](const OwnerTask &x, const OwnerTask &y) { return x.len > y.len; });
-      for (size_t b = 0; b < sec.size(); b += 64) {
-        std::vector<OwnerTask> tasks(64, OwnerTask{-1, 0, 0});
-        for (size_t i = b; i < std::min(sec.size(), b + 64); ++i) tasks[i - b] = sec[i];
-        load[w] += sec[b].len;
-        sec_slots[w].push_back(tasks);
+    auto part_begin = [&](int h, int hv) { return first[h] + (hv ? len_a[h] : 0); };
+    auto part_len = [&](int h, int hv) { return !split_src ? deg(first, h) : hv ? deg(first, h) - len_a[h] : (int)len_a[h]; };
+    std::vector<std::vector<std::vector<OwnerTask>>> slots_h[2];
+    std::vector<std::vector<int2>> fix_of_thread[2];
+    std::vector<std::vector<std::vector<OwnerTask>>> sec_slots_h[2];
+    for (int hv = 0; hv < halves; ++hv) {
+      auto &slots = slots_h[hv];
+      slots.assign(kWaves, std::vector<std::vector<OwnerTask>>(K, std::vector<OwnerTask>(64)));
+      // Secondary rows stay on the wave that owns their state: its lanes commit them to private slots and the owner
+      // lane reads them back after the WAVE's walk -- LDS operations of one wave execute in order, so the fold needs
+      // no workgroup barrier and a wave that has finished its walk goes on to its per-state pass while others still
+      // walk (dealt to the least-loaded wave instead, every frame of a graph with popular states paid a barrier at
+      // which the fast waves idled for 1-5 k cycles: profiles/r02_phase_stamps_r3.txt).
+      std::vector<std::vector<OwnerTask>> secondary(kWaves);
+      for (int w = 0; w < kWaves; ++w)
+        for (int k = 0; k < K; ++k)
+          for (int l = 0; l < 64; ++l) {
+            const int p = 4 * ((64 * w + l) + kThreads * (k >> 2)) + (k & 3);
+            const int h = state_at[p];
+            OwnerTask t{h, 0, 0};
+            if (h >= 0) {
+              const int d = part_len(h, hv);
+              t.begin = part_begin(h, hv);
+              t.len = std::min(d, max_row);
+              for (int done = t.len; done < d; done += max_row)
+                secondary[w].push_back(OwnerTask{h, part_begin(h, hv) + done, std::min(max_row, d - done)});
+            }
+            slots[w][k][l] = t;
+          }
+      sec_slots_h[hv].assign(kWaves, {});
+      for (int w = 0; w < kWaves; ++w) {
+        std::vector<OwnerTask> &sec = secondary[w];
+        std::stable_sort(sec.begin(), sec.end(), [](const OwnerTask &x, const OwnerTask &y) { return x.len > y.len; });
+        for (size_t b = 0; b < sec.size(); b += 64) {
+          std::vector<OwnerTask> tasks(64, OwnerTask{-1, 0, 0});
+          for (size_t i = b; i < std::min(sec.size(), b + 64); ++i) tasks[i - b] = sec[i];
+          sec_slots_h[hv][w].push_back(tasks);
+        }
       }
     }
     // private slots: wave w's j-th secondary row, lane l -> accumulator index Npos + 4 + 64 * (extra_first[w] + j) + l
-    for (int w = 0; w < kWaves; ++w) extra_first[w + 1] = extra_first[w] + (int)sec_slots[w].size();
-    for (int w = 0; w < kWaves; ++w)
-      for (size_t j = 0; j < sec_slots[w].size(); ++j) {
-        for (int l = 0; l < 64; ++l) {
-          const OwnerTask &t = sec_slots[w][j][l];
-          if (t.state < 0) continue;
-          const int p = g->pos[t.state];
-          fix_of_thread[(p >> 2) % kThreads].push_back(make_int2(p, Npos + 4 + 64 * (extra_first[w] + (int)j) + l));
+    // (the two halves of a split source use the same slots one after the other: a wave folds the first half's into its
+    // planes' row sums before it walks the second half's)
+    std::vector<int> extra_first(kWaves + 1, 0);
+    for (int w = 0; w < kWaves; ++w) {
+      size_t n = 0;
+      for (int hv = 0; hv < halves; ++hv) n = std::max(n, sec_slots_h[hv][w].size());
+      extra_first[w + 1] = extra_first[w] + (int)n;
+    }
+    for (int hv = 0; hv < halves; ++hv) {
+      fix_of_thread[hv].assign(kThreads, {});
+      for (int w = 0; w < kWaves; ++w)
+        for (size_t j = 0; j < sec_slots_h[hv][w].size(); ++j) {
+          for (int l = 0; l < 64; ++l) {
+            const OwnerTask &t = sec_slots_h[hv][w][j][l];
+            if (t.state < 0) continue;
+            const int p = g->pos[t.state];
+            fix_of_thread[hv][(p >> 2) % kThreads].push_back(make_int2(p, Npos + 4 + 64 * (extra_first[w] + (int)j) + l));
+          }
+          slots_h[hv][w].push_back(sec_slots_h[hv][w][j]);
         }
-        slots[w].push_back(sec_slots[w][j]);
-      }
+    }
     out->extra_first.assign(extra_first.begin(), extra_first.end() - 1);
     out->extra_slots = 64 * extra_first[kWaves];
     extra_total[dir] = out->extra_slots;
     out->fix.clear();
     if (planewise) {
-      // per thread AND plane: the pass of a plane folds that plane's secondary rows
+      // per (half,) thread AND plane: the pass of a plane folds that plane's secondary rows
       const int planes = K / 4;
-      out->fix_begin.assign((size_t)kThreads * planes + 1, 0);
-      for (int t = 0; t < kThreads; ++t)
-        for (int j = 0; j < planes; ++j) {
-          out->fix_begin[(size_t)t * planes + j] = (int)out->fix.size();
-          for (auto &f : fix_of_thread[t])
-            if (f.x / (4 * kThreads) == j) out->fix.push_back(f);
-        }
-      out->fix_begin[(size_t)kThreads * planes] = (int)out->fix.size();
+      out->fix_begin.assign((size_t)halves * kThreads * planes + 1, 0);
+      for (int hv = 0; hv < halves; ++hv)
+        for (int t = 0; t < kThreads; ++t)
+          for (int j = 0; j < planes; ++j) {
+            out->fix_begin[((size_t)hv * kThreads + t) * planes + j] = (int)out->fix.size();
+            for (auto &f : fix_of_thread[hv][t])
+              if (f.x / (4 * kThreads) == j) out->fix.push_back(f);
+          }
+      out->fix_begin[(size_t)halves * kThreads * planes] = (int)out->fix.size();
     } else {
       out->fix_begin.assign(kThreads + 1, 0);
       for (int t = 0; t < kThreads; ++t) {
         out->fix_begin[t] = (int)out->fix.size();
-        for (auto &f : fix_of_thread[t]) out->fix.push_back(f);
+        for (auto &f : fix_of_thread[0][t]) out->fix.push_back(f);
       }
       out->fix_begin[kThreads] = (int)out->fix.size();
     }
     out->nfix = (int32_t)out->fix.size();
     if (out->fix.empty()) out->fix.push_back(make_int2(0, 0));
-    emit_owner_stream(Npos, K, slots, order, opos.data(), prob.data(), out, planewise, count_only, general ? apdf.data() : nullptr, g->P);
+    emit_owner_stream(Npos, K, slots_h[0], order_h, opos.data(), prob.data(), out, planewise, count_only, general ? apdf.data() : nullptr, g->P,
+                      split_src ? &slots_h[1] : nullptr, half_pos);
     if (count_only) continue;
     if (planewise && out->mask_stride > 64) return false;  // (a wave's mask words live in one register: at most 256 chunks)
   }
@@ -934,7 +1122,7 @@ bool make_work_graph(tc_den_graph *g) {
   // nearly tied graphs of 3000 / 6000 states with 60-90 % of the states entered through 2-3 pdfs (one MI355X,
   // 256 x 150, tied vs general): 1.77 vs 2.04 ms at 1.9x the states, 1.54 vs 2.04 at 2.3x; across the 8192-state
   // step 2.63 vs 3.26 at 1.9x but 3.56 vs 3.24 at 2.3x.
-  if (WH > kMaxPlanePositions) return false;
+  if (WH > kMaxSplitPositions) return false;
   if (WH <= 8192 ? WH > (int64_t)H * 5 / 2 + 64 : WH > 2 * (int64_t)H + 64) return false;
   std::vector<int32_t> ws, wd, wp;
   std::vector<float> ww;
