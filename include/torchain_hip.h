@@ -221,7 +221,8 @@ int tc_supervision_stage(tc_supervision *supervision, int device);
  *   graphs beyond LDS       4 (T + 1) S' H + 12 S' H + 8 S' P   S' = S rounded up to whole slabs of 16 sequences (32 from
  *                                                              28000 states on): the streamed path's [slab][state][G] matrices
  *                           + 4 T S' P if that is <= 1 GB       exp(y) of every frame, transposed once (else per frame)
- * plus a few KB of per-sequence scalars. */
+ *   tied, 28673..40960 positions, S >= 129  + 4 S (1.5 Hs + ...)  second half of the gather source, parked row sums
+ * plus a few KB of per-sequence scalars and 4 S (T + 2) bytes of frame sums (used by long utterances only). */
 int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);
 
 /* Replaces my_lib_ComputeChainObjfAndDeriv (src/my_lib.h:33-42, src/my_lib_chain.cpp:104-136), i.e.
@@ -320,8 +321,10 @@ int tc_xent_objf(const float *xent_output, int64_t num_rows, int32_t num_cols, i
  * out[6], out[7] = forward / backward LDS bank-conflict factor of the placed arc gathers x 1000, where
  * 1000 means conflict-free; out[8] = 1 when the graph is "tied" -- all non-self-loop arcs entering a
  * state carry one pdf, possibly after state splitting -- and runs a factorised on-chip kernel (one-stream forms up to
- * 16384 layout positions, the plane-wise form up to 28672), 2 when the graph is too large for the on-chip layouts and
- * runs the streamed kernel, 0 for a general on-chip kernel (up to 8192 states: on owner-computes schedules). */
+ * 16384 layout positions, the plane-wise form up to 28672, with its gather source in LDS a half at a time up to 40960 -- a graph
+ * of that last class runs the streamed kernel for batches below 129 sequences, where it is the faster), 2 when the graph is too
+ * large for the on-chip layouts and runs the streamed kernel, 0 for a general on-chip kernel (up to 8192 states: on
+ * owner-computes schedules). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
 /* Kernel choice of batches above one sequence per two CUs.  Tied on-chip graphs of up to 8192 positions have two
