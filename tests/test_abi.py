@@ -9,6 +9,7 @@ import struct
 import numpy as np
 import pytest
 
+from fixtures import write_openfst_vector
 from torchain_amd import io, synth
 from torchain_amd._lib import LIB_PATH, TorchainHipError, lib
 
@@ -77,35 +78,6 @@ def test_den_graph_rejects_bad_fst():
     bad = fst._replace(dst=(fst.dst + 100).astype(np.int32))
     with pytest.raises(TorchainHipError):
         io.DenominatorGraph(bad, 5)
-
-
-def write_openfst_vector(path, fst, with_symbols=False, fst_type=b"vector", arc_type=b"standard", version=2,
-                         truncate_to=None):
-    """Writes an OpenFst binary VectorFst<StdArc> (what fst::ReadFstKaldi reads for a plain file): FstHeader
-    {int32 magic, string fsttype, string arctype, int32 version, int32 flags, uint64 properties, int64 start,
-    int64 numstates, int64 numarcs}, optional input / output symbol tables (flags bits 0 / 1), then per state
-    {float final, int64 narcs, narcs x {int32 ilabel, int32 olabel, float weight, int32 nextstate}}."""
-    def s(b):
-        return struct.pack("<i", len(b)) + b
-
-    def symtab(name, n):
-        out = struct.pack("<i", 2125658996) + s(name) + struct.pack("<qq", n, n)
-        for k in range(n):
-            out += s(b"pdf%d" % k if k else b"<eps>") + struct.pack("<q", k)
-        return out
-
-    blob = struct.pack("<i", 2125659606) + s(fst_type) + s(arc_type)
-    blob += struct.pack("<iiQqqq", version, 3 if with_symbols else 0, 0, int(fst.start), fst.num_states, len(fst.src))
-    if with_symbols:
-        blob += symtab(b"isyms", fst.num_pdfs + 1) + symtab(b"osyms", fst.num_pdfs + 1)
-    first = np.searchsorted(fst.src, np.arange(fst.num_states + 1))
-    for st in range(fst.num_states):
-        blob += struct.pack("<fq", float(fst.final[st]), int(first[st + 1] - first[st]))
-        for a in range(first[st], first[st + 1]):
-            blob += struct.pack("<iifi", int(fst.ilabel[a]), int(fst.ilabel[a]), float(fst.weight[a]), int(fst.dst[a]))
-    with open(path, "wb") as f:
-        f.write(blob if truncate_to is None else blob[:truncate_to])
-    return len(blob)
 
 
 def test_den_fst_file_reader(tmp_path):

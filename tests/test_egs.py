@@ -11,30 +11,9 @@ import torch
 from torchain_amd import egs, io, synth
 
 import kaldi_egs_writer as kw
+from fixtures import make_example, same_fst, write_set as _write_set
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-def make_example(fst, T, seed, n_seq=1, feat_dim=7, ivec_dim=3, left=4, weight=1.0, final_weights=False):
-    """A synthetic chain eg: T output frames at t = 0, 3, 6, ... (frame-subsampling 3 as in the recipe), an input
-    window of 3*T + 2*left frames, a one-row i-vector, a supervision of `n_seq` sequences."""
-    rng = np.random.default_rng(seed)
-    sup = synth.random_supervision(fst, n_seq, T, 2, seed=seed, weight=weight, final_weights=final_weights)
-    n_in = 3 * T + 2 * left
-    feats = rng.standard_normal((n_seq * n_in, feat_dim)).astype(np.float32)
-    in_idx = np.array([(n, t, 0) for n in range(n_seq) for t in range(-left, 3 * T + left)], np.int32)
-    ivec = rng.standard_normal((n_seq, ivec_dim)).astype(np.float32)
-    iv_idx = np.array([(n, 0, 0) for n in range(n_seq)], np.int32)
-    out_idx = np.array([(n, 3 * t, 0) for t in range(T) for n in range(n_seq)], np.int32)  # frame-major
-    dw = rng.choice([0.0, 1.0], size=n_seq * T, p=[0.1, 0.9]).astype(np.float32)
-    return dict(inputs=[dict(name="input", indexes=in_idx, features=feats), dict(name="ivector", indexes=iv_idx, features=ivec)],
-                outputs=[dict(name="output", indexes=out_idx, supervision=sup, deriv_weights=dw)])
-
-
-def same_fst(a, b):
-    return (a.num_states == b.num_states and np.array_equal(a.arc_begin, b.arc_begin) and np.array_equal(a.ilabel, b.ilabel)
-            and np.array_equal(a.nextstate, b.nextstate) and np.allclose(a.arc_weight, b.arc_weight)
-            and np.array_equal(np.isinf(a.final), np.isinf(b.final)) and np.allclose(a.final[~np.isinf(a.final)], b.final[~np.isinf(b.final)]))
 
 
 @pytest.mark.parametrize("kind,tol", [("FM", 0.0), ("CM2", 2e-4), ("CM3", 3e-2), ("CM", 8e-2)])
@@ -153,13 +132,6 @@ def test_append_supervisions_is_the_product_of_the_pieces(oracle):
         s0 += n
     assert abs(tot["logprob_weighted"] - acc) <= 1e-5 * abs(acc)
     assert np.abs(tot["deriv"].reshape(T, S, 16) - derivs).max() <= 1e-5
-
-
-def _write_set(tmp_path, fst, lengths, **kwargs):
-    keyed = [("utt%03d-%d" % (i, L), make_example(fst, L, seed=20 + i)) for i, L in enumerate(lengths)]
-    ark, scp = str(tmp_path / "egs.ark"), str(tmp_path / "egs.scp")
-    kw.write_ark(ark, keyed, scp_path=scp, **kwargs)
-    return keyed, ark, scp
 
 
 def test_sequential_reader_delivers_every_example(tmp_path):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from helpers import hip_chain, hip_den, hip_num, rel_err
-from test_oracle_golden import GOLDEN, load
+from fixtures import GOLDEN, load_golden as load
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4

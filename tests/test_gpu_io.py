@@ -21,7 +21,7 @@ def test_denominator_graph_from_den_fst_file(oracle, tmp_path):
     src/my_lib_example.cpp:129-134) on a den.fst written to disk (with symbol tables), then the full objective
     on the GPU against the oracle built from the in-memory arrays."""
     from torchain_amd import io
-    from test_abi import write_openfst_vector
+    from fixtures import write_openfst_vector
 
     fst = synth.nearly_tied_den_fst(900, 5, 200, seed=17, fraction=0.05)
     path = str(tmp_path / "den.fst")
@@ -45,7 +45,7 @@ def test_chain_loss_on_minibatches_from_the_egs_reader(oracle, tmp_path):
     supervision comes out of the Kaldi-free egs reader and goes through tc_supervision_create; objective and
     derivative against the oracle on the same merged FST."""
     import kaldi_egs_writer as kw
-    from test_egs import make_example
+    from fixtures import make_example
     from torchain_amd import egs, io
     from torchain_amd.functions import chain_loss
 

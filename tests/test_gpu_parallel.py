@@ -127,7 +127,7 @@ def test_two_ranks_fed_from_the_native_reader(tmp_path):
 
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.dirname(__file__))
-    from test_egs import _write_set
+    from fixtures import write_set as _write_set
 
     P = 24
     fst = synth.random_den_fst(40, 4, P, seed=1)

@@ -577,7 +577,7 @@ def test_golden_derivative_element_wise():
     the mass, 1e-4 holds."""
     import os
 
-    from test_oracle_golden import GOLDEN, load
+    from fixtures import GOLDEN, load_golden as load
     checked = 0
     for path in GOLDEN:
         z, fst, sup = load(path)

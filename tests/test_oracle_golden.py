@@ -1,7 +1,6 @@
 """The CPU oracle (oracle/chain_oracle.c, Kaldi-style float/double arithmetic) against the committed
 golden vectors (tests/golden/*.npz, produced by the independent float64 autograd formulation).
 This is what pins the restatement: parity with the reference itself is unpinned (no Kaldi here)."""
-import glob
 import os
 
 import numpy as np
@@ -9,17 +8,7 @@ import pytest
 
 from torchain_amd import synth
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-
-
-def load(path):
-    z = np.load(path)
-    fst = synth.DenFst(int(z["den_num_states"]), z["den_src"], z["den_dst"], z["den_ilabel"], z["den_weight"],
-                       z["den_final"], int(z["den_start"]), int(z["num_pdfs"]))
-    sup = synth.SupFst(float(z["sup_weight"]), int(z["num_sequences"]), int(z["frames_per_sequence"]),
-                       int(z["num_pdfs"]), int(z["sup_num_states"]), z["sup_arc_begin"], z["sup_ilabel"],
-                       z["sup_arc_weight"], z["sup_nextstate"], z["sup_final"])
-    return z, fst, sup
+from fixtures import GOLDEN, load_golden as load
 
 
 def test_fixtures_present():
