@@ -221,7 +221,7 @@ int tc_supervision_stage(tc_supervision *supervision, int device);
  *   graphs beyond LDS       4 (T + 1) S' H + 12 S' H + 8 S' P   S' = S rounded up to whole slabs of 16 sequences (32 from
  *                                                              28000 states on): the streamed path's [slab][state][G] matrices
  *                           + 4 T S' P if that is <= 1 GB       exp(y) of every frame, transposed once (else per frame)
- *   tied, 28673..40960 positions, S >= 129  + 4 S (1.5 Hs + ...)  second half of the gather source, parked row sums
+ *   tied, 28673..40960 positions  + 8 S (2 Hs + ...)            second half of the gather source, parked row sums (per workgroup)
  * plus a few KB of per-sequence scalars and 4 S (T + 2) bytes of frame sums (used by long utterances only). */
 int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequences, int32_t frames_per_sequence);
 
@@ -321,9 +321,8 @@ int tc_xent_objf(const float *xent_output, int64_t num_rows, int32_t num_cols, i
  * out[6], out[7] = forward / backward LDS bank-conflict factor of the placed arc gathers x 1000, where
  * 1000 means conflict-free; out[8] = 1 when the graph is "tied" -- all non-self-loop arcs entering a
  * state carry one pdf, possibly after state splitting -- and runs a factorised on-chip kernel (one-stream forms up to
- * 16384 layout positions, the plane-wise form up to 28672, with its gather source in LDS a half at a time up to 40960 -- a graph
- * of that last class runs the streamed kernel for batches below 129 sequences, where it is the faster), 2 when the graph is too
- * large for the on-chip layouts and runs the streamed kernel, 0 for a general on-chip kernel (up to 8192 states: on
+ * 16384 layout positions, the plane-wise form up to 28672, with its gather source in LDS a half at a time up to 40960), 2 when
+ * the graph is too large for the on-chip layouts and runs the streamed kernel, 0 for a general on-chip kernel (up to 8192 states: on
  * owner-computes schedules). */
 int tc_den_graph_stats(const tc_den_graph *graph, int64_t *out9);
 
@@ -389,8 +388,6 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "no_split_source" (1: tied graphs of 28673..40960 positions take the streamed path at every batch, as before round 6)
  *   "old_general"    (1: general graphs take round 1's on-chip kernel, not the one on owner-computes schedules)
  * Read at launch (one relaxed atomic load):
- *   "split_source_any_batch" (1: tied graphs of 28673..40960 positions run their on-chip kernel also below 129 sequences,
- *                     where the library routes them to the streamed path: it is the faster one there)
  *   "no_phase_split" (1: batches of at most 128 sequences of tied on-chip graphs take the fused kernel instead of
  *                     running forward and backward recursion on two CUs at once; the plane-wise kernel likewise)
  *   "no_num_overlap" (1: the numerator always follows the denominator on the caller's stream; by default it runs

@@ -18,12 +18,11 @@ for hd in "18000 12" "24000 12" "28000 10"; do set -- $hd
   b=$(TC_DEBUG=no_planes TC_CFG=H=$1,degree=$2,P=2928 python scripts/time_den.py X2 2>&1 | tail -1 | grep -o "[0-9.]* ms")
   echo "H=$1 degree=$2: plane-wise $a | streamed $b"
 done
-echo "== split gather source (28673..40960 positions, round 6): on chip (default from 129 sequences) vs the streamed path (no_split_source)"
-for S in 256 129 128 64; do
+echo "== split gather source (28673..40960 positions, round 6): on chip (two workgroups per sequence up to 128 sequences) vs the streamed path (no_split_source)"
+for S in 256 128 64 16; do
   a=$(python scripts/time_den.py X2 $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
   b=$(TC_DEBUG=no_split_source python scripts/time_den.py X2 $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
-  c=$(TC_DEBUG=split_source_any_batch python scripts/time_den.py X2 $S 2>&1 | tail -1 | grep -o "[0-9.]* ms")
-  echo "X2 batch $S: default $a | streamed $b | on chip $c"
+  echo "X2 batch $S: on chip $a | streamed $b"
 done
 for hd in "32000 10" "36000 8"; do set -- $hd
   a=$(TC_CFG=H=$1,degree=$2,P=2928 python scripts/time_den.py X2 2>&1 | tail -1 | grep -o "[0-9.]* ms")

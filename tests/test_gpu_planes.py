@@ -205,11 +205,12 @@ def test_plane_wise_graph_through_chain_loss(oracle):
 
 
 # ---- 28673..40960 positions: the gather source in LDS a half at a time (round 6) ----------------------------------------------
-def test_split_source_kernel_small(oracle, kernel_family):
+@pytest.mark.parametrize("form", ["two_cu", "fused"])
+def test_split_source_kernel_small(oracle, kernel_family, form):
     """Against the oracle at toy batches: log-prob, derivative, row sums; Kaldi's accumulate form; the forward-only call; bitwise
-    reproducibility and slice identity (sequences never interact).  (Below 129 sequences the library routes this class to the
-    streamed path, which is faster there; `split_source_any_batch` keeps the on-chip kernel under test.)"""
-    kernel_family("split_source_any_batch")
+    reproducibility and slice identity (sequences never interact)."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     fst = synth.random_den_fst(30000, 3, 900, seed=71)
     S, T = 5, 9
     y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=72)
@@ -231,17 +232,17 @@ def test_split_source_kernel_small(oracle, kernel_family):
     assert np.array_equal(part["deriv"].reshape(T, 3, P), out["deriv"].reshape(T, S, P)[:, 1:4])
 
 
-@pytest.mark.parametrize("S,T", [(64, 150), (256, 30)])
-def test_split_source_kernel_at_size(oracle, kernel_family, S, T):
-    """X2 (40000 states, 400000 arcs, 4096 pdfs) at size, with the element-wise bounds."""
-    kernel_family("split_source_any_batch")
+@pytest.mark.parametrize("S,T,form", [(64, 150, "two_cu"), (64, 150, "fused"), (256, 30, "fused"), (128, 31, "two_cu")])
+def test_split_source_kernel_at_size(oracle, kernel_family, S, T, form):
+    """X2 (40000 states, 400000 arcs, 4096 pdfs) at size, with the element-wise bounds, one and two workgroups per sequence."""
+    if form == "fused":
+        kernel_family("no_phase_split")
     compare_at_size(oracle, "X2", S, T, seed=601, expect_tied=1)
 
 
 def test_split_source_kernel_hub_states_and_full_objective(oracle, kernel_family):
     """A phone-LM-structured graph of 32000 states (in-degrees of hundreds: secondary rows of both halves share their private
     slots) through the full objective, numerator included."""
-    kernel_family("split_source_any_batch")
     fst = synth.phone_lm_den_fst(num_histories=3200, branching=10, seed=11)
     assert fst.num_states > 28672
     out, _ref = check_full(oracle, fst, 4, 12, 5e-5, 0.1, seed=81)
@@ -251,7 +252,6 @@ def test_split_source_kernel_hub_states_and_full_objective(oracle, kernel_family
 def test_split_source_kernel_peaky_and_float64(oracle, kernel_family):
     """Peaky outputs (T = 150) against the float64 formulation, and the element-wise reading on N(0, 1) outputs: every entry above
     1e-4 within 1e-4 relative (tests/test_gpu_tied.py: test_derivative_elementwise_against_float64)."""
-    kernel_family("split_source_any_batch")
     peaky_check(oracle, synth.random_den_fst(30000, 3, 600, seed=77), 1, 150, 10.0, 0.1)
     for leaky in (0.1, 1e-5):
         fst, y, lp, ref = float64_truth("X2", 2, 40, leaky)
@@ -266,7 +266,6 @@ def test_split_source_kernel_peaky_and_float64(oracle, kernel_family):
 
 def test_split_source_graph_long_utterance(oracle, kernel_family):
     """... and a long utterance (T = 900) on a 10-plane graph."""
-    kernel_family("split_source_any_batch")
     fst = synth.random_den_fst(40000, 3, 4096, seed=91)
     S, T = 2, 900
     y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=92)
@@ -275,16 +274,3 @@ def test_split_source_graph_long_utterance(oracle, kernel_family):
     assert out["graph"].stats()["tied"] == 1 and out["status"] == 0
     assert abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
     assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL
-
-
-def test_split_source_class_routes_small_batches_to_the_streamed_path(oracle):
-    """One graph handle, two paths: 129 sequences and more run the on-chip kernel, fewer the streamed path (faster there: X2 at 64
-    sequences 11.0 vs 18.5 ms) -- both against the oracle, through one workspace-size query each."""
-    fst = synth.random_den_fst(30000, 3, 900, seed=71)
-    T = 3
-    for S in (4, 130):
-        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=S)
-        ref = oracle.den_forward_backward(oracle.DenGraph(fst), y, S, leaky=0.1, deriv_weight=1.0)
-        out = hip_den(fst, y, S, leaky=0.1, deriv_weight=1.0)
-        assert out["status"] == 0 and abs(out["logprob"] - ref["logprob"]) <= REL * abs(ref["logprob"])
-        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL

@@ -71,8 +71,9 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
   w.asum_g = (float *)take((size_t)S * asum_stride(T) * sizeof(float));  // frame sums of utterances too long for LDS
   if (planes && Hs > kMaxPlanePositions) {
     const int planes_n = Hs / 4096, planes_b = planes_n - (planes_n + 1) / 2;
-    w.src_scratch = (float *)take((size_t)S * 4096 * planes_b * sizeof(float));
-    w.part_scratch = (float *)take((size_t)S * (Hs + 4096 * ((planes_n + 1) / 2)) * sizeof(float));  // (+ alpha' of the first half's planes)
+    // (per WORKGROUP: two per sequence in the two-workgroup form of small batches)
+    w.src_scratch = (float *)take((size_t)2 * S * 4096 * planes_b * sizeof(float));
+    w.part_scratch = (float *)take((size_t)2 * S * (Hs + 4096 * ((planes_n + 1) / 2)) * sizeof(float));  // (+ alpha' of the first half's planes)
   }
   w.den_lp = (double *)take((size_t)S * 8);
   w.num_lp = (double *)take((size_t)S * 8);
@@ -106,12 +107,6 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
 }
 
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
-
-// the handle that computes a batch of S sequences (chain_internal.h: tc_den_graph::small_batch)
-tc_den_graph *route(tc_den_graph *g, int S) {
-  return g && g->small_batch && S < kSplitSourceMinSeq && !debug_flag(kDbgSplitSrcAnyBatch) ? g->small_batch : g;
-}
-const tc_den_graph *route(const tc_den_graph *g, int S) { return route(const_cast<tc_den_graph *>(g), S); }
 
 struct DeviceGuard {
   int prev = -1;
@@ -398,7 +393,6 @@ uint64_t tc_den_graph_hash(const tc_den_graph *g) {
 
 int64_t tc_chain_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  g = route(g, S);
   return (int64_t)carve(nullptr, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g)).total;
 }
 
@@ -407,7 +401,6 @@ int tc_den_forward_backward(tc_den_graph *g, int32_t S, const float *y, int64_t 
                             float *deriv, int64_t deriv_stride, double *logprob_dev, int32_t *status_dev,
                             void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || S <= 0 || rows <= 0 || rows % S != 0) return TC_ERR_INVALID_ARGUMENT;
-  g = route(g, S);
   const int T = (int)(rows / S);
   Workspace w = carve((char *)workspace, hist_states(g), S, T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, S), pair_room(g), planes_room(g));
   if (!workspace || (int64_t)w.total > workspace_bytes || !aligned16(workspace)) return TC_ERR_WORKSPACE;
@@ -462,7 +455,6 @@ static int chain_objf(tc_den_graph *g, tc_supervision *sup, const float *y, int6
                       int xent_bct = 0, int xent_out_bct = 0, const float *bct_input = nullptr,
                       bool xent_sums_ready = false, float *loss_dev1 = nullptr) {
   if (!g || !sup || !y || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
-  g = route(g, sup->S);
   if (sup->P != g->P) return TC_ERR_INVALID_ARGUMENT;
   if ((int64_t)sup->S * sup->T != rows) return TC_ERR_INVALID_ARGUMENT;
   Workspace w = carve((char *)workspace, hist_states(g), sup->S, sup->T, big_p(g), big_h(g), big_g(g), big_hb(g), split_room(g, sup->S), pair_room(g), planes_room(g));
@@ -611,7 +603,6 @@ StepWorkspace carve_step(char *base, const tc_den_graph *g, int S, int T, int P,
 
 int64_t tc_chain_step_workspace_bytes(const tc_den_graph *g, int32_t S, int32_t T, int three_d, int with_xent) {
   if (!g || S <= 0 || T <= 0) return TC_ERR_INVALID_ARGUMENT;
-  g = route(g, S);
   return (int64_t)carve_step(nullptr, g, S, T, g->P, three_d != 0, with_xent != 0).total;
 }
 
@@ -620,7 +611,6 @@ int tc_chain_step(tc_den_graph *g, tc_supervision *sup, const float *input, cons
                   float *grad, float *xent_grad, float *results_dev3, float *loss_dev1, double *xent_objf_dev,
                   void *workspace, int64_t workspace_bytes, int device, void *stream_v) {
   if (!g || !sup || !input || !results_dev3) return TC_ERR_INVALID_ARGUMENT;
-  g = route(g, sup->S);
   const bool use_xent = xent_input != nullptr && xent_regularize != 0.0f;
   // grad == NULL: an evaluation step ([K] ComputeChainObjfAndDeriv with nnet_output_deriv == NULL, as Kaldi's own
   // diagnostics call it): the two forward recursions, the results and the loss; no Backward(), so no alpha-beta

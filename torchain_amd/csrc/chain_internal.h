@@ -76,7 +76,6 @@ constexpr int kMaxPlanePositions = 4096 * kJvPlanes;
 // wait in the workspace (DenParams::part_scratch) for the second, which runs the per-state pass.  ScheduleHost::halves.
 constexpr int kJvPlanesSplit = 10;
 constexpr int kMaxSplitPositions = 4096 * kJvPlanesSplit;
-constexpr int kSplitSourceMinSeq = 129;  // batches below take the streamed path (tc_den_graph::small_batch)
 
 struct ScheduleHost {
   std::vector<ArcRec> cells;       // all waves' streams, [cell][lane] (final layout [pair][lane][2])
@@ -287,13 +286,6 @@ struct tc_den_graph {
   std::vector<int32_t> big_f_off;
   std::vector<int32_t> tied_f, tied_s;  // per work state: forward / special self-loop pdf, -1 if none
   float big_sum_pi = 0.f;
-  // Graphs of kMaxPlanePositions + 1 .. kMaxSplitPositions positions (split gather source, den_tied_planes.hip) have only
-  // the one-workgroup-per-sequence form on chip, which costs the same whatever the batch; below kSplitSourceMinSeq sequences
-  // the streamed path is faster (X2: 11.0 vs 18.5 ms at 64 sequences, 17.2 vs 18.6 at 128; 27.3 vs 20.4 at 256).  Such a graph
-  // therefore carries a second handle of the same FST built for the streamed path, and every entry point that knows the
-  // batch routes to it (api.cpp: route()).  Owned: freed and uploaded with this one.
-  tc_den_graph *small_batch = nullptr;
-  bool build_streamed = false;  // (this handle IS such a second one)
   std::mutex mu;
   std::map<int, tc::DenGraphDev> dev;
   std::map<int, int> preset_variant;  // device -> kernel choice fixed by the caller (tc_den_graph_set_variant)
@@ -471,7 +463,7 @@ extern thread_local int g_last_hip_error;
 // replace what used to be environment variables of the shipping library.
 // bumped whenever a round changes a kernel the per-graph choice is timed on (tuning_cache.cpp: part of the cache key)
 constexpr int kKernelGeneration = 6;
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgNoSplitSrc, kDbgSplitSrcAnyBatch, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgNoSplitSrc, kDbgCount };
 bool debug_flag(DebugFlag f);
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp

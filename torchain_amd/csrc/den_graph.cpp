@@ -255,7 +255,7 @@ static void build_big_tied(tc_den_graph *g, const std::vector<char> &special) {
 }
 
 int build_schedules(tc_den_graph *g) {
-  bool want_big = debug_flag(kDbgForceStreamed) || g->build_streamed || g->H > kMaxSplitPositions || g->P > kMaxIndex;
+  bool want_big = debug_flag(kDbgForceStreamed) || g->H > kMaxSplitPositions || g->P > kMaxIndex;
   bool split_made = false;  // tied only thanks to make_work_graph
   // ---- the tied path: on the FST as it is, or on its tied-ified work graph
   std::vector<char> special;
@@ -425,7 +425,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search", "no_split_source", "split_source_any_batch"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search", "no_split_source"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {
@@ -532,21 +532,6 @@ int tc_den_graph_create(tc_den_graph **out, int32_t num_states, int64_t num_arcs
     for (int s = 0; s < H; ++s) g->initial_probs[s] = (float)avg[s];
   }
   build_schedules(g);
-  if (!g->big && g->tied && g->layout_ok && g->layout.planewise && g->layout.src_planes < g->layout.JV) {
-    // split gather source: small batches take the streamed path (chain_internal.h: tc_den_graph::small_batch)
-    tc_den_graph *alt = new tc_den_graph();
-    alt->H = g->H;
-    alt->P = g->P;
-    alt->A = g->A;
-    alt->arc_src = g->arc_src;
-    alt->arc_dst = g->arc_dst;
-    alt->arc_pdf = g->arc_pdf;
-    alt->arc_prob = g->arc_prob;
-    alt->initial_probs = g->initial_probs;
-    alt->build_streamed = true;
-    build_schedules(alt);
-    g->small_batch = alt;
-  }
   *out = g;
   return TC_OK;
 }
@@ -660,7 +645,6 @@ int tc_den_graph_read(tc_den_graph **out, const char *rxfilename, int32_t num_pd
 
 void tc_den_graph_free(tc_den_graph *g) {
   if (!g) return;
-  if (g->small_batch) tc_den_graph_free(g->small_batch);
   for (auto &kv : g->dev) {
     if (kv.second.blob) {
       int cur = 0;
@@ -936,8 +920,7 @@ static int upload_den_graph(tc_den_graph *g, int device);
 // two-sequence kernel on that device and keeps the faster (tune_den_variant).
 int tc_den_graph_prepare(tc_den_graph *g, int device) {
   if (!g) return TC_ERR_INVALID_ARGUMENT;
-  int rc = upload_den_graph(g, device);
-  if (rc == TC_OK && g->small_batch) rc = tc_den_graph_prepare(g->small_batch, device);
+  const int rc = upload_den_graph(g, device);
   if (rc != TC_OK) return rc;
   return tune_den_variant(g, device);
 }

@@ -101,7 +101,8 @@ struct PlaneSeq {
   long long st_prev, st_acc[8];
 #endif
 
-  __device__ __forceinline__ PlaneSeq(const DenParams &pp, int seq)
+  // role: which of a sequence's two workgroups (two-workgroup form; the split source's scratch rows are per workgroup)
+  __device__ __forceinline__ PlaneSeq(const DenParams &pp, int seq, int role = 0)
       : p(pp), tid(threadIdx.x), lane(threadIdx.x & 63u), wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)), s(seq), H(pp.H), S(pp.S),
         T(pp.T), Hs(pp.L.Hs), Ps(pp.L.Ps), planes(pp.L.Hs / (4 * kThreads)), own16(16u * threadIdx.x), lane16(16u * (threadIdx.x & 63u)),
         aACC(4u * (uint32_t)pp.L.off_acc),
@@ -114,8 +115,8 @@ struct PlaneSeq {
         bhist(pp.beta_hist ? pp.beta_hist + (int64_t)seq * pp.L.Hs : nullptr) {
     if constexpr (SPLIT) {
       sp.planes_a = pp.L.src_planes;
-      sp.src_b = pp.src_scratch + (int64_t)seq * (4 * kThreads) * (pp.L.JV - pp.L.src_planes);
-      sp.parked = pp.part_scratch + (int64_t)seq * (pp.L.Hs + 4 * kThreads * pp.L.src_planes);
+      sp.src_b = pp.src_scratch + (int64_t)(2 * seq + role) * (4 * kThreads) * (pp.L.JV - pp.L.src_planes);
+      sp.parked = pp.part_scratch + (int64_t)(2 * seq + role) * (pp.L.Hs + 4 * kThreads * pp.L.src_planes);
     }
   }
 
@@ -325,6 +326,18 @@ struct PlaneSeq {
     } else {
       lds4_st(kA0 + own16 + j * kPlane, v);
     }
+  }
+  // ... scaled in place (the two-workgroup form's hand-over)
+  __device__ __forceinline__ void source_scale(int j, float c) {
+    if constexpr (SPLIT) {
+      if (j >= sp.planes_a) {
+        const rsrc_t r = make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a));
+        const uint32_t at = own16 + (uint32_t)(j - sp.planes_a) * kPlane;
+        bst4_aux<0>(r, at, bld4(r, at, 0) * c);
+        return;
+      }
+    }
+    lds4_st(kA0 + own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane) * c);
   }
   __device__ __forceinline__ rsrc_t part_rsrc() const {
     if constexpr (SPLIT)  // [row sums of every plane | alpha'_{t-1} of the first half's planes]
@@ -673,9 +686,9 @@ __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenPara
 // Two workgroups per sequence that meet in the middle (batches of at most half the CUs): den_tied_mitm.hip's scheme
 // =========================================================================================================
 // ROLE F: alpha forward over frames 1..M exactly as the fused kernel, the hand-over, then frames M+1..T with gamma_{t-1}
-template <bool ACCUM, int MAXP>
+template <bool ACCUM, int MAXP, bool SPLIT>
 __device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const MitmParams &mq, int s) {
-  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_PAIR> q(p, s);
+  PlaneSeq<ACCUM, MAXP, SPLIT ? TC_PW_BUFFERS_FUSED : TC_PW_BUFFERS_PAIR, SPLIT> q(p, s, 0);
   const int T = q.T, M = mq.M;
   q.forward_begin();
   for (int t = 1; t <= M; ++t) q.template forward_frame<false>(t);
@@ -695,9 +708,9 @@ __device__ __forceinline__ void planes_mitm_forward(const DenParams &p, const Mi
 }
 
 // ROLE B: frames T-1..M with normalisers of its own and no gamma, the hand-over, then the fused kernel's backward frame
-template <bool ACCUM, int MAXP>
+template <bool ACCUM, int MAXP, bool SPLIT>
 __device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const MitmParams &mq, int s) {
-  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_PAIR> q(p, s);
+  PlaneSeq<ACCUM, MAXP, SPLIT ? TC_PW_BUFFERS_FUSED : TC_PW_BUFFERS_PAIR, SPLIT> q(p, s, 1);
   const int T = q.T, M = mq.M;
   q.template backward_begin<true>(1.0f);  // B'_T = 1
   for (int t = T - 1; t >= M; --t) q.template backward_frame<true>(t);
@@ -714,7 +727,7 @@ __device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const M
 #pragma unroll
     for (int j = 0; j < MAXP; ++j) {
       q.R[j] = q.R[j] * c;  // beta_M = c_M B_M, where frame M-1 looks for beta_{t+1}
-      if (j < q.planes) lds4_st(q.kA0 + q.own16 + j * kPlane, lds4(q.kA0 + q.own16 + j * kPlane) * c);  // Y_{M-1}
+      if (j < q.planes) q.source_scale(j, c);  // Y_{M-1}
     }
   }
   for (int t = M - 1; t >= 0; --t)
@@ -722,26 +735,27 @@ __device__ __forceinline__ void planes_mitm_backward(const DenParams &p, const M
   if (!partner_ok && q.tid == 0) p.seq_ab[s] = __builtin_nanf("");
 }
 
-template <bool ACCUM, int MAXP>
+template <bool ACCUM, int MAXP, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_mitm_kernel(const DenParams p, const MitmParams q) {
   const uint32_t ticket = take_ticket(q);
   const int s = (int)(ticket >> 1);
   if (s >= p.S) return;
   if ((ticket & 1u) == 0u)
-    planes_mitm_forward<ACCUM, MAXP>(p, q, s);
+    planes_mitm_forward<ACCUM, MAXP, SPLIT>(p, q, s);
   else
-    planes_mitm_backward<ACCUM, MAXP>(p, q, s);
+    planes_mitm_backward<ACCUM, MAXP, SPLIT>(p, q, s);
 }
 
 }  // namespace
 
 bool planes_mitm_fits(const DenParams &p) {
-  return p.L.planewise && !p.L.asum_global && p.L.src_planes == p.L.JV && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
+  return p.L.planewise && !p.L.asum_global && p.T >= 2 && p.deriv && p.beta_hist && p.fwd_norm && p.bwd_norm && p.mitm_sync &&
          (size_t)layout_lds_bytes(p.L, p.T) + 16u <= (size_t)kLdsLimitBytes;
 }
 
 int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t stream) {
-  if (!planes_mitm_fits(p) || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanes) return TC_ERR_UNSUPPORTED;
+  if (!planes_mitm_fits(p) || p.L.PV != kPvSmall || p.L.JV < 5 || p.L.JV > kJvPlanesSplit) return TC_ERR_UNSUPPORTED;
+  if (p.L.src_planes < p.L.JV && (!p.src_scratch || !p.part_scratch)) return TC_ERR_WORKSPACE;
   const size_t lds = (size_t)layout_lds_bytes(p.L, p.T) + 16u;
   MitmParams q;
   q.sync = p.mitm_sync;
@@ -749,7 +763,9 @@ int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t 
   q.aScr = (uint32_t)layout_lds_bytes(p.L, p.T);
   TC_HIP_CHECK(hipMemsetAsync(p.mitm_sync, 0, mitm_sync_bytes(p.S), stream));
   void (*k)(const DenParams, const MitmParams) = nullptr;
-  if (p.L.JV <= 6)
+  if (p.L.src_planes < p.L.JV)
+    k = accumulate ? den_tied_planes_mitm_kernel<true, kJvPlanesSplit, true> : den_tied_planes_mitm_kernel<false, kJvPlanesSplit, true>;
+  else if (p.L.JV <= 6)
     k = accumulate ? den_tied_planes_mitm_kernel<true, 6> : den_tied_planes_mitm_kernel<false, 6>;
   else
     k = accumulate ? den_tied_planes_mitm_kernel<true, kJvPlanes> : den_tied_planes_mitm_kernel<false, kJvPlanes>;
