@@ -42,7 +42,11 @@ namespace {
 // per-plane "pass" only parks the plane's row sums in the workspace, then -- the second half of the source brought in from
 // the workspace, where the previous frame's tail left it -- the second, whose per-plane pass adds the parked sums and is
 // the frame's real per-state pass.  Two more barriers and ~0.5 MB of L2 traffic per frame pair and CU beside 4.8 MB of cells.
-template <bool ACCUM, int MAXP, int BUF, bool SPLIT = false>
+// REGS (split source, fused kernel): what waits between a frame's two walks waits in the per-state registers where it can --
+// the forward walk's row sums in R (free until the second walk's passes fill it), the second half of the backward gather
+// source re-formed from R's beta rows -- instead of in the workspace: X2 at 256 sequences 18.5 -> 17.5 ms.  The two-workgroup
+// form keeps the workspace rows: with them in registers its kernel (both roles' code) spills 80 registers and loses 25 %.
+template <bool ACCUM, int MAXP, int BUF, bool SPLIT = false, bool REGS = false>
 struct PlaneSeq {
   static constexpr uint32_t kPB = 0u;             // exp(y_t)
   static constexpr uint32_t kA0 = 16u * kThreads;  // alpha'_t (forward) / Y_t (backward): the gather source
@@ -301,19 +305,40 @@ struct PlaneSeq {
     run_stream(q, [&](int j) __attribute__((always_inline)) {
       const int fx0 = fx0_n, fx1 = fx1_n;
       for (int e = fx0; e < fx1; ++e) fold_row_pw(fix[e], vrow, aACC, Hs);
-      bst4_aux<0>(r_part, own16 + (uint32_t)j * kPlane, own_rows(vrow, 0));
+      // (forward: the per-state rows R are free until the second walk's passes fill them with alpha_t -- the row sums wait there
+      // instead of going through L2: 320 KB per frame and CU whose 32 copies per XCD do not fit its L2 anyway)
+      if (FORWARD && REGS)
+        rset(j, own_rows(vrow, 0));
+      else
+        bst4_aux<0>(r_part, own16 + (uint32_t)j * kPlane, own_rows(vrow, 0));
       if (FORWARD && j < sp.planes_a) bst4_aux<0>(r_part, own16 + (uint32_t)j * kPlane + 4u * (uint32_t)Hs, lds4(kA0 + own16 + (uint32_t)j * kPlane));
       request_fix(j + 1 < planes ? j + 1 : j, 0);
     }, 0);
     request_first(q, 1);
-    const rsrc_t r_src = make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a));
-    f4 sb[(MAXP + 1) / 2];
+    if (FORWARD || !REGS) {
+      const rsrc_t r_src = make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a));
+      f4 sb[(MAXP + 1) / 2];
 #pragma unroll
-    for (int j = 0; j < (MAXP + 1) / 2; ++j) sb[j] = bld4(r_src, own16, j * kPlane);  // (beyond the half's planes: zeros)
-    __syncthreads();  // every wave has gathered its last value of the first half
+      for (int j = 0; j < (MAXP + 1) / 2; ++j) sb[j] = bld4(r_src, own16, j * kPlane);  // (beyond the half's planes: zeros)
+      __syncthreads();  // every wave has gathered its last value of the first half
 #pragma unroll
-    for (int j = 0; j < (MAXP + 1) / 2; ++j)
-      if (j < planes - sp.planes_a) lds4_st(kA0 + own16 + j * kPlane, sb[j]);
+      for (int j = 0; j < (MAXP + 1) / 2; ++j)
+        if (j < planes - sp.planes_a) lds4_st(kA0 + own16 + j * kPlane, sb[j]);
+    } else {
+      // backward: the second half of Y_t = beta_{t+1} * p_t(f) is formed here, from the beta rows the registers hold and the
+      // exp(y_t) buffer, instead of travelling through the workspace (a written and a read row of per-CU data per frame)
+      u4 fsb[(MAXP + 1) / 2];
+#pragma unroll
+      for (int j = 0; j < (MAXP + 1) / 2; ++j) fsb[j] = bld4u(r_fs, own16, (uint32_t)(sp.planes_a + j) * kPlane);
+      __syncthreads();  // every wave has gathered its last value of the first half
+#pragma unroll
+      for (int j = 0; j < (MAXP + 1) / 2; ++j)
+        if (j < planes - sp.planes_a) {
+          const f4 b = rget(sp.planes_a + j);
+          lds4_st(kA0 + own16 + j * kPlane, f4{b.x * ldsf(kPB + (fsb[j].x & 0xffffu)), b.y * ldsf(kPB + (fsb[j].y & 0xffffu)),
+                                               b.z * ldsf(kPB + (fsb[j].z & 0xffffu)), b.w * ldsf(kPB + (fsb[j].w & 0xffffu))});
+        }
+    }
     __syncthreads();  // the second half is in place
   }
   // a plane's value of the next frame's gather source: the first half's planes to LDS, the others to the workspace
@@ -327,14 +352,24 @@ struct PlaneSeq {
       lds4_st(kA0 + own16 + j * kPlane, v);
     }
   }
+  // backward: only the first half's planes are stored (the second half of Y is formed from the beta rows when it is needed)
+  __device__ __forceinline__ void source_st_bwd(int j, f4 v) {
+    if constexpr (SPLIT && REGS) {
+      if (j < sp.planes_a) lds4_st(kA0 + own16 + j * kPlane, v);
+    } else {
+      source_st(j, v);
+    }
+  }
   // ... scaled in place (the two-workgroup form's hand-over)
   __device__ __forceinline__ void source_scale(int j, float c) {
     if constexpr (SPLIT) {
       if (j >= sp.planes_a) {
-        const rsrc_t r = make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a));
-        const uint32_t at = own16 + (uint32_t)(j - sp.planes_a) * kPlane;
-        bst4_aux<0>(r, at, bld4(r, at, 0) * c);
-        return;
+        if constexpr (!REGS) {
+          const rsrc_t r = make_rsrc(sp.src_b, 16u * kThreads * (uint32_t)(planes - sp.planes_a));
+          const uint32_t at = own16 + (uint32_t)(j - sp.planes_a) * kPlane;
+          bst4_aux<0>(r, at, bld4(r, at, 0) * c);
+        }
+        return;  // (REGS: the second half of Y is formed from the beta rows, which the caller scales)
       }
     }
     lds4_st(kA0 + own16 + j * kPlane, lds4(kA0 + own16 + j * kPlane) * c);
@@ -405,7 +440,7 @@ struct PlaneSeq {
       first_walk<true>(q);  // the cells whose source lies in the first half; the second half of alpha'_{t-1} is in LDS behind it
       fs_n = bld4u(r_fs, own16, 0);
       ws_n = bld4(r_ws, own16, 0);
-      sp.part_n = bld4(r_part, own16, 0);
+      if (!REGS) sp.part_n = bld4(r_part, own16, 0);
       sp.al_n = bld4(r_part, own16, 4u * (uint32_t)Hs);
       request_fix(0, 1);
     }
@@ -420,7 +455,7 @@ struct PlaneSeq {
       f4 F = own_rows(vrow, 0);
       f4 al;  // alpha'_{t-1} of the owned states
       if constexpr (SPLIT) {
-        F += sp.part_n;
+        F += REGS ? rget(j) : sp.part_n;  // (the first walk's row sums)
         // (the second half's planes are what LDS holds now; the first half's were parked by the first walk)
         al = j < sp.planes_a ? sp.al_n : lds4(kA0 + own16 + (uint32_t)(j - sp.planes_a < 0 ? 0 : j - sp.planes_a) * kPlane);
       } else {
@@ -440,7 +475,7 @@ struct PlaneSeq {
         ws_n = bld4(r_ws, own16, (uint32_t)jn * kPlane);
         if (GAMMA) bt_n = bld4(brow, own16, (uint32_t)jn * kPlane);
         if constexpr (SPLIT) {
-          sp.part_n = bld4(r_part, own16, (uint32_t)jn * kPlane);
+          if (!REGS) sp.part_n = bld4(r_part, own16, (uint32_t)jn * kPlane);
           sp.al_n = bld4(r_part, own16, (uint32_t)(jn < sp.planes_a ? jn : 0) * kPlane + 4u * (uint32_t)Hs);
         }
         request_fix(jn, SPLIT ? 1 : 0);
@@ -534,8 +569,8 @@ struct PlaneSeq {
       R[j] = b;
       if (j < planes) {
         if (PURE) bst4_aux<0>(bhist_row(T), own16 + j * kPlane, b);  // B_T
-        source_st(j, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
-                        b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
+        source_st_bwd(j, f4{b.x * ldsf(kPB + (fs.x & 0xffffu)), b.y * ldsf(kPB + (fs.y & 0xffffu)),
+                            b.z * ldsf(kPB + (fs.z & 0xffffu)), b.w * ldsf(kPB + (fs.w & 0xffffu))});
       }
     }
     stamps_reset();
@@ -656,8 +691,8 @@ struct PlaneSeq {
       R[j] = b;  // beta_t (B_t) for the next frame's passes
       if (j < planes) {
         if (PURE) bst4_aux<0>(bhist_row(t), own16 + j * kPlane, b);  // B_t for the partner
-        source_st(j, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
-                        b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
+        source_st_bwd(j, f4{b.x * ldsf(kPB + (fsT[j].x & 0xffffu)), b.y * ldsf(kPB + (fsT[j].y & 0xffffu)),
+                            b.z * ldsf(kPB + (fsT[j].z & 0xffffu)), b.w * ldsf(kPB + (fsT[j].w & 0xffffu))});
       }
     }
     TC_STAMP(4)
@@ -667,7 +702,7 @@ struct PlaneSeq {
 
 template <bool ACCUM, bool WANT_DERIV, int MAXP, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void den_tied_planes_kernel(const DenParams p) {
-  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_FUSED, SPLIT> q(p, (int)blockIdx.x);
+  PlaneSeq<ACCUM, MAXP, TC_PW_BUFFERS_FUSED, SPLIT, SPLIT> q(p, (int)blockIdx.x);
   const int T = q.T;
   // ---- forward: alpha'_0, frames 1..T, total probability
   q.forward_begin();
