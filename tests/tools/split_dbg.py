@@ -1,5 +1,8 @@
+"""Development aid (GPU box): the split-source plane-wise kernel (graphs of 28673..40960 positions) against the oracle on tiny batches --
+forward-only and forward + backward log-prob, derivative, row sums.  Test infrastructure: it imports the oracle."""
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import hip_den, rel_err
 from oracle import pyoracle
