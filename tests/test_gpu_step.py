@@ -396,3 +396,27 @@ def test_registered_operator_equals_chain_loss(three_d, xent):
         le, re_ = chain_loss_op(x, graph, sup, xent_input=xe if xent else None, **kw)
     assert _delta(before)["den_backward_launches"] == 0
     np.testing.assert_allclose(re_.data.numpy(), r0.numpy(), rtol=1e-6)
+
+
+def test_registered_operator_traces_as_one_node():
+    """What the registration is for: a function whose loss is the operator compiles with ``fullgraph=True`` (fake implementation for
+    the shapes, the registered autograd formula for the backward) and returns the eager path's loss and gradient bit for bit."""
+    from torchain_amd import ops  # noqa: F401
+    S, T = 4, 20
+    fst = synth.random_den_fst(256, 6, 100, seed=5)
+    graph = io.DenominatorGraph(fst, 100).prepare(DEV)
+    sup = io.Supervision.from_synth(synth.random_supervision(fst, S, T, 3, seed=9, initial_probs=graph.initial_probs()))
+    x = torch.from_numpy(synth.random_nnet_output(S, T, 100, seed=10)).to(DEV)
+    gp, sp = int(graph.ptr.value), int(sup.ptr.value)
+
+    def step(a):
+        out, _grad, _xgrad = torch.ops.torchain_amd.chain_step(a, a.new_empty((0,)), gp, sp, 5e-5, 0.1, 0.0, True, True)
+        return out[3]
+
+    a = x.clone().requires_grad_(True)
+    loss = torch.compile(step, backend="aot_eager", fullgraph=True)(a)
+    loss.backward()
+    b = x.clone().requires_grad_(True)
+    ref, _ = chain_loss(b, graph, sup, 5e-5, 0.1)
+    ref.backward()
+    assert float(loss.detach()) == float(ref.detach()) and torch.equal(a.grad, b.grad)
