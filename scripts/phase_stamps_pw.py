@@ -26,7 +26,13 @@ ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
 stream = torch.cuda.current_stream()
 a256 = lambda x: (x + 255) & ~255
 Hs = 4096 * ((fst.num_states + 4095) // 4096)
-off = a256((T + 2) * S * Hs * 4) + 4 * a256(S * 8) + 2 * a256(S * 4) + 256
+# the stamp area is the workspace's `scalar` block (csrc/api.cpp: carve): behind the history, the frame sums, the split-source
+# scratch rows of graphs beyond 28672 positions, the per-sequence doubles and floats and the failure flag
+planes = Hs // 4096
+split = 0
+if Hs > 28672:
+    split = a256(2 * S * 4096 * (planes - (planes + 1) // 2) * 4) + a256(2 * S * (Hs + 4096 * ((planes + 1) // 2)) * 4)
+off = a256((T + 1) * S * Hs * 4) + a256(S * ((T + 2 + 3) & ~3) * 4) + split + 4 * a256(S * 8) + 2 * a256(S * 4) + 256
 names = ["barrier", "secondary", "plane walks", "plane passes", "reduce+tail"]
 for _ in range(2):
     check(lib.tc_den_forward_backward(

@@ -51,7 +51,7 @@ int big_hb(const tc_den_graph *g) { return g->big ? g->big_hb : 0; }
 bool split_room(const tc_den_graph *g, int S) { return g->tied && !g->big && S <= kSplitMaxSeq; }
 // Tied on-chip graphs of at most 8192 positions may run two sequences per workgroup (den_tied_pair.hip): two more
 // history rows, the two roles' normalisers and the pairing words.
-// ... and the plane-wise kernel of 16385..28672 positions keeps one more history row (den_tied_planes.hip)
+// ... the plane-wise kernel of 16385..40960 positions (den_tied_planes.hip): scratch rows of its split-source form
 bool planes_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.planewise; }
 bool pair_room(const tc_den_graph *g) { return g->tied && !g->big && g->layout_ok && g->layout.JV == kJvSmall; }
 
@@ -66,8 +66,8 @@ Workspace carve(char *base, int Hs, int S, int T, int big_P = 0, int big_H = 0, 
     off += align256(bytes);
     return p;
   };
-  // (pair form: row T + 1 holds the backward role's B_M; plane-wise form: beta'_t of the running backward frame)
-  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair || planes ? 2 : 1)) * S * Hs * sizeof(float));
+  // (pair form: row T + 1 holds the backward role's B_M)
+  w.alpha_hist = (float *)take(big_P ? (size_t)(T + 1) * Sp * big_H * sizeof(float) : (size_t)(T + (pair ? 2 : 1)) * S * Hs * sizeof(float));
   w.asum_g = (float *)take((size_t)S * asum_stride(T) * sizeof(float));  // frame sums of utterances too long for LDS
   if (planes && Hs > kMaxPlanePositions) {
     const int planes_n = Hs / 4096, planes_b = planes_n - (planes_n + 1) / 2;
