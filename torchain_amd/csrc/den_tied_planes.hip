@@ -203,6 +203,9 @@ struct PlaneSeq {
 #ifndef TC_PW_HIST_AUX
 #define TC_PW_HIST_AUX 2  /* cache policy of the alpha history's stores (0: default, 2: nt: the backward pass is their next reader -- R4 8.04 -> 7.80 ms) */
 #endif
+#ifndef TC_PW_BWD_PRIO
+#define TC_PW_BWD_PRIO 0  /* 1: the backward walks run at issue priorities by wave age, youngest highest; 2: the forward walks too */
+#endif
 #ifndef TC_PW_AL_AUX
 #define TC_PW_AL_AUX 0  /* ... of the backward pass's first read of a history row (alpha_t in frame t) */
 #endif
@@ -615,6 +618,7 @@ struct PlaneSeq {
     }
     part = 0.f;
     float part_ab = 0.f, part_g = 0.f, part_u = 0.f;
+    if (TC_PW_BWD_PRIO) age_prio_on(wave);
     run_stream(q, [&](int j) __attribute__((always_inline)) {
       TC_STAMP(2)
       const u4 fs = fs_n;
@@ -640,6 +644,7 @@ struct PlaneSeq {
       if constexpr (SPLIT) sp.part_n = bld4(r_part, own16, (uint32_t)(j + 1 < planes ? j + 1 : j) * kPlane);
       TC_STAMP(3)
     }, SPLIT ? 1 : 0);
+    if (TC_PW_BWD_PRIO) __builtin_amdgcn_s_setprio(0);
     // beta'_t and the forward pdfs again, for the Y update behind the two barriers
     // y_{t-1} (at t == 0 frame 0 again) for the next frame's exp(y), y_t once more for the derivative row's l2 term (this CU
     // read it a frame ago: L2) -- requested here rather than held in registers through the walks
