@@ -109,50 +109,65 @@ def test_plane_wise_kernel_long_utterance(oracle, kernel_family):
         assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL, form
 
 
+def planes_fuzz_case(oracle, rng, split):
+    """One seeded case of the plane-wise kernel's sweep: random chain-structured graphs, graphs with hub states (secondary rows
+    folded per plane, or home rows cut longer), nearly chain-structured graphs the library splits, phone-LM structure; 1 to 5
+    sequences (two workgroups per sequence, or the fused kernel), 1 to 12 frames, through the full objective (tests/test_gpu_fuzz.py's
+    bounds).  ``split``: graphs of 28673..40960 positions (gather source in LDS a half at a time), else 16385..28672."""
+    from torchain_amd._lib import lib
+    kind = str(rng.choice(["tied", "hubs", "nearly", "phone_lm"]))
+    seed = int(rng.integers(0, 10000))
+    P = int(rng.choice([64, 700, 2928, 4096]))
+    lo, hi = (28700, 40900) if split else (16500, 28600)
+    if kind == "tied":
+        fst = synth.random_den_fst(int(rng.integers(lo, hi)), int(rng.integers(2, 7)), P, seed=seed)
+    elif kind == "hubs":
+        H = int(rng.integers(lo, hi - 1600))
+        fst = synth.skewed_tied_den_fst(H, H * int(rng.integers(3, 8)), P, seed=seed, hub_fraction=float(rng.choice([0.002, 0.01])))
+    elif kind == "nearly":
+        nlo, nhi = (15200, 19000) if split else (9000, 13000)  # (states before the library splits them)
+        fst = synth.nearly_tied_den_fst(int(rng.integers(nlo, nhi)), int(rng.integers(3, 6)), P, seed=seed, fraction=float(rng.uniform(0.3, 0.8)))
+    else:
+        hlo, hhi = (2600, 3300) if split else (1500, 2300)
+        fst = synth.phone_lm_den_fst(num_histories=int(rng.integers(hlo, hhi)), branching=int(rng.integers(9, 13)), num_pdfs=max(P, 200), seed=seed)
+    S, T = int(rng.integers(1, 6)), int(rng.integers(1, 13))
+    leaky, l2 = float(rng.choice([1e-5, 0.05, 0.2])), float(rng.choice([0.0, 1e-4]))
+    fused = bool(rng.integers(0, 2))
+    lib.tc_debug_set(b"no_phase_split", 1 if fused else 0)
+    try:
+        g = oracle.DenGraph(fst)
+        sup = synth.random_supervision(fst, S, T, 2, seed=seed + 1, initial_probs=g.initial_probs())
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=seed + 2, scale=float(rng.choice([1.0, 3.0])))
+        ref = oracle.compute_chain_objf_and_deriv(g, sup, y, l2, leaky, want_xent=True)
+        out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True)
+    finally:
+        lib.tc_debug_set(b"no_phase_split", 0)
+    st = out["graph"].stats()
+    res = out["results"]
+    e_obj = abs(res[0] - ref["objf"]) / max(abs(ref["objf"]), 0.05 * S * T)
+    e_der, e_x = rel_err(out["deriv"], ref["deriv"], floor=1.0), rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0)
+    desc = "%s H=%d A=%d P=%d S=%d T=%d leaky=%g l2=%g fused=%d kernel=%d lds=%d: objf %.1e deriv %.1e xent %.1e" % (
+        kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, fused, st["tied"], st["lds_bytes"], e_obj, e_der, e_x)
+    assert e_obj <= REL and e_der <= REL and e_x <= REL and res[2] == ref["weight"], desc
+    # (seven planes fit the LDS only beside at most ~3000 pdfs: 112 KB of gather source + exp(y) + gamma + 16 KB of row sums)
+    if kind in ("tied", "phone_lm") and fst.num_pdfs <= 4096 and (16384 < fst.num_states <= 24576 or 28672 < fst.num_states <= 40960):
+        assert st["tied"] == 1, desc  # (on chip: the plane-wise kernel)
+    return desc
+
+
 @pytest.mark.parametrize("chunk", range(4))
 def test_plane_wise_kernel_fuzz(oracle, chunk):
-    """Seeded sweep over the plane-wise kernel's graphs: random chain-structured graphs, graphs with hub states (secondary
-    rows folded per plane, or home rows cut longer), nearly chain-structured graphs the library splits into 16385..28672
-    positions, phone-LM structure; 5 to 7 planes, 1 to 5 sequences (two workgroups per sequence, or the fused kernel), 1 to 12
-    frames, through the full objective (tests/test_gpu_fuzz.py's bounds)."""
-    from torchain_amd._lib import lib
+    """Seeded sweep over the plane-wise kernel's graphs of 5 to 7 planes (planes_fuzz_case)."""
     rng = np.random.default_rng(4200 + chunk)
     for _ in range(6):
-        kind = str(rng.choice(["tied", "hubs", "nearly", "phone_lm"]))
-        seed = int(rng.integers(0, 10000))
-        P = int(rng.choice([64, 700, 2928, 4096]))
-        if kind == "tied":
-            fst = synth.random_den_fst(int(rng.integers(16500, 28600)), int(rng.integers(2, 7)), P, seed=seed)
-        elif kind == "hubs":
-            H = int(rng.integers(16500, 27000))
-            fst = synth.skewed_tied_den_fst(H, H * int(rng.integers(3, 8)), P, seed=seed, hub_fraction=float(rng.choice([0.002, 0.01])))
-        elif kind == "nearly":
-            fst = synth.nearly_tied_den_fst(int(rng.integers(9000, 13000)), int(rng.integers(3, 6)), P, seed=seed, fraction=float(rng.uniform(0.3, 0.8)))
-        else:
-            fst = synth.phone_lm_den_fst(num_histories=int(rng.integers(1500, 2300)), branching=int(rng.integers(9, 13)), num_pdfs=max(P, 200), seed=seed)
-        S, T = int(rng.integers(1, 6)), int(rng.integers(1, 13))
-        leaky, l2 = float(rng.choice([1e-5, 0.05, 0.2])), float(rng.choice([0.0, 1e-4]))
-        fused = bool(rng.integers(0, 2))
-        lib.tc_debug_set(b"no_phase_split", 1 if fused else 0)
-        try:
-            g = oracle.DenGraph(fst)
-            sup = synth.random_supervision(fst, S, T, 2, seed=seed + 1, initial_probs=g.initial_probs())
-            y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=seed + 2, scale=float(rng.choice([1.0, 3.0])))
-            ref = oracle.compute_chain_objf_and_deriv(g, sup, y, l2, leaky, want_xent=True)
-            out = hip_chain(fst, sup, y, l2=l2, leaky=leaky, xent=True)
-        finally:
-            lib.tc_debug_set(b"no_phase_split", 0)
-        st = out["graph"].stats()
-        desc = "%s H=%d A=%d P=%d S=%d T=%d leaky=%g l2=%g fused=%d kernel=%d lds=%d" % (
-            kind, fst.num_states, len(fst.src), fst.num_pdfs, S, T, leaky, l2, fused, st["tied"], st["lds_bytes"])
-        res = out["results"]
-        assert abs(res[0] - ref["objf"]) / max(abs(ref["objf"]), 0.05 * S * T) <= REL, desc
-        assert rel_err(out["deriv"], ref["deriv"], floor=1.0) <= REL, desc
-        assert rel_err(out["xent_deriv"], ref["xent_deriv"], floor=1.0) <= REL, desc
-        assert res[2] == ref["weight"], desc
-        # (seven planes fit the LDS only beside at most ~3000 pdfs: 112 KB of gather source + exp(y) + gamma + 16 KB of row sums)
-        if kind in ("tied", "phone_lm") and 16384 < fst.num_states <= 24576 and fst.num_pdfs <= 4096:
-            assert st["tied"] == 1, desc  # (on chip: the plane-wise kernel)
+        planes_fuzz_case(oracle, rng, split=False)
+
+
+def test_split_source_kernel_fuzz(oracle):
+    """... and of 8 to 10 planes (split gather source); a longer run of the same generator is logged in profiles/r06_fuzz_split.txt."""
+    rng = np.random.default_rng(4300)
+    for _ in range(4):
+        planes_fuzz_case(oracle, rng, split=True)
 
 
 def test_plane_wise_pairs_with_a_co_tenant():
