@@ -64,7 +64,8 @@ constexpr int kStreamUnrollTied = 8;  // tied streams: a wave's range is padded 
 // (den_tied_kernel.hip), which must exist whatever the graph
 constexpr int kTiedMinChunks = 6;
 constexpr int kMaxIndex = 1 << 14;
-// Tied graphs of 16385..28672 positions ("plane-wise" form of the owner-computes kernel, den_tied_planes.hip): the gather
+// Tied graphs of 16385..28672 positions ("plane-wise" form of the owner-computes kernel, den_tied_planes.hip; kJvPlanesSplit
+// below takes it to 40960): the gather
 // source alone takes 4 bytes per position of the CU's 160 KB, so a thread's 20-28 states are taken one float4 ("plane")
 // at a time -- walk the four rows of the plane, then its per-state pass -- and the row sums of all planes share four
 // rows per wave.  Cells carry positions (16 bits), not byte offsets.

@@ -1,4 +1,4 @@
-// Fused denominator forward-backward for TIED graphs of 16385..28672 positions on gfx950: the "plane-wise" form of
+// Fused denominator forward-backward for TIED graphs of 16385..40960 positions on gfx950: the "plane-wise" form of
 // den_tied_kernel.hip (same mapping: one workgroup = one sequence = one CU, owner-computes schedules, the per-state
 // formulas of den_tied_frames.h).  This is the size class of the den.fst the reference's recipe really loads (a pruned
 // phone LM with Kaldi's default 2000 extra LM states: example/chime5/train_faster.py:91 -> src/my_lib_example.cpp:129-134
@@ -24,7 +24,8 @@
 //   * the rest of the registers go to the stream: two chunk buffers in the fused kernel, three in the two-workgroup form.
 //     The history rows are stored `nt`: their next reader is the backward pass.
 //   * cells carry 16-bit POSITIONS (byte offset = one SDWA shift), one row-end byte per chunk.
-// One instantiation serves 5, 6 and 7 planes (the plane index is a wave-uniform run-time value).
+// One instantiation serves 5 and 6 planes, one 7 (the plane index is a wave-uniform run-time value), one 8 to 10: beyond 28672
+// positions the gather source is in LDS a half at a time and a frame is two walks (SPLIT, below).
 //
 // Batches of at most half the CUs run TWO workgroups per sequence that meet in the middle (den_tied_mitm.hip's scheme
 // with these frames): role F = the forward frame, from the meeting frame on forming gamma_{t-1} from the stored B_t;
