@@ -395,6 +395,8 @@ int tc_from2d(const float *in2d, int64_t in_stride, int32_t B, int32_t C, int32_
  *   "force_pair"     (1: the two-sequence kernel wherever it fits, whatever the batch and the graph's timing said)
  *   "no_mitm" / "force_mitm" (two CUs per sequence: never / always the form that meets in the middle instead of
  *                     two pure recursions and a combining pass; by default from 32 / 48 / 64 sequences by layout class)
+ *   "planes_meet_at" (M > 0: the two-workgroup form of the plane-wise kernel meets at frame M instead of T / 2 -- measured:
+ *                     T / 2 is the balanced choice, profiles/r06_planes_ab.txt)
  *   "exp_per_frame"  (1: the streamed path transposes exp(y) one frame at a time, as it does when all frames would take
  *                     more than 1 GB of workspace)
  * Read when a graph first reaches a device (tc_den_graph_prepare, see tc_den_graph_tuning):

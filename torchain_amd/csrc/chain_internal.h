@@ -464,8 +464,9 @@ extern thread_local int g_last_hip_error;
 // replace what used to be environment variables of the shipping library.
 // bumped whenever a round changes a kernel the per-graph choice is timed on (tuning_cache.cpp: part of the cache key)
 constexpr int kKernelGeneration = 6;
-enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgNoSplitSrc, kDbgCount };
+enum DebugFlag { kDbgForceGeneral = 0, kDbgForceStreamed, kDbgNoSplit, kDbgNoPdfBanks, kDbgNoBankSearch, kDbgSchedTrace, kDbgNoPhaseSplit, kDbgNoNumOverlap, kDbgNoPair, kDbgForcePair, kDbgNoTune, kDbgNoMitm, kDbgForceMitm, kDbgSlabWide, kDbgSlabNarrow, kDbgExpPerFrame, kDbgOldArrange, kDbgNoPlanes, kDbgOldGeneral, kDbgPhantomPdf0, kDbgNoPdfSearch, kDbgNoSplitSrc, kDbgPlanesMeetAt, kDbgCount };
 bool debug_flag(DebugFlag f);
+int debug_value(DebugFlag f);  // the switch's integer value (0: not set)
 
 int pool_acquire(int device, size_t bytes, PoolSlot **out);                      // supervision.cpp
 void pool_release(int device, PoolSlot *slot);

@@ -95,6 +95,7 @@ int side_streams(hipStream_t stream, SideStreams **out) {
 
 static std::atomic<int> g_debug[kDbgCount];
 bool debug_flag(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed) != 0; }
+int debug_value(DebugFlag f) { return g_debug[f].load(std::memory_order_relaxed); }
 static std::atomic<int64_t> g_launches[kCntCount];
 void count_launch(LaunchCounter c) { g_launches[c].fetch_add(1, std::memory_order_relaxed); }
 
@@ -425,7 +426,7 @@ extern "C" {
 int tc_debug_set(const char *key, int value) {
   static const char *const names[kDbgCount] = {"force_general", "force_streamed", "no_split", "no_pdf_banks",
                                                "no_bank_search", "sched_trace", "no_phase_split", "no_num_overlap", "no_pair",
-                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search", "no_split_source"};
+                                               "force_pair", "no_tune", "no_mitm", "force_mitm", "slab_wide", "slab_narrow", "exp_per_frame", "old_arrange", "no_planes", "old_general", "phantom_pdf0", "no_pdf_search", "no_split_source", "planes_meet_at"};
   if (!key) return TC_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < kDbgCount; ++i)
     if (!strcmp(key, names[i])) {

@@ -801,6 +801,7 @@ int launch_den_tied_planes_mitm(const DenParams &p, int accumulate, hipStream_t 
   MitmParams q;
   q.sync = p.mitm_sync;
   q.M = p.T / 2;
+  if (const int m = debug_value(kDbgPlanesMeetAt)) q.M = std::min(std::max(m, 1), p.T - 1);  // (diagnostic: the meeting frame)
   q.aScr = (uint32_t)layout_lds_bytes(p.L, p.T);
   TC_HIP_CHECK(hipMemsetAsync(p.mitm_sync, 0, mitm_sync_bytes(p.S), stream));
   void (*k)(const DenParams, const MitmParams) = nullptr;
