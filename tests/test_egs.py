@@ -286,6 +286,16 @@ def test_reference_batch_order(tmp_path):
                 p.reset()
             rd.reset()
         assert sorted(k for b in got for k in b) == sorted(k for k, _ in keyed)
+    # without a length file the reference reads the lengths from the egs in scp order (src/my_lib_example_rand.cpp:95-110): the same
+    # lists as with a length file written in that order
+    os.rename(scp + ".len", scp + ".len.away")
+    in_scp_order = str(tmp_path / "scp_order.len")
+    with open(in_scp_order, "w") as f:
+        f.write("".join("%s %d\n" % (k, L) for (k, _), L in zip(keyed, lengths)))
+    want0 = [line.partition(":")[2].split() for line in subprocess.check_output([exe, in_scp_order, "9", "3", "1"], text=True).splitlines()]
+    rd = io.RandExample(scp, seed=9, batchsize=3, prefetch=False, order="reference")
+    assert [rd.batch_keys(i) for i in range(rd.n_batch)] == want0
+    os.rename(scp + ".len.away", scp + ".len")
     # the default order is another one: lengths ascending
     first, ref = io.RandExample(scp, seed=1, batchsize=3, prefetch=False), io.RandExample(scp, seed=1, batchsize=3, prefetch=False, order="reference")
     assert first.n_batch == ref.n_batch and [first.batch_keys(i) for i in range(first.n_batch)] != [ref.batch_keys(i) for i in range(ref.n_batch)]

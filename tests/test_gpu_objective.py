@@ -235,3 +235,19 @@ def test_native_self_test_entry():
     assert rc == 0, (rc, list(rep))
     assert weight == 0.5 * 3 * 9 and objf < 0 and l2_term == 0.0
     assert worst_row <= 1e-4 and abs(observed - predicted) <= 0.1 * abs(predicted) + 1e-4 and predicted != 0.0
+
+
+def test_objective_without_derivatives_through_the_plain_entry_point(oracle):
+    """``tc_chain_objf_and_deriv`` with ``nnet_output_deriv == NULL`` ([K] ``ComputeChainObjfAndDeriv``'s own optional argument; the
+    evaluation step of ``tc_chain_step`` is the same computation): results equal to the call with derivatives, on a small and a
+    plane-wise graph, in the fused and the two-workgroup forms the derivative call takes."""
+    for fst, S, T in ((synth.random_den_fst(300, 5, 90, seed=3), 6, 11), (synth.random_den_fst(17000, 3, 500, seed=4), 3, 7)):
+        g = oracle.DenGraph(fst)
+        sup = synth.random_supervision(fst, S, T, 2, seed=8, initial_probs=g.initial_probs())
+        y = synth.random_nnet_output(S, T, fst.num_pdfs, seed=9)
+        ref = oracle.compute_chain_objf_and_deriv(g, sup, y, 1e-4, 0.1)
+        full = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1)
+        none = hip_chain(fst, sup, y, l2=1e-4, leaky=0.1, want_deriv=False, graph=full["graph"])
+        assert none["deriv"] is None
+        np.testing.assert_allclose(none["results"], full["results"], rtol=1e-6)
+        assert abs(none["results"][0] - ref["objf"]) <= REL * abs(ref["objf"]) and none["results"][2] == ref["weight"]
