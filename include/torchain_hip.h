@@ -233,9 +233,13 @@ int64_t tc_chain_workspace_bytes(const tc_den_graph *graph, int32_t num_sequence
  * and on NaN/inf or a failed alpha.beta check: deriv = xent_deriv = 0, objf = -10*weight.
  * results_dev3 is DEVICE memory for {objf, l2_term, weight} (the reference writes a CPU
  * THFloatTensor, src/my_lib_chain.cpp:126,130; the host wrapper copies the 12 bytes).
- * Stream capture: tc_den_forward_backward may be captured in a HIP graph (tested); this call may not -- it orders
- * itself behind the supervision's upload with an event from outside the capture, and a supervision is new with
- * every minibatch anyway. */
+ * Stream capture: this call, tc_chain_objf_and_grad, tc_chain_step and tc_den_forward_backward may be captured in a HIP
+ * graph (tested: tests/test_gpu_step.py, tests/test_gpu_tied.py).  Warm the call up once outside the capture (per-device
+ * tables, pools and side streams are created on first use).  Inside a capture the supervision's upload becomes a node of
+ * the graph -- every replay copies its tables again from the library's pinned block -- and none of the library's events
+ * is waited for or recorded on the capturing stream except the fork / join pair of its own side streams; the caller keeps
+ * graph, supervision and workspace alive for as long as the graph may be replayed.  (A supervision is new with every
+ * minibatch, so a captured TRAINING step is a benchmark's tool; DESIGN.md 7 has what replay saves: host time only.) */
 int tc_chain_objf_and_deriv(tc_den_graph *graph, tc_supervision *supervision, const float *nnet_output,
                             int64_t num_rows, int32_t num_cols, int64_t row_stride, float *results_dev3,
                             float *nnet_output_deriv, int64_t deriv_stride, float *xent_output_deriv,

@@ -420,3 +420,55 @@ def test_registered_operator_traces_as_one_node():
     ref, _ = chain_loss(b, graph, sup, 5e-5, 0.1)
     ref.backward()
     assert float(loss.detach()) == float(ref.detach()) and torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("three_d", [False, True])
+def test_training_step_replays_from_a_captured_graph(three_d):
+    """The captured step: ``chain_loss`` with the xent branch + the backward, captured once into a
+    ``torch.cuda.CUDAGraph`` -- the library's side streams fork from and join the capturing stream, its pools are warm, nothing in the
+    call reads the device -- and replayed on new activations: loss and both gradients bit-identical to the direct call's."""
+    S, T = 8, 30
+    cfg, graph, sup, y2d = _workload("C2", S, T)
+    kw = dict(l2_regularize=5e-5, leaky_hmm_coefficient=cfg["leaky"], xent_regularize=0.1, kaldi_way=True)
+    x = (_as_bct(y2d, S, T) if three_d else y2d).clone().requires_grad_(True)
+    xe = (0.5 * x.detach()).clone().requires_grad_(True)
+
+    seen = []
+
+    def step():
+        loss, results = chain_loss(x, graph, sup, xent_input=xe, **kw)
+        g, gx = torch.autograd.grad(loss, (x, xe))
+        seen.append(results)
+        return loss.detach(), g, gx
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()  # warm-up outside the capture: tables, pools, side streams
+    side.synchronize()
+    before = _counters()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg, stream=side):
+        captured = step()
+    assert _delta(before)["den_launches"] == 1  # (captured, not run)
+    captured_results = seen[-1]
+    for seed in (21, 22):
+        fresh = torch.randn(x.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        with torch.no_grad():
+            x.copy_(fresh)
+            xe.copy_(0.25 * fresh)
+        before = _counters()
+        cg.replay()
+        torch.cuda.synchronize()
+        assert _delta(before)["den_launches"] == 0  # no library call: the graph's own nodes ran
+        got = [t.clone() for t in captured]
+        captured_results.invalidate()  # the replay wrote new values behind it
+        got_results = captured_results.data.clone(), captured_results.xent_objf
+        want = step()
+        torch.cuda.synchronize()
+        assert torch.equal(got_results[0], seen[-1].data) and got_results[1] == seen[-1].xent_objf
+        assert abs(float(got[0]) + float(got_results[0][0]) / float(got_results[0][2])) <= 1e-6 * abs(float(got[0]))
+        assert bool(torch.isfinite(got[0]).all()) and float(got[1].abs().max()) > 0
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)

@@ -125,6 +125,10 @@ int supervision_mark_use(tc_supervision *sup, int device, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(sup->mu);
   auto it = sup->dev.find(device);
   if (it == sup->dev.end()) return TC_OK;
+  // (not inside a graph capture: the event would become a captured one, useless to the pool's queries.  Whoever keeps the
+  // graph keeps the supervision alive for as long as it may be replayed -- include/torchain_hip.h, "stream capture")
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive) return TC_OK;
   TC_HIP_CHECK(hipEventRecord(it->second.slot->done, stream));
   return TC_OK;
 }
@@ -386,7 +390,14 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   std::lock_guard<std::mutex> lock(sup->mu);
   auto it = sup->dev.find(device);
-  if (it != sup->dev.end() && it->second.uploaded) {
+  // A stream that is being captured into a graph can neither wait for nor ask about an event of this library: HIP counts
+  // an event last recorded on that stream BEFORE the capture began as a captured one (hipStreamWaitEvent:
+  // hipErrorStreamCaptureIsolation; hipEventSynchronize / hipEventQuery: hipErrorCapturedEvent, and the capture is
+  // invalidated).  So inside a capture the upload is a node of the graph itself -- every replay copies the tables again
+  // from the slot's own pinned block, ordered before the kernels that read them by the graph -- and no event is touched.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive;
+  if (it != sup->dev.end() && it->second.uploaded && !capturing) {
     // uploaded earlier, possibly on another stream: order this stream behind the copy
     TC_HIP_CHECK(hipStreamWaitEvent(stream, it->second.slot->ready, 0));
     return TC_OK;
@@ -398,6 +409,11 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
   }
   PoolSlot *slot = it->second.slot;
   hipError_t e = hipMemcpyAsync(slot->blob, slot->host, it->second.upload_bytes, hipMemcpyHostToDevice, stream);
+  if (capturing) {
+    // (the supervision's state for calls outside the graph is left as it was)
+    TC_HIP_CHECK(e);
+    return TC_OK;
+  }
   if (e == hipSuccess) e = hipEventRecord(slot->ready, stream);
   if (e == hipSuccess) e = hipEventRecord(slot->done, stream);  // (moved forward by every launch that reads the slot)
   if (e != hipSuccess) {

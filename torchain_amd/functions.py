@@ -54,6 +54,14 @@ class ChainResults:
             self._stale = False
         return self._host
 
+    def invalidate(self):
+        """The device-side values changed behind this object -- a captured graph holding the step was replayed: the next
+        read of ``data`` / ``xent_objf`` copies them again (on the current stream, behind the replay)."""
+        if self._dev is not None:
+            self._stale = True
+        if self._xent_dev is not None:
+            self._xent_host = None
+
     @data.setter
     def data(self, value):
         self._host = value
@@ -343,7 +351,9 @@ def _run_step(input, xent_input, results, den_graph, supervision, l2_regularize,
             if nbytes < 0:
                 check(int(nbytes), "tc_chain_step_workspace_bytes")
             sizes[key] = nbytes
-        ws = _workspace(device, cur.cuda_stream, nbytes)
+        capturing = torch.cuda.is_current_stream_capturing()
+        # (inside a graph capture the workspace comes from the graph's own pool and lives as long as the graph does)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device) if capturing else _workspace(device, cur.cuda_stream, nbytes)
         out = torch.empty(6, dtype=torch.float32, device=device)  # objf, l2_term, weight | loss | xent objective (f64)
         rc = lib.tc_chain_step(den_ptr, sup_ptr, _ptr(x), _ptr(xe), int(three_d), 0 if three_d else x.stride(0),
                                float(l2_regularize), float(leaky_hmm_coefficient), float(xent_regularize),
@@ -353,8 +363,12 @@ def _run_step(input, xent_input, results, den_graph, supervision, l2_regularize,
         check(rc, "tc_chain_step")
         results._dev = out[:3]
         results._stale = True
-        results._ready = torch.cuda.Event()
-        results._ready.record(cur)
+        results._ready = None
+        if capturing:
+            results._graph_keeps = ws  # replays write through it; read the values after a replay with ``invalidate()``
+        else:
+            results._ready = torch.cuda.Event()
+            results._ready.record(cur)
         if use_xent:
             results._xent_dev = out[4:6].view(torch.float64)
             results._xent_ready = results._ready
