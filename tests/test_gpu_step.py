@@ -453,6 +453,19 @@ def test_training_step_replays_from_a_captured_graph(three_d):
         captured = step()
     assert _delta(before)["den_launches"] == 1  # (captured, not run)
     captured_results = seen[-1]
+    # a supervision the library has not seen before the capture: staged and uploaded by a node of the graph
+    if not three_d:
+        sup2 = io.Supervision.from_synth(synth.random_supervision(synth.config_den_fst("C2"), S, T, 3, seed=77,
+                                                                  initial_probs=graph.initial_probs()))
+        cg2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg2, stream=side):
+            loss2, _ = chain_loss(x, graph, sup2, xent_input=xe, **kw)
+            g2 = torch.autograd.grad(loss2, x)[0]
+        cg2.replay()
+        torch.cuda.synchronize()
+        got2 = g2.clone()
+        want_loss2, _ = chain_loss(x, graph, sup2, xent_input=xe, **kw)
+        assert torch.equal(got2, torch.autograd.grad(want_loss2, x)[0])
     for seed in (21, 22):
         fresh = torch.randn(x.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
         with torch.no_grad():

@@ -403,7 +403,11 @@ int tc_supervision_prepare(tc_supervision *sup, int device, void *stream_v) {
     return TC_OK;
   }
   if (it == sup->dev.end()) {
+    // (a pool that has to grow allocates: allowed during somebody's capture only in the relaxed mode)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (capturing) TC_HIP_CHECK(hipThreadExchangeStreamCaptureMode(&mode));
     const int rc = stage_locked(sup, device);
+    if (capturing) (void)hipThreadExchangeStreamCaptureMode(&mode);
     if (rc != TC_OK) return rc;
     it = sup->dev.find(device);
   }
